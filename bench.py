@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""bench.py - BASELINE.json's metric on its own config.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one MPM substep (grid update -> fused G2P2G -> sparse partition rebuild [-> halo exchange for
+N > 1]) over one synthetic scene.  N = 1 runs BASELINE config 3, the configuration the metric is quoted on:
+the 40.1 M-particle Drucker-Prager sand column on a 512^3 sparse grid (`configs[2]`); N > 1 keeps the total
+work fixed (strong scaling, MGSP static particle partition: equal-count slabs of the initial lattice, one
+rank per GPU over RCCL).  Inputs are resident in HBM before the timed region; value = particles * K / time.
+
+Extra objects on the JSON line:
+  roofline     - G2P2G (the dominant kernel): algorithmic bytes per launch (144 B/particle
+                 for sand) / average kernel duration from HIP events on the engine's compute stream, vs 8 TB/s
+  cpu_baseline - the CPU oracle ("port" of the reference pipeline, serial) timed on this host on a bounded,
+                 geometrically similar sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+BYTES_PER_PARTICLE = {0: 72, 1: 136, 2: 144, 3: 144}  # BASELINE.md section 4 / SURVEY.md 8(d)
+HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_scene(args):
+    from claymore_amd import scenes
+    if args.scene == "sand40m":
+        sc = scenes.sand_column(9) if args.fraction >= 1.0 else scenes.scaled_sand_column(9, args.fraction)
+        name = "C3 sand column collapse (Drucker-Prager), 512^3 sparse grid"
+    elif args.scene == "sphere5m":
+        sc = scenes.sphere_drop()
+        name = "C2 elastic sphere drop (fixed-corotated), 256^3 sparse grid"
+    elif args.scene == "spheres50k":
+        sc = scenes.two_spheres()
+        name = "C1 two elastic spheres, 128^3 grid"
+    else:
+        raise SystemExit(f"unknown scene {args.scene}")
+    return sc, name
+
+
+def cpu_baseline(args):
+    """Serial CPU oracle on a bounded sample (about 10-30 s of CPU work)."""
+    import __graft_entry__ as g
+    g.build_oracle()
+    from claymore_amd import scenes
+    from claymore_amd.engine import build_engine
+    from oracle_ffi import oracle_api
+    if args.scene == "sand40m":
+        frac = 1.0 / 64.0
+        sc = scenes.scaled_sand_column(9, frac)
+        sample = f"sand column scaled to {scenes.total_particles(sc)} particles (1/64 of C3, same aspect ratio, 512^3 grid)"
+    elif args.scene == "sphere5m":
+        sc = scenes.sphere_drop(radius_cells=20.0)
+        sample = f"elastic sphere R=20dx, {scenes.total_particles(sc)} particles, 256^3 grid"
+    else:
+        sc = scenes.two_spheres()
+        sample = "the full C1 scene"
+    n = scenes.total_particles(sc)
+    eng = build_engine(sc, api=oracle_api())
+    eng.initial_setup()
+    eng.run_fixed(1, sc["dt"])  # warm
+    steps = max(2, min(20, int(12e6 / n)))
+    t0 = time.perf_counter()
+    eng.run_fixed(steps, sc["dt"])
+    dt = time.perf_counter() - t0
+    eng.close()
+    return {"value": n * steps / dt, "unit": "particles*steps/s", "cores": 1, "kind": "port",
+            "sample": f"{sample}, {steps} substeps, serial C oracle (oracle/mpm_oracle.c), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scene", default="sand40m", choices=["sand40m", "sphere5m", "spheres50k"])
+    ap.add_argument("--fraction", type=float, default=1.0, help="debug: shrink the sand column")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as g
+    if rank == 0:
+        g.build_hip()
+    if world > 1:
+        dist.barrier()
+
+    from claymore_amd import scenes
+    sc, workload = make_scene(args)
+    n_total = scenes.total_particles(sc)
+    material = sc["models"][0]["material"]
+    dt = sc["dt"]
+
+    if world == 1:
+        from claymore_amd.engine import build_engine
+        eng = build_engine(sc, device=local_rank)
+        eng.initial_setup()
+        eng.run_fixed(args.warmup, dt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.run_fixed(args.steps, dt)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        tm = eng.timers()
+        g2p2g_ms = tm.g2p2g_ms
+        phases = {"grid_update_ms": tm.grid_update_ms, "g2p2g_ms": tm.g2p2g_ms, "partition_ms": tm.partition_ms,
+                  "device_total_ms": tm.total_ms}
+        cnt = eng.counts()
+        blocks = {"particle": cnt.particle_blocks, "neighbor": cnt.neighbor_blocks, "exterior": cnt.exterior_blocks}
+        n_rank = n_total
+        eng.close()
+    else:
+        from claymore_amd.mgsp import MgspRank
+        sim = MgspRank(sc, rank, world, device=local_rank)
+        sim.initial_setup()
+        sim.run_fixed(args.warmup, dt)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sim.run_fixed(args.steps, dt)
+        torch.cuda.synchronize()
+        dist.barrier()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        g2p2g_ms = sim.g2p2g_ms_avg
+        phases = sim.phase_ms()
+        blocks = sim.block_counts()
+        n_rank = sim.n_local
+        sim.close()
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = n_total * args.steps / elapsed
+        bpp = BYTES_PER_PARTICLE[material]
+        achieved = (n_rank * bpp) / (g2p2g_ms * 1e-3) / 1e9 if g2p2g_ms > 0 else 0.0
+        out = {
+            "metric": "particles*steps/sec", "value": value, "unit": "particles*steps/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "particles": n_total, "dt": dt,
+                       "parallelism": "single GPU" if world == 1 else f"mgsp static particle partition x{world}",
+                       "blocks": blocks, "phases_ms": phases},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "g2p2g_kernel", "bytes_per_particle": bpp, "particles_per_launch": n_rank,
+                         "kernel_ms": g2p2g_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,757 @@
+// claymore_hip.hip — host side of libclaymore_hip.so: the C ABI of include/claymore_amd.h on top of the gfx950
+// kernels in mpm_kernels.hpp.  One context = one HIP device, two streams (compute, comm), all buffers owned here.
+// Replaces the launch/orchestration part of GmpmSimulator (Projects/GMPM/gmpm_simulator.cuh:283-781) and the thin
+// CUDA wrapper it sits on (Library/MnSystem/Cuda/Cuda.h, Cuda.cu).  No CPU fallback: every path needs a GPU.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/claymore_amd.h"
+#include "mpm_kernels.hpp"
+
+using namespace mpm;
+
+namespace {
+
+struct Partition {
+	int* table = nullptr;
+	int* keys  = nullptr;
+	int* count = nullptr;
+};
+
+struct Model {
+	int material = 0;
+	int nch		 = 0;
+	mpm_material_params p {};
+	MaterialConst mc {};
+	size_t n	 = 0;
+	float* d_xyz = nullptr;// initial particle array; also the staging buffer of retrieve
+	float v0[3]	 = {0, 0, 0};
+	float* bins[2]	 = {nullptr, nullptr};
+	size_t bin_cap	 = 0;
+	int* binoff[2]	 = {nullptr, nullptr};
+	int* list[2]	 = {nullptr, nullptr};
+	int* size		 = nullptr;
+	int* row_of		 = nullptr;
+	int* out_count	 = nullptr;
+	int64_t bincount = 0;
+	int list_in		 = 0;// which list buffer g2p2g reads next
+};
+
+}// namespace
+
+struct mpm_ctx {
+	mpm_config cfg {};
+	GridCfg g {};
+	int device = 0;
+	hipStream_t s_compute = nullptr, s_comm = nullptr;
+	hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_g0 = nullptr, ev_g1 = nullptr, ev_comm = nullptr;
+	Partition part[2];
+	float* grid[2] = {nullptr, nullptr};
+	int rollid	   = 0;
+	int pbc = 0, nbc = 0, ebc = 0;
+	std::vector<Model> models;
+	int* d_status		  = nullptr;// ST_WORDS ints
+	int* h_status		  = nullptr;// pinned
+	unsigned* d_maxvel	  = nullptr;
+	float* h_maxvel		  = nullptr;// pinned
+	double* d_totals	  = nullptr;
+	unsigned long long* d_counter = nullptr;
+	bool ready = false;
+	mpm_timers timers {};
+	float last_g2p2g_ms = 0.f;
+	// halo state (MGSP)
+	int* d_overlap	   = nullptr;// per neighbour block: bit mask of peers that also own it
+	int* d_halo_list   = nullptr;// particle blocks touching an overlap block
+	int* d_inner_list  = nullptr;
+	int* d_halo_counts = nullptr;// [0]=halo blocks, [1]=interior blocks, [2+peer]=send count for peer
+	int* d_send_ids[32] = {nullptr};
+	int n_halo = 0, n_inner = 0;
+	int send_count[32] = {0};
+	std::string err;
+};
+
+#define HIP_TRY(expr)                                                                                            \
+	do {                                                                                                         \
+		hipError_t e_ = (expr);                                                                                  \
+		if(e_ != hipSuccess) {                                                                                   \
+			ctx->err = std::string(#expr) + " -> " + hipGetErrorString(e_) + " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"; \
+			return MPM_ERR_DEVICE;                                                                               \
+		}                                                                                                        \
+	} while(0)
+
+static int fail(mpm_ctx* ctx, int code, const std::string& msg) {
+	ctx->err = msg;
+	return code;
+}
+
+template<typename T>
+static hipError_t dalloc(T** p, size_t n) {
+	return hipMalloc((void**) p, sizeof(T) * (n ? n : 1));
+}
+
+static inline unsigned cdiv(size_t a, size_t b) {
+	return (unsigned) ((a + b - 1) / b);
+}
+
+extern "C" {
+
+int mpm_default_config(int domain_bits, mpm_config* cfg) {
+	if(!cfg || domain_bits < 4 || domain_bits > 10) return MPM_ERR_INVALID;
+	memset(cfg, 0, sizeof(*cfg));
+	cfg->domain_bits	 = domain_bits;
+	cfg->max_ppc		 = 128;	  // settings.h:75
+	cfg->boundary_blocks = 2;	  // settings.h:63
+	cfg->gravity		 = -9.8f; // settings.h:85
+	cfg->cfl			 = 0.5f;  // settings.h:53
+	cfg->max_blocks		 = 0;
+	return MPM_OK;
+}
+
+int mpm_default_material(int material, int domain_bits, mpm_material_params* p) {
+	if(!p) return MPM_ERR_INVALID;
+	memset(p, 0, sizeof(*p));
+	const float n	  = (float) (1u << domain_bits);
+	p->rho			  = 1e3f;// settings.h:81-83
+	p->youngs_modulus = 5e3f;
+	p->poisson_ratio  = 0.4f;
+	const float vol1  = 1.0f / n / n / n / 8.0f;
+	const float vol10 = 10.f / n / n / n / 8.0f;// particle_buffer.cuh:176,:203 (sic)
+	switch(material) {
+		case MPM_J_FLUID:
+			p->volume	 = vol1;
+			p->bulk		 = 4e4f;
+			p->gamma	 = 7.15f;
+			p->viscosity = 0.01f;
+			break;
+		case MPM_FIXED_COROTATED: p->volume = vol10; break;
+		case MPM_SAND:
+			p->volume			 = vol10;
+			p->cohesion			 = 0.f;
+			p->beta				 = 1.f;
+			p->yield_surface	 = 0.816496580927726f * 2.f * 0.5f / (3.f - 0.5f);
+			p->volume_correction = 1;
+			p->log_jp0			 = 0.f;
+			break;
+		case MPM_NACC:
+			p->volume		= vol1;
+			p->xi			= 0.8f;
+			p->beta			= 0.5f;
+			p->msqr			= 3.423772074299613f;
+			p->hardening_on = 1;
+			p->log_jp0		= -0.01f;
+			break;
+		default: return MPM_ERR_INVALID;
+	}
+	return MPM_OK;
+}
+
+static MaterialConst make_material_const(const mpm_material_params& p) {
+	MaterialConst mc {};
+	const float e = p.youngs_modulus, nu = p.poisson_ratio;
+	mc.volume			 = p.volume;
+	mc.mass				 = p.volume * p.rho;						  // particle_buffer.cuh:158,:186,:252
+	mc.lambda			 = e * nu / ((1 + nu) * (1 - 2 * nu));		  // :187
+	mc.mu				 = e / (2 * (1 + nu));						  // :188
+	mc.bm				 = 2.f / 3.f * (e / (2 * (1 + nu))) + (e * nu / ((1 + nu) * (1 - 2 * nu)));// :255
+	mc.bulk				 = p.bulk;
+	mc.gamma			 = p.gamma;
+	mc.viscosity		 = p.viscosity;
+	mc.cohesion			 = p.cohesion;
+	mc.beta				 = p.beta;
+	mc.yield_surface	 = p.yield_surface;
+	mc.xi				 = p.xi;
+	mc.msqr				 = p.msqr;
+	mc.log_jp0			 = p.log_jp0;
+	mc.volume_correction = p.volume_correction;
+	mc.hardening_on		 = p.hardening_on;
+	return mc;
+}
+
+int mpm_create(const mpm_config* cfg, int device, mpm_ctx** out) {
+	if(!cfg || !out) return MPM_ERR_INVALID;
+	if(cfg->domain_bits < 4 || cfg->domain_bits > 10) return MPM_ERR_INVALID;
+	if(cfg->max_ppc < 1 || cfg->max_ppc > 128 || (cfg->max_ppc & (cfg->max_ppc - 1))) return MPM_ERR_INVALID;
+	int ndev = 0;
+	if(hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || device < 0 || device >= ndev) {
+		fprintf(stderr, "claymore_hip: no usable HIP device %d (found %d) - there is no CPU fallback\n", device, ndev);
+		return MPM_ERR_DEVICE;
+	}
+	mpm_ctx* ctx = new mpm_ctx();
+	ctx->cfg	 = *cfg;
+	ctx->device	 = device;
+	GridCfg& g	 = ctx->g;
+	g.gbits		 = cfg->domain_bits - 2;
+	g.G			 = 1 << g.gbits;
+	g.ppb		 = cfg->max_ppc * 64;
+	g.pid_bits	 = 0;
+	while((1 << g.pid_bits) < g.ppb) g.pid_bits++;
+	g.boundary = cfg->boundary_blocks;
+	g.dx_inv   = (float) (1 << cfg->domain_bits);
+	g.dx	   = 1.f / g.dx_inv;
+	g.d_inv	   = 4.f * g.dx_inv * g.dx_inv;
+	g.gravity  = cfg->gravity;
+	g.cap	   = 0;
+	if(hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->s_compute, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ctx->s_comm, hipStreamNonBlocking) != hipSuccess) {
+		delete ctx;
+		return MPM_ERR_DEVICE;
+	}
+	hipEventCreate(&ctx->ev_a);
+	hipEventCreate(&ctx->ev_b);
+	hipEventCreate(&ctx->ev_g0);
+	hipEventCreate(&ctx->ev_g1);
+	hipEventCreateWithFlags(&ctx->ev_comm, hipEventDisableTiming);
+	*out = ctx;
+	return MPM_OK;
+}
+
+void mpm_destroy(mpm_ctx* ctx) {
+	if(!ctx) return;
+	hipSetDevice(ctx->device);
+	hipDeviceSynchronize();
+	for(int i = 0; i < 2; ++i) {
+		hipFree(ctx->part[i].table);
+		hipFree(ctx->part[i].keys);
+		hipFree(ctx->part[i].count);
+		hipFree(ctx->grid[i]);
+	}
+	for(auto& m: ctx->models) {
+		hipFree(m.d_xyz);
+		for(int i = 0; i < 2; ++i) {
+			hipFree(m.bins[i]);
+			hipFree(m.binoff[i]);
+			hipFree(m.list[i]);
+		}
+		hipFree(m.size);
+		hipFree(m.row_of);
+		hipFree(m.out_count);
+	}
+	hipFree(ctx->d_status);
+	hipFree(ctx->d_maxvel);
+	hipFree(ctx->d_totals);
+	hipFree(ctx->d_counter);
+	hipFree(ctx->d_overlap);
+	hipFree(ctx->d_halo_list);
+	hipFree(ctx->d_inner_list);
+	hipFree(ctx->d_halo_counts);
+	for(auto& p: ctx->d_send_ids) hipFree(p);
+	if(ctx->h_status) hipHostFree(ctx->h_status);
+	if(ctx->h_maxvel) hipHostFree(ctx->h_maxvel);
+	hipEventDestroy(ctx->ev_a);
+	hipEventDestroy(ctx->ev_b);
+	hipEventDestroy(ctx->ev_g0);
+	hipEventDestroy(ctx->ev_g1);
+	hipEventDestroy(ctx->ev_comm);
+	hipStreamDestroy(ctx->s_compute);
+	hipStreamDestroy(ctx->s_comm);
+	delete ctx;
+}
+
+const char* mpm_last_error(const mpm_ctx* ctx) {
+	return ctx ? ctx->err.c_str() : "null context";
+}
+
+int mpm_add_model(mpm_ctx* ctx, int material, const mpm_material_params* params, const float* xyz, size_t n, const float v0[3], int* model_id) {
+	if(!ctx || !params || !xyz || ctx->ready) return MPM_ERR_INVALID;
+	if(material < 0 || material > 3) return fail(ctx, MPM_ERR_INVALID, "unknown material");
+	if((int) ctx->models.size() >= kMaxModels) return fail(ctx, MPM_ERR_CAPACITY, "too many models");
+	HIP_TRY(hipSetDevice(ctx->device));
+	Model m;
+	m.material = material;
+	m.p		   = *params;
+	m.mc	   = make_material_const(*params);
+	m.nch	   = material == MPM_J_FLUID ? 4 : (material == MPM_FIXED_COROTATED ? 12 : 13);
+	m.n		   = n;
+	for(int d = 0; d < 3; ++d) m.v0[d] = v0 ? v0[d] : 0.f;
+	HIP_TRY(dalloc(&m.d_xyz, 3 * n));
+	HIP_TRY(hipMemcpyAsync(m.d_xyz, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, ctx->s_compute));
+	HIP_TRY(hipStreamSynchronize(ctx->s_compute));
+	if(model_id) *model_id = (int) ctx->models.size();
+	ctx->models.push_back(m);
+	return MPM_OK;
+}
+
+static int read_status(mpm_ctx* ctx) {
+	HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int) * ST_WORDS, hipMemcpyDeviceToHost, ctx->s_compute));
+	HIP_TRY(hipStreamSynchronize(ctx->s_compute));
+	return MPM_OK;
+}
+
+static int check_status(mpm_ctx* ctx) {
+	const int* st = ctx->h_status;
+	if(st[ST_OVERFLOW] & 1) return fail(ctx, MPM_ERR_CAPACITY, "Too much active blocks: block capacity " + std::to_string(ctx->g.cap) + " exceeded");
+	if(st[ST_OVERFLOW] & 2) return fail(ctx, MPM_ERR_CAPACITY, "particles-per-block capacity exceeded (max_ppc*64 = " + std::to_string(ctx->g.ppb) + ")");
+	return MPM_OK;
+}
+
+// initial_setup, gmpm_simulator.cuh:637-781
+int mpm_initial_setup(mpm_ctx* ctx) {
+	if(!ctx || ctx->ready || ctx->models.empty()) return MPM_ERR_INVALID;
+	HIP_TRY(hipSetDevice(ctx->device));
+	GridCfg& g		   = ctx->g;
+	hipStream_t s	   = ctx->s_compute;
+	const size_t table = (size_t) g.G * g.G * g.G;
+	const int r = ctx->rollid, n = r ^ 1;
+	HIP_TRY(dalloc(&ctx->d_status, ST_WORDS));
+	HIP_TRY(hipHostMalloc((void**) &ctx->h_status, sizeof(int) * ST_WORDS));
+	HIP_TRY(dalloc(&ctx->d_maxvel, 1));
+	HIP_TRY(hipHostMalloc((void**) &ctx->h_maxvel, sizeof(float)));
+	HIP_TRY(dalloc(&ctx->d_totals, 4));
+	HIP_TRY(dalloc(&ctx->d_counter, 1));
+	HIP_TRY(hipMemsetAsync(ctx->d_status, 0, sizeof(int) * ST_WORDS, s));
+	for(int i = 0; i < 2; ++i) {
+		HIP_TRY(dalloc(&ctx->part[i].table, table));
+		HIP_TRY(dalloc(&ctx->part[i].count, 1));
+		HIP_TRY(hipMemsetAsync(ctx->part[i].table, 0xff, sizeof(int) * table, s));
+		HIP_TRY(hipMemsetAsync(ctx->part[i].count, 0, sizeof(int), s));
+	}
+	// Pass 1: activate particle blocks with a provisional capacity = table size bound by the particle count
+	size_t total_particles = 0;
+	for(auto& m: ctx->models) total_particles += m.n;
+	size_t prov = std::min(table, total_particles + 1);
+	if(ctx->cfg.max_blocks > 0) prov = std::min<size_t>(table, (size_t) ctx->cfg.max_blocks);
+	Partition& P = ctx->part[n];
+	HIP_TRY(dalloc(&P.keys, 3 * prov));
+	g.cap = (int) prov;
+	for(auto& m: ctx->models)
+		if(m.n) activate_blocks_kernel<<<cdiv(m.n, 256), 256, 0, s>>>(g, m.n, m.d_xyz, P.table, P.keys, P.count, ctx->d_status);
+	int pbc = 0;
+	HIP_TRY(hipMemcpyAsync(&pbc, P.count, sizeof(int), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	if(pbc > g.cap) return fail(ctx, MPM_ERR_CAPACITY, "Too much active blocks: " + std::to_string(pbc));
+	ctx->pbc = pbc;
+	// final capacity (reference: compile-time G_MAX_ACTIVE_BLOCK, grown by 1.5x on demand, gmpm_simulator.cuh:283-300)
+	size_t cap = ctx->cfg.max_blocks > 0 ? (size_t) ctx->cfg.max_blocks : std::min(table, (size_t) pbc * 6 + 4096);
+	if(cap < (size_t) pbc) return fail(ctx, MPM_ERR_CAPACITY, "max_blocks smaller than the initial particle block count");
+	{
+		int* keys = nullptr;
+		HIP_TRY(dalloc(&keys, 3 * cap));
+		HIP_TRY(hipMemcpyAsync(keys, P.keys, sizeof(int) * 3 * (size_t) pbc, hipMemcpyDeviceToDevice, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		HIP_TRY(hipFree(P.keys));
+		P.keys = keys;
+		HIP_TRY(dalloc(&ctx->part[r].keys, 3 * cap));
+	}
+	g.cap = (int) cap;
+	for(int i = 0; i < 2; ++i) {
+		HIP_TRY(dalloc(&ctx->grid[i], cap * 256));
+	}
+	// per model: bucket particles per block, allocate bins, fill bins + identity advection records
+	for(size_t mi = 0; mi < ctx->models.size(); ++mi) {
+		Model& m  = ctx->models[mi];
+		m.bin_cap = m.n / kBin + cap + 1;
+		for(int i = 0; i < 2; ++i) {
+			HIP_TRY(dalloc(&m.bins[i], m.bin_cap * m.nch * kBin));
+			HIP_TRY(dalloc(&m.binoff[i], cap + 1));
+			HIP_TRY(dalloc(&m.list[i], cap * (size_t) g.ppb));
+		}
+		HIP_TRY(dalloc(&m.size, cap + 1));
+		HIP_TRY(dalloc(&m.row_of, cap + 1));
+		HIP_TRY(dalloc(&m.out_count, cap + 1));
+		HIP_TRY(hipMemsetAsync(m.out_count, 0, sizeof(int) * (cap + 1), s));
+		HIP_TRY(hipMemsetAsync(m.size, 0, sizeof(int) * (cap + 1), s));
+		if(m.n) bucket_particles_kernel<<<cdiv(m.n, 256), 256, 0, s>>>(g, m.n, m.d_xyz, P.table, m.out_count, m.list[1], ctx->d_status);
+		if(pbc) {
+			init_bins_kernel<<<cdiv(pbc, 256), 256, 0, s>>>(pbc, m.out_count, m.size, m.row_of, m.binoff[r], m.binoff[n], &ctx->d_status[ST_BINS0 + mi]);
+			fill_bins_kernel<<<pbc, 256, 0, s>>>(g, m.nch, m.mc.log_jp0, m.d_xyz, m.list[1], m.size, m.binoff[r], m.bins[r], m.list[0]);
+		}
+		m.list_in = 0;
+	}
+	// neighbours, exterior (gmpm_simulator.cuh:706-734)
+	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_PBC], P.count, sizeof(int), hipMemcpyDeviceToDevice, s));
+	register_blocks_kernel<0, 1><<<std::max(1u, std::min(2048u, cdiv(pbc, 256))), 256, 0, s>>>(g, &ctx->d_status[ST_PBC], P.table, P.keys, P.count, ctx->d_status);
+	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_NBC], P.count, sizeof(int), hipMemcpyDeviceToDevice, s));
+	register_blocks_kernel<-1, 1><<<std::max(1u, std::min(2048u, cdiv(pbc, 256))), 256, 0, s>>>(g, &ctx->d_status[ST_PBC], P.table, P.keys, P.count, ctx->d_status);
+	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_EBC], P.count, sizeof(int), hipMemcpyDeviceToDevice, s));
+	int rc = read_status(ctx);
+	if(rc) return rc;
+	rc = check_status(ctx);
+	if(rc) return rc;
+	if(ctx->h_status[ST_LOST]) return fail(ctx, MPM_ERR_INVALID, "particles outside the domain at setup");
+	ctx->nbc = ctx->h_status[ST_NBC];
+	ctx->ebc = ctx->h_status[ST_EBC];
+	for(size_t mi = 0; mi < ctx->models.size(); ++mi) {
+		ctx->models[mi].bincount = ctx->h_status[ST_BINS0 + mi];
+		if((size_t) ctx->models[mi].bincount > ctx->models[mi].bin_cap) return fail(ctx, MPM_ERR_CAPACITY, "bin capacity");
+	}
+	// copy the partition to the other roll (gmpm_simulator.cuh:745-748): previous numbering == current numbering
+	HIP_TRY(hipMemcpyAsync(ctx->part[r].table, P.table, sizeof(int) * table, hipMemcpyDeviceToDevice, s));
+	HIP_TRY(hipMemcpyAsync(ctx->part[r].keys, P.keys, sizeof(int) * 3 * (size_t) ctx->ebc, hipMemcpyDeviceToDevice, s));
+	HIP_TRY(hipMemcpyAsync(ctx->part[r].count, P.count, sizeof(int), hipMemcpyDeviceToDevice, s));
+	// rasterize (gmpm_simulator.cuh:763-771)
+	HIP_TRY(hipMemsetAsync(ctx->grid[0], 0, sizeof(float) * 256 * (size_t) ctx->nbc, s));
+	for(auto& m: ctx->models)
+		if(m.n) rasterize_kernel<<<cdiv(m.n, 256), 256, 0, s>>>(g, m.n, m.d_xyz, ctx->part[r].table, ctx->grid[0], m.mc.mass, m.v0[0], m.v0[1], m.v0[2]);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(s));
+	ctx->ready = true;
+	return MPM_OK;
+}
+
+// grid-update phase, gmpm_simulator.cuh:326-347
+static int launch_grid_update(mpm_ctx* ctx, float dt) {
+	hipStream_t s = ctx->s_compute;
+	HIP_TRY(hipMemsetAsync(ctx->d_maxvel, 0, sizeof(unsigned), s));
+	if(ctx->nbc) grid_update_kernel<<<cdiv(ctx->nbc, 4), 256, 0, s>>>(ctx->g, ctx->nbc, ctx->grid[0], ctx->part[ctx->rollid].keys, dt, ctx->d_maxvel);
+	return MPM_OK;
+}
+
+int mpm_grid_update(mpm_ctx* ctx, float dt, float* max_vel_sqr) {
+	if(!ctx || !ctx->ready) return MPM_ERR_NOT_READY;
+	HIP_TRY(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->s_compute;
+	HIP_TRY(hipEventRecord(ctx->ev_a, s));
+	int rc = launch_grid_update(ctx, dt);
+	if(rc) return rc;
+	HIP_TRY(hipEventRecord(ctx->ev_b, s));
+	HIP_TRY(hipMemcpyAsync(ctx->h_maxvel, ctx->d_maxvel, sizeof(float), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	HIP_TRY(hipEventElapsedTime(&ctx->timers.grid_update_ms, ctx->ev_a, ctx->ev_b));
+	if(max_vel_sqr) *max_vel_sqr = *ctx->h_maxvel;
+	return MPM_OK;
+}
+
+float mpm_compute_dt(const mpm_ctx* ctx, float max_vel, float cur_time, float next_time, float dt_default) {
+	// utility_funcs.hpp:36-49
+	float dt = dt_default;
+	if(max_vel > 0.0f) dt = std::min(ctx->g.dx * ctx->cfg.cfl / max_vel, dt);
+	return std::min(dt, next_time - cur_time);
+}
+
+static ModelView make_view(mpm_ctx* ctx, Model& m) {
+	const int r = ctx->rollid, n = r ^ 1;
+	ModelView v {};
+	v.bins_src	 = m.bins[r];
+	v.bins_dst	 = m.bins[n];
+	v.binoff_src = m.binoff[r];
+	v.binoff_dst = m.binoff[n];
+	v.list_in	 = m.list[m.list_in];
+	v.list_out	 = m.list[m.list_in ^ 1];
+	v.size		 = m.size;
+	v.row_of	 = m.row_of;
+	v.out_count	 = m.out_count;
+	v.mc		 = m.mc;
+	return v;
+}
+
+static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, int nblocks, float dt, float next_dt, hipStream_t s) {
+	const int r = ctx->rollid, n = r ^ 1;
+	ModelView v = make_view(ctx, m);
+	const int* cur_table  = ctx->part[r].table;
+	const int* cur_keys	  = ctx->part[r].keys;
+	const int* prev_table = ctx->part[n].table;
+	switch(m.material) {
+		case MPM_J_FLUID: g2p2g_kernel<0><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_table, cur_keys, prev_table, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
+		case MPM_FIXED_COROTATED: g2p2g_kernel<1><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_table, cur_keys, prev_table, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
+		case MPM_SAND: g2p2g_kernel<2><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_table, cur_keys, prev_table, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
+		default: g2p2g_kernel<3><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_table, cur_keys, prev_table, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
+	}
+}
+
+// clears that precede g2p2g (gmpm_simulator.cuh:383,:389)
+static int launch_g2p2g_prologue(mpm_ctx* ctx) {
+	hipStream_t s = ctx->s_compute;
+	HIP_TRY(hipMemsetAsync(ctx->grid[1], 0, sizeof(float) * 256 * (size_t) ctx->nbc, s));
+	for(auto& m: ctx->models) HIP_TRY(hipMemsetAsync(m.out_count, 0, sizeof(int) * ((size_t) ctx->ebc + 1), s));
+	return MPM_OK;
+}
+
+static int launch_g2p2g(mpm_ctx* ctx, float dt, float next_dt) {
+	hipStream_t s = ctx->s_compute;
+	int rc		  = launch_g2p2g_prologue(ctx);
+	if(rc) return rc;
+	HIP_TRY(hipEventRecord(ctx->ev_g0, s));
+	if(ctx->pbc)
+		for(auto& m: ctx->models) launch_g2p2g_model(ctx, m, nullptr, ctx->pbc, dt, next_dt, s);
+	HIP_TRY(hipEventRecord(ctx->ev_g1, s));
+	return MPM_OK;
+}
+
+int mpm_g2p2g(mpm_ctx* ctx, float dt, float next_dt) {
+	if(!ctx || !ctx->ready) return MPM_ERR_NOT_READY;
+	HIP_TRY(hipSetDevice(ctx->device));
+	int rc = launch_g2p2g(ctx, dt, next_dt);
+	if(rc) return rc;
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(ctx->s_compute));
+	HIP_TRY(hipEventElapsedTime(&ctx->last_g2p2g_ms, ctx->ev_g0, ctx->ev_g1));
+	ctx->timers.g2p2g_ms = ctx->last_g2p2g_ms;
+	return MPM_OK;
+}
+
+// partition rebuild, gmpm_simulator.cuh:415-579 (launches only; no host round trip inside)
+static int launch_rebuild(mpm_ctx* ctx) {
+	hipStream_t s = ctx->s_compute;
+	GridCfg& g	  = ctx->g;
+	const int r = ctx->rollid, n = r ^ 1;
+	Partition& Pn = ctx->part[n];
+	Partition& Pr = ctx->part[r];
+	const size_t table = (size_t) g.G * g.G * g.G;
+	HIP_TRY(hipMemsetAsync(Pn.table, 0xff, sizeof(int) * table, s));// reset_table, hash_table.cuh:110-112
+	HIP_TRY(hipMemsetAsync(Pn.count, 0, sizeof(int), s));
+	HIP_TRY(hipMemsetAsync(&ctx->d_status[ST_BINS0], 0, sizeof(int) * kMaxModels, s));
+	RebuildModels rm {};
+	rm.n = (int) ctx->models.size();
+	for(int mi = 0; mi < rm.n; ++mi) {
+		Model& m		 = ctx->models[mi];
+		rm.out_count[mi] = m.out_count;
+		rm.size[mi]		 = m.size;
+		rm.row_of[mi]	 = m.row_of;
+		rm.binoff[mi]	 = m.binoff[r];// becomes the destination offsets after the roll
+	}
+	if(ctx->ebc) compact_blocks_kernel<<<cdiv(ctx->ebc, 256), 256, 0, s>>>(g, ctx->ebc, rm, Pr.keys, Pn.keys, Pn.table, Pn.count, ctx->d_status);
+	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_PBC], Pn.count, sizeof(int), hipMemcpyDeviceToDevice, s));
+	const unsigned rg = std::max(1u, std::min(2048u, cdiv(ctx->ebc, 256)));
+	register_blocks_kernel<0, 1><<<rg, 256, 0, s>>>(g, &ctx->d_status[ST_PBC], Pn.table, Pn.keys, Pn.count, ctx->d_status);
+	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_NBC], Pn.count, sizeof(int), hipMemcpyDeviceToDevice, s));
+	carry_grid_kernel<<<2048, 256, 0, s>>>(g, &ctx->d_status[ST_NBC], Pn.keys, Pr.table, ctx->nbc, ctx->grid[1], ctx->grid[0]);
+	register_blocks_kernel<-1, 1><<<rg, 256, 0, s>>>(g, &ctx->d_status[ST_PBC], Pn.table, Pn.keys, Pn.count, ctx->d_status);
+	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_EBC], Pn.count, sizeof(int), hipMemcpyDeviceToDevice, s));
+	return MPM_OK;
+}
+
+static int finish_rebuild(mpm_ctx* ctx, mpm_counts* counts) {
+	int rc = read_status(ctx);
+	if(rc) return rc;
+	rc = check_status(ctx);
+	if(rc) return rc;
+	ctx->pbc = ctx->h_status[ST_PBC];
+	ctx->nbc = ctx->h_status[ST_NBC];
+	ctx->ebc = ctx->h_status[ST_EBC];
+	if(ctx->ebc > ctx->g.cap) return fail(ctx, MPM_ERR_CAPACITY, "Too much exterior blocks: " + std::to_string(ctx->ebc));
+	for(size_t mi = 0; mi < ctx->models.size(); ++mi) {
+		Model& m   = ctx->models[mi];
+		m.bincount = ctx->h_status[ST_BINS0 + mi];
+		if((size_t) m.bincount > m.bin_cap) return fail(ctx, MPM_ERR_CAPACITY, "bin capacity exceeded");
+		m.list_in ^= 1;
+	}
+	ctx->rollid ^= 1;// gmpm_simulator.cuh:578
+	if(counts) return mpm_get_counts(ctx, counts);
+	return MPM_OK;
+}
+
+int mpm_rebuild_partition(mpm_ctx* ctx, mpm_counts* counts) {
+	if(!ctx || !ctx->ready) return MPM_ERR_NOT_READY;
+	HIP_TRY(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->s_compute;
+	HIP_TRY(hipEventRecord(ctx->ev_a, s));
+	int rc = launch_rebuild(ctx);
+	if(rc) return rc;
+	HIP_TRY(hipEventRecord(ctx->ev_b, s));
+	HIP_TRY(hipGetLastError());
+	rc = finish_rebuild(ctx, counts);
+	if(rc) return rc;
+	HIP_TRY(hipEventElapsedTime(&ctx->timers.partition_ms, ctx->ev_a, ctx->ev_b));
+	return MPM_OK;
+}
+
+int mpm_substep(mpm_ctx* ctx, float dt, float step_time, float frame_time, float dt_default, float* next_dt, float* max_vel) {
+	float mv2 = 0.f;
+	int rc	  = mpm_grid_update(ctx, dt, &mv2);
+	if(rc) return rc;
+	if(std::isinf(mv2)) return fail(ctx, MPM_ERR_NONFINITE, "Maximum velocity is infinity");// gmpm_simulator.cuh:355-358
+	const float mv = std::sqrt(mv2);																 // :360
+	const float nd = mpm_compute_dt(ctx, mv, step_time, frame_time, dt_default);
+	if(max_vel) *max_vel = mv;
+	if(next_dt) *next_dt = nd;
+	rc = launch_g2p2g(ctx, dt, nd);
+	if(rc) return rc;
+	hipStream_t s = ctx->s_compute;
+	HIP_TRY(hipEventRecord(ctx->ev_a, s));
+	rc = launch_rebuild(ctx);
+	if(rc) return rc;
+	HIP_TRY(hipEventRecord(ctx->ev_b, s));
+	HIP_TRY(hipGetLastError());
+	rc = finish_rebuild(ctx, nullptr);
+	if(rc) return rc;
+	HIP_TRY(hipEventElapsedTime(&ctx->last_g2p2g_ms, ctx->ev_g0, ctx->ev_g1));
+	HIP_TRY(hipEventElapsedTime(&ctx->timers.partition_ms, ctx->ev_a, ctx->ev_b));
+	ctx->timers.g2p2g_ms = ctx->last_g2p2g_ms;
+	ctx->timers.total_ms = ctx->timers.grid_update_ms + ctx->timers.g2p2g_ms + ctx->timers.partition_ms;
+	return MPM_OK;
+}
+
+int mpm_run_fixed(mpm_ctx* ctx, int nsteps, float dt) {
+	if(!ctx || !ctx->ready) return MPM_ERR_NOT_READY;
+	HIP_TRY(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->s_compute;
+	double acc_grid = 0, acc_g2p2g = 0, acc_part = 0, acc_total = 0;
+	for(int it = 0; it < nsteps; ++it) {
+		HIP_TRY(hipEventRecord(ctx->ev_a, s));
+		int rc = launch_grid_update(ctx, dt);
+		if(rc) return rc;
+		rc = launch_g2p2g(ctx, dt, dt);// records ev_g0 / ev_g1 around the G2P2G kernel(s)
+		if(rc) return rc;
+		rc = launch_rebuild(ctx);
+		if(rc) return rc;
+		HIP_TRY(hipEventRecord(ctx->ev_b, s));
+		HIP_TRY(hipMemcpyAsync(ctx->h_maxvel, ctx->d_maxvel, sizeof(float), hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipGetLastError());
+		rc = finish_rebuild(ctx, nullptr);
+		if(rc) return rc;
+		if(std::isinf(*ctx->h_maxvel)) return fail(ctx, MPM_ERR_NONFINITE, "Maximum velocity is infinity");
+		float t_grid = 0, t_g = 0, t_part = 0, t_tot = 0;
+		HIP_TRY(hipEventElapsedTime(&t_grid, ctx->ev_a, ctx->ev_g0));
+		HIP_TRY(hipEventElapsedTime(&t_g, ctx->ev_g0, ctx->ev_g1));
+		HIP_TRY(hipEventElapsedTime(&t_part, ctx->ev_g1, ctx->ev_b));
+		HIP_TRY(hipEventElapsedTime(&t_tot, ctx->ev_a, ctx->ev_b));
+		acc_grid += t_grid;
+		acc_g2p2g += t_g;
+		acc_part += t_part;
+		acc_total += t_tot;
+		ctx->last_g2p2g_ms = t_g;
+	}
+	if(nsteps > 0) {// per-substep averages over this call, HIP events on the compute stream
+		ctx->timers.grid_update_ms = (float) (acc_grid / nsteps);
+		ctx->timers.g2p2g_ms	   = (float) (acc_g2p2g / nsteps);
+		ctx->timers.partition_ms   = (float) (acc_part / nsteps);
+		ctx->timers.total_ms	   = (float) (acc_total / nsteps);
+	}
+	return MPM_OK;
+}
+
+int mpm_last_g2p2g_ms(mpm_ctx* ctx, float* ms) {
+	if(!ctx || !ms) return MPM_ERR_INVALID;
+	*ms = ctx->last_g2p2g_ms;
+	return MPM_OK;
+}
+
+int mpm_get_counts(mpm_ctx* ctx, mpm_counts* counts) {
+	if(!ctx || !ctx->ready || !counts) return MPM_ERR_NOT_READY;
+	memset(counts, 0, sizeof(*counts));
+	counts->particle_blocks = ctx->pbc;
+	counts->neighbor_blocks = ctx->nbc;
+	counts->exterior_blocks = ctx->ebc;
+	counts->model_count		= (int) ctx->models.size();
+	HIP_TRY(hipSetDevice(ctx->device));
+	std::vector<int> sizes((size_t) ctx->pbc + 1);
+	for(size_t mi = 0; mi < ctx->models.size(); ++mi) {
+		counts->bins[mi] = ctx->models[mi].bincount;
+		HIP_TRY(hipMemcpy(sizes.data(), ctx->models[mi].size, sizeof(int) * (size_t) ctx->pbc, hipMemcpyDeviceToHost));
+		int64_t np = 0;
+		for(int b = 0; b < ctx->pbc; ++b) np += sizes[b];
+		counts->particles[mi] = np;
+	}
+	return MPM_OK;
+}
+
+int mpm_get_timers(mpm_ctx* ctx, mpm_timers* t) {
+	if(!ctx || !t) return MPM_ERR_INVALID;
+	*t = ctx->timers;
+	return MPM_OK;
+}
+
+// output_model, gmpm_simulator.cuh:594-634
+int mpm_retrieve_state(mpm_ctx* ctx, int model, float* xyz, float* state9, float* logjp, size_t* n) {
+	if(!ctx || !ctx->ready || model < 0 || model >= (int) ctx->models.size() || !n || !xyz) return MPM_ERR_INVALID;
+	HIP_TRY(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->s_compute;
+	Model& m	  = ctx->models[model];
+	const int r = ctx->rollid, nn = r ^ 1;
+	const size_t cap = std::min(*n, m.n);
+	float *d_state = nullptr, *d_lj = nullptr;
+	if(state9) HIP_TRY(dalloc(&d_state, 9 * cap));
+	if(logjp) HIP_TRY(dalloc(&d_lj, cap));
+	HIP_TRY(hipMemsetAsync(ctx->d_counter, 0, sizeof(unsigned long long), s));
+	if(ctx->pbc) retrieve_kernel<<<ctx->pbc, 256, 0, s>>>(ctx->g, m.nch, ctx->part[r].keys, ctx->part[nn].table, m.size, m.row_of, m.list[m.list_in], m.binoff[r], m.bins[r], m.d_xyz, d_state, d_lj, (unsigned long long) cap, ctx->d_counter);
+	unsigned long long count = 0;
+	HIP_TRY(hipMemcpyAsync(&count, ctx->d_counter, sizeof(count), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	const size_t got = std::min<size_t>(count, cap);
+	HIP_TRY(hipMemcpy(xyz, m.d_xyz, sizeof(float) * 3 * got, hipMemcpyDeviceToHost));
+	if(state9) HIP_TRY(hipMemcpy(state9, d_state, sizeof(float) * 9 * got, hipMemcpyDeviceToHost));
+	if(logjp) HIP_TRY(hipMemcpy(logjp, d_lj, sizeof(float) * got, hipMemcpyDeviceToHost));
+	hipFree(d_state);
+	hipFree(d_lj);
+	*n = got;
+	if(count > cap) return fail(ctx, MPM_ERR_CAPACITY, "output array too small");
+	return MPM_OK;
+}
+
+int mpm_retrieve_positions(mpm_ctx* ctx, int model, float* xyz, size_t* n) {
+	return mpm_retrieve_state(ctx, model, xyz, nullptr, nullptr, n);
+}
+
+int mpm_grid_totals(mpm_ctx* ctx, double out[4]) {
+	if(!ctx || !ctx->ready || !out) return MPM_ERR_NOT_READY;
+	HIP_TRY(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->s_compute;
+	HIP_TRY(hipMemsetAsync(ctx->d_totals, 0, sizeof(double) * 4, s));
+	if(ctx->nbc) grid_totals_kernel<<<256, 256, 0, s>>>(ctx->nbc, ctx->grid[0], ctx->d_totals);
+	HIP_TRY(hipMemcpyAsync(out, ctx->d_totals, sizeof(double) * 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	return MPM_OK;
+}
+
+int mpm_dump_grid(mpm_ctx* ctx, int* keys, float* blocks, size_t* nblocks) {
+	if(!ctx || !ctx->ready || !nblocks) return MPM_ERR_NOT_READY;
+	if(*nblocks < (size_t) ctx->nbc) return fail(ctx, MPM_ERR_CAPACITY, "grid dump too small");
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipStreamSynchronize(ctx->s_compute));
+	if(keys) HIP_TRY(hipMemcpy(keys, ctx->part[ctx->rollid].keys, sizeof(int) * 3 * (size_t) ctx->nbc, hipMemcpyDeviceToHost));
+	if(blocks) HIP_TRY(hipMemcpy(blocks, ctx->grid[0], sizeof(float) * 256 * (size_t) ctx->nbc, hipMemcpyDeviceToHost));
+	*nblocks = ctx->nbc;
+	return MPM_OK;
+}
+
+// ---- function-level tests ---------------------------------------------------------------------------
+#define HIP_TRY0(expr)                         \
+	do {                                       \
+		if((expr) != hipSuccess) return MPM_ERR_DEVICE; \
+	} while(0)
+
+int mpm_test_svd(const float* F, size_t n, float* out21, int device) {
+	HIP_TRY0(hipSetDevice(device));
+	float *dF = nullptr, *dO = nullptr;
+	HIP_TRY0(dalloc(&dF, 9 * n));
+	HIP_TRY0(dalloc(&dO, 21 * n));
+	HIP_TRY0(hipMemcpy(dF, F, sizeof(float) * 9 * n, hipMemcpyHostToDevice));
+	test_svd_kernel<<<cdiv(n, 256), 256>>>(n, dF, dO);
+	HIP_TRY0(hipMemcpy(out21, dO, sizeof(float) * 21 * n, hipMemcpyDeviceToHost));
+	hipFree(dF);
+	hipFree(dO);
+	return MPM_OK;
+}
+
+int mpm_test_stress(int material, const mpm_material_params* p, const float* F, const float* logjp, size_t n, float* out19, int device) {
+	if(material < 1 || material > 3 || !p) return MPM_ERR_INVALID;
+	HIP_TRY0(hipSetDevice(device));
+	float *dF = nullptr, *dL = nullptr, *dO = nullptr;
+	HIP_TRY0(dalloc(&dF, 9 * n));
+	HIP_TRY0(dalloc(&dO, 19 * n));
+	HIP_TRY0(hipMemcpy(dF, F, sizeof(float) * 9 * n, hipMemcpyHostToDevice));
+	if(logjp) {
+		HIP_TRY0(dalloc(&dL, n));
+		HIP_TRY0(hipMemcpy(dL, logjp, sizeof(float) * n, hipMemcpyHostToDevice));
+	}
+	test_stress_kernel<<<cdiv(n, 256), 256>>>(material, make_material_const(*p), n, dF, dL, dO);
+	HIP_TRY0(hipMemcpy(out19, dO, sizeof(float) * 19 * n, hipMemcpyDeviceToHost));
+	hipFree(dF);
+	hipFree(dL);
+	hipFree(dO);
+	return MPM_OK;
+}
+
+int mpm_streams(mpm_ctx* ctx, void** compute_stream, void** comm_stream) {
+	if(!ctx) return MPM_ERR_INVALID;
+	if(compute_stream) *compute_stream = (void*) ctx->s_compute;
+	if(comm_stream) *comm_stream = (void*) ctx->s_comm;
+	return MPM_OK;
+}
+
+int mpm_sync(mpm_ctx* ctx) {
+	if(!ctx) return MPM_ERR_INVALID;
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipStreamSynchronize(ctx->s_compute));
+	HIP_TRY(hipStreamSynchronize(ctx->s_comm));
+	return MPM_OK;
+}
+
+}// extern "C"
+
+#include "mpm_halo.inc"

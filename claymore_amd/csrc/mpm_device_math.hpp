@@ -1,0 +1,491 @@
+// mpm_device_math.hpp — register-resident per-particle math for gfx950 (CDNA4).
+//
+// Device versions of the arithmetic on claymore's G2P2G path.  Everything stays in VGPRs: 3x3 products,
+// the McAdams SVD and the four constitutive models (no MFMA: the contractions are 3-wide).  The
+// algorithms are the reference's (cited per function, paths relative to /root/reference); the code is
+// written for the AMD compiler: selects instead of bit masks (v_cndmask), v_rsq_f32 where the algorithm
+// tolerates an approximate reciprocal square root, FMA contraction allowed.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mpm {
+
+#define MPM_DEV __device__ __forceinline__
+
+// Projects/GMPM/utility_funcs.hpp:10-19 — quadratic B-spline weights; d = offset from the base node in cells
+MPM_DEV void bspline_weight_cells(float d, float (&w)[3]) {
+	const float a = 1.5f - d;
+	w[0]		  = 0.5f * a * a;
+	const float b = d - 1.0f;
+	w[1]		  = 0.75f - b * b;
+	const float c = d - 0.5f;
+	w[2]		  = 0.5f * c * c;
+}
+
+// utility_funcs.hpp:21-23: lround(x * dx_inv) for x >= 0 (round half away from zero)
+MPM_DEV int node_index(float x, float dx_inv) {
+	return (int) __builtin_roundf(x * dx_inv);
+}
+
+// Library/MnBase/Math/Matrix/MatrixUtils.h:147-157 (column-major)
+MPM_DEV void matmul3(const float (&a)[9], const float (&b)[9], float (&c)[9]) {
+#pragma unroll
+	for(int j = 0; j < 3; ++j) {
+#pragma unroll
+		for(int i = 0; i < 3; ++i) c[3 * j + i] = a[i] * b[3 * j] + a[3 + i] * b[3 * j + 1] + a[6 + i] * b[3 * j + 2];
+	}
+}
+// MatrixUtils.h:29-41: out = m1 * diag * m2^T
+MPM_DEV void mat_diag_matT(float (&out)[9], const float (&m1)[9], const float (&dg)[3], const float (&m2)[9]) {
+#pragma unroll
+	for(int j = 0; j < 3; ++j) {
+#pragma unroll
+		for(int i = 0; i < 3; ++i) out[3 * j + i] = m1[i] * dg[0] * m2[j] + m1[3 + i] * dg[1] * m2[3 + j] + m1[6 + i] * dg[2] * m2[6 + j];
+	}
+}
+// P F^T * volume (tail of constitutive_models.cuh:63-72)
+MPM_DEV void P_Ft_vol(const float (&P)[9], const float (&F)[9], float volume, float (&PF)[9]) {
+#pragma unroll
+	for(int j = 0; j < 3; ++j) {
+#pragma unroll
+		for(int i = 0; i < 3; ++i) PF[3 * j + i] = (P[i] * F[j] + P[3 + i] * F[3 + j] + P[6 + i] * F[6 + j]) * volume;
+	}
+}
+
+MPM_DEV float rsqrt_approx(float x) {
+	return __builtin_amdgcn_rsqf(x);// v_rsq_f32, ~1 ulp; the algorithm re-normalises (svd.cuh:210-215)
+}
+// rsqrt refined by one Newton step, svd.cuh:487-498
+MPM_DEV float rsqrt_newton(float x) {
+	float t1 = rsqrt_approx(x);
+	float t4 = t1 * 0.5f;
+	float t3 = t1 * t4;
+	t3		 = t1 * t3;
+	t3		 = x * t3;
+	t1		 = t1 + t4;
+	return t1 - t3;
+}
+
+// One Jacobi conjugation, Library/MnBase/Math/Matrix/svd.cuh:167-252 (and its two index-permuted copies).
+MPM_DEV void jacobi_conj(float& s11, float& s21, float& s22, float& s31, float& s32, float& s33, float& qx, float& qy, float& qz, float& qs) {
+	float sh   = s21 * 0.5f;
+	float tmp5 = s11 - s22;
+	float tmp2 = sh * sh;
+	bool m	   = tmp2 >= 1.e-20f;
+	sh		   = m ? sh : 0.0f;
+	float ch   = m ? tmp5 : 1.0f;
+	float tmp1 = sh * sh;
+	tmp2	   = ch * ch;
+	float tmp3 = tmp1 + tmp2;
+	float tmp4 = rsqrt_approx(tmp3);
+	sh		   = tmp4 * sh;
+	ch		   = tmp4 * ch;
+	tmp1	   = 5.8284273147583007813f * tmp1;
+	m		   = tmp2 <= tmp1;
+	sh		   = m ? __uint_as_float(1053028117u) : sh;// sin(pi/8)
+	ch		   = m ? __uint_as_float(1064076127u) : ch;// cos(pi/8)
+	tmp1	   = sh * sh;
+	tmp2	   = ch * ch;
+	float c	   = tmp2 - tmp1;
+	float s	   = ch * sh;
+	s		   = s + s;
+	tmp3	   = tmp1 + tmp2;
+	s33		   = s33 * tmp3;
+	s31		   = s31 * tmp3;
+	s32		   = s32 * tmp3;
+	s33		   = s33 * tmp3;
+	tmp1	   = s * s31;
+	tmp2	   = s * s32;
+	s31		   = c * s31;
+	s32		   = c * s32;
+	s31		   = tmp2 + s31;
+	s32		   = s32 - tmp1;
+	tmp2	   = s * s;
+	tmp1	   = s22 * tmp2;
+	tmp3	   = s11 * tmp2;
+	tmp4	   = c * c;
+	s11		   = s11 * tmp4;
+	s22		   = s22 * tmp4;
+	s11		   = s11 + tmp1;
+	s22		   = s22 + tmp3;
+	tmp4	   = tmp4 - tmp2;
+	tmp2	   = s21 + s21;
+	s21		   = s21 * tmp4;
+	tmp4	   = c * s;
+	tmp2	   = tmp2 * tmp4;
+	tmp5	   = tmp5 * tmp4;
+	s11		   = s11 + tmp2;
+	s21		   = s21 - tmp5;
+	s22		   = s22 - tmp2;
+	tmp1	   = sh * qx;
+	tmp2	   = sh * qy;
+	tmp3	   = sh * qz;
+	sh		   = sh * qs;
+	qs		   = ch * qs;
+	qx		   = ch * qx;
+	qy		   = ch * qy;
+	qz		   = ch * qz;
+	qz		   = qz + sh;
+	qs		   = qs - tmp3;
+	qx		   = qx + tmp2;
+	qy		   = qy - tmp1;
+}
+
+MPM_DEV void cond_swap(bool c, float& x, float& y) {
+	const float t = x;
+	x			  = c ? y : x;
+	y			  = c ? t : y;
+}
+
+// One Givens step of the QR factorisation, svd.cuh:786-880.  (ap*, aq*) are rows p and q of B, (up*, uq*) columns
+// p and q of U; apiv / aqpiv are the pivot-column entries (aliases of ap*/aq* elements, read first).
+MPM_DEV void qr_givens(float apiv, float aqpiv, float& ap1, float& ap2, float& ap3, float& aq1, float& aq2, float& aq3, float& up1, float& up2, float& up3, float& uq1, float& uq2, float& uq3) {
+	float sh   = aqpiv * aqpiv;
+	sh		   = (sh >= 1.e-12f) ? aqpiv : 0.0f;
+	float ch   = fmaxf(fmaxf(-apiv, apiv), 1.e-12f);
+	const bool m = apiv >= 0.f;
+	float tmp2 = ch * ch + sh * sh;
+	float tmp1 = rsqrt_newton(tmp2) * tmp2;
+	ch		   = ch + tmp1;
+	{
+		const float nch = m ? ch : sh;
+		const float nsh = m ? sh : ch;
+		ch				= nch;
+		sh				= nsh;
+	}
+	tmp2	= ch * ch + sh * sh;
+	tmp1	= rsqrt_newton(tmp2);
+	ch		= ch * tmp1;
+	sh		= sh * tmp1;
+	const float c = ch * ch - sh * sh;
+	float s		  = sh * ch;
+	s			  = s + s;
+#define MPM_ROT(x, y)            \
+	{                            \
+		const float t1 = s * x;  \
+		const float t2 = s * y;  \
+		x			   = c * x + t2; \
+		y			   = c * y - t1; \
+	}
+	MPM_ROT(ap1, aq1)
+	MPM_ROT(ap2, aq2)
+	MPM_ROT(ap3, aq3)
+	MPM_ROT(up1, uq1)
+	MPM_ROT(up2, uq2)
+	MPM_ROT(up3, uq3)
+#undef MPM_ROT
+}
+
+// math::svd, Library/MnBase/Math/Matrix/svd.cuh:27-1123.  Column-major F, U, V.
+MPM_DEV void svd3(const float (&F)[9], float (&U)[9], float (&S)[3], float (&V)[9]) {
+	float a11 = F[0], a21 = F[1], a31 = F[2], a12 = F[3], a22 = F[4], a32 = F[5], a13 = F[6], a23 = F[7], a33 = F[8];
+	float s11 = a11 * a11 + a21 * a21 + a31 * a31;
+	float s21 = a12 * a11 + a22 * a21 + a32 * a31;
+	float s31 = a13 * a11 + a23 * a21 + a33 * a31;
+	float s22 = a12 * a12 + a22 * a22 + a32 * a32;
+	float s32 = a13 * a12 + a23 * a22 + a33 * a32;
+	float s33 = a13 * a13 + a23 * a23 + a33 * a33;
+	float qs = 1.f, qx = 0.f, qy = 0.f, qz = 0.f;
+#pragma unroll
+	for(int it = 0; it < 4; ++it) {
+		jacobi_conj(s11, s21, s22, s31, s32, s33, qx, qy, qz, qs);
+		jacobi_conj(s22, s32, s33, s21, s31, s11, qy, qz, qx, qs);
+		jacobi_conj(s33, s31, s11, s32, s21, s22, qz, qx, qy, qs);
+	}
+	// normalise the quaternion (svd.cuh:475-498) and expand it to V (:500-530)
+	{
+		const float n = rsqrt_newton(qs * qs + qx * qx + qy * qy + qz * qz);
+		qs *= n;
+		qx *= n;
+		qy *= n;
+		qz *= n;
+	}
+	float tmp1 = qx * qx, tmp2 = qy * qy, tmp3 = qz * qz;
+	float v11 = qs * qs;
+	float v22 = v11 - tmp1;
+	float v33 = v22 - tmp2;
+	v33		  = v33 + tmp3;
+	v22		  = v22 + tmp2;
+	v22		  = v22 - tmp3;
+	v11		  = v11 + tmp1;
+	v11		  = v11 - tmp2;
+	v11		  = v11 - tmp3;
+	tmp1	  = qx + qx;
+	tmp2	  = qy + qy;
+	tmp3	  = qz + qz;
+	float v32 = qs * tmp1;
+	float v13 = qs * tmp2;
+	float v21 = qs * tmp3;
+	tmp1	  = qy * tmp1;
+	tmp2	  = qz * tmp2;
+	tmp3	  = qx * tmp3;
+	float v12 = tmp1 - v21;
+	float v23 = tmp2 - v32;
+	float v31 = tmp3 - v13;
+	v21		  = tmp1 + v21;
+	v32		  = tmp2 + v32;
+	v13		  = tmp3 + v13;
+	// B = A V (svd.cuh:532-588)
+#define MPM_ROWV(x1, x2, x3)                          \
+	{                                                 \
+		const float o1 = x1, o2 = x2, o3 = x3;        \
+		x1 = v11 * o1 + v21 * o2 + v31 * o3;          \
+		x2 = v12 * o1 + v22 * o2 + v32 * o3;          \
+		x3 = v13 * o1 + v23 * o2 + v33 * o3;          \
+	}
+	MPM_ROWV(a11, a12, a13)
+	MPM_ROWV(a21, a22, a23)
+	MPM_ROWV(a31, a32, a33)
+#undef MPM_ROWV
+	// sort columns by squared norm, descending, keeping V a rotation (svd.cuh:590-770)
+	tmp1 = a11 * a11 + a21 * a21 + a31 * a31;
+	tmp2 = a12 * a12 + a22 * a22 + a32 * a32;
+	tmp3 = a13 * a13 + a23 * a23 + a33 * a33;
+	{
+		bool c = tmp1 < tmp2;
+		cond_swap(c, a11, a12);
+		cond_swap(c, a21, a22);
+		cond_swap(c, a31, a32);
+		cond_swap(c, v11, v12);
+		cond_swap(c, v21, v22);
+		cond_swap(c, v31, v32);
+		cond_swap(c, tmp1, tmp2);
+		float neg = c ? -1.f : 1.f;
+		a12 *= neg;
+		a22 *= neg;
+		a32 *= neg;
+		v12 *= neg;
+		v22 *= neg;
+		v32 *= neg;
+		c = tmp1 < tmp3;
+		cond_swap(c, a11, a13);
+		cond_swap(c, a21, a23);
+		cond_swap(c, a31, a33);
+		cond_swap(c, v11, v13);
+		cond_swap(c, v21, v23);
+		cond_swap(c, v31, v33);
+		cond_swap(c, tmp1, tmp3);
+		neg = c ? -1.f : 1.f;
+		a11 *= neg;
+		a21 *= neg;
+		a31 *= neg;
+		v11 *= neg;
+		v21 *= neg;
+		v31 *= neg;
+		c = tmp2 < tmp3;
+		cond_swap(c, a12, a13);
+		cond_swap(c, a22, a23);
+		cond_swap(c, a32, a33);
+		cond_swap(c, v12, v13);
+		cond_swap(c, v22, v23);
+		cond_swap(c, v32, v33);
+		neg = c ? -1.f : 1.f;
+		a13 *= neg;
+		a23 *= neg;
+		a33 *= neg;
+		v13 *= neg;
+		v23 *= neg;
+		v33 *= neg;
+	}
+	// QR by three Givens rotations (svd.cuh:772-1090)
+	float u11 = 1.f, u12 = 0.f, u13 = 0.f, u21 = 0.f, u22 = 1.f, u23 = 0.f, u31 = 0.f, u32 = 0.f, u33 = 1.f;
+	qr_givens(a11, a21, a11, a12, a13, a21, a22, a23, u11, u21, u31, u12, u22, u32);
+	qr_givens(a11, a31, a11, a12, a13, a31, a32, a33, u11, u21, u31, u13, u23, u33);
+	qr_givens(a22, a32, a21, a22, a23, a31, a32, a33, u12, u22, u32, u13, u23, u33);
+	U[0] = u11;
+	U[1] = u21;
+	U[2] = u31;
+	U[3] = u12;
+	U[4] = u22;
+	U[5] = u32;
+	U[6] = u13;
+	U[7] = u23;
+	U[8] = u33;
+	V[0] = v11;
+	V[1] = v21;
+	V[2] = v31;
+	V[3] = v12;
+	V[4] = v22;
+	V[5] = v32;
+	V[6] = v13;
+	V[7] = v23;
+	V[8] = v33;
+	S[0] = a11;
+	S[1] = a22;
+	S[2] = a33;
+}
+
+// Material constants passed by value to the kernels (Projects/GMPM/particle_buffer.cuh:141-264)
+struct MaterialConst {
+	float mass, volume, mu, lambda;
+	float bulk, gamma, viscosity;		 // J_FLUID
+	float cohesion, beta, yield_surface;// SAND (beta also NACC)
+	float bm, xi, msqr;					 // NACC
+	float log_jp0;
+	int volume_correction, hardening_on;
+};
+
+// compute_stress<FIXED_COROTATED>, Projects/GMPM/constitutive_models.cuh:36-73
+MPM_DEV void stress_fixed_corotated(const MaterialConst& mc, const float (&F)[9], float (&PF)[9]) {
+	float U[9], S[3], V[9];
+	svd3(F, U, S, V);
+	const float J			  = S[0] * S[1] * S[2];
+	const float scaled_mu	  = 2.0f * mc.mu;
+	const float scaled_lambda = mc.lambda * (J - 1.0f);
+	float Ph[3];
+	Ph[0] = scaled_mu * (S[0] - 1.f) + scaled_lambda * (S[1] * S[2]);
+	Ph[1] = scaled_mu * (S[1] - 1.f) + scaled_lambda * (S[0] * S[2]);
+	Ph[2] = scaled_mu * (S[2] - 1.f) + scaled_lambda * (S[0] * S[1]);
+	float P[9];
+	mat_diag_matT(P, U, Ph, V);
+	P_Ft_vol(P, F, mc.volume, PF);
+}
+
+// compute_stress<SAND>, constitutive_models.cuh:238-335 (Drucker-Prager return mapping, StVK-Hencky)
+MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9]) {
+	float U[9], S[3], V[9];
+	svd3(F, U, S, V);
+	const float scaled_mu = 2.0f * mc.mu;
+	float epsilon[3], New_S[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+	for(int i = 0; i < 3; i++) {
+		const float abs_S = fmaxf(fabsf(S[i]), 1e-4f);
+		epsilon[i]		  = logf(abs_S) - mc.cohesion;
+	}
+	const float sum_epsilon	  = epsilon[0] + epsilon[1] + epsilon[2];
+	const float trace_epsilon = sum_epsilon + log_jp;
+	float epsilon_hat[3];
+#pragma unroll
+	for(int i = 0; i < 3; i++) epsilon_hat[i] = epsilon[i] - (trace_epsilon / 3.0f);
+	const float epsilon_hat_norm = sqrtf(epsilon_hat[0] * epsilon_hat[0] + epsilon_hat[1] * epsilon_hat[1] + epsilon_hat[2] * epsilon_hat[2]);
+	bool rebuild = false;
+	if(trace_epsilon >= 0.0f) {// case II: cone tip
+		New_S[0] = New_S[1] = New_S[2] = expf(mc.cohesion);
+		rebuild						   = true;
+		if(mc.volume_correction) log_jp = mc.beta * sum_epsilon + log_jp;
+	} else if(mc.mu != 0.f) {
+		log_jp					= 0.f;
+		const float delta_gamma = epsilon_hat_norm + (3.0f * mc.lambda + scaled_mu) / scaled_mu * trace_epsilon * mc.yield_surface;
+		float H[3];
+		if(delta_gamma <= 0.f) {// case I: inside the cone
+#pragma unroll
+			for(int i = 0; i < 3; i++) H[i] = epsilon[i] + mc.cohesion;
+		} else {// case III: project to the cone surface
+#pragma unroll
+			for(int i = 0; i < 3; i++) H[i] = epsilon[i] - (delta_gamma / epsilon_hat_norm) * epsilon_hat[i] + mc.cohesion;
+		}
+#pragma unroll
+		for(int i = 0; i < 3; i++) New_S[i] = expf(H[i]);
+		rebuild = true;
+	}
+	if(rebuild) mat_diag_matT(F, U, New_S, V);
+	const float ls0 = logf(New_S[0]), ls1 = logf(New_S[1]), ls2 = logf(New_S[2]);
+	const float trace_log_S = ls0 + ls1 + ls2;
+	float P_hat[3];
+	P_hat[0] = (scaled_mu * ls0 + mc.lambda * trace_log_S) / New_S[0];
+	P_hat[1] = (scaled_mu * ls1 + mc.lambda * trace_log_S) / New_S[1];
+	P_hat[2] = (scaled_mu * ls2 + mc.lambda * trace_log_S) / New_S[2];
+	float P[9];
+	mat_diag_matT(P, U, P_hat, V);
+	P_Ft_vol(P, F, mc.volume, PF);
+}
+
+// compute_stress<NACC>, constitutive_models.cuh:77-234 (USE_JOSH_FRACTURE_PAPER branch)
+MPM_DEV void stress_nacc(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9]) {
+	float U[9], S[3], V[9];
+	svd3(F, U, S, V);
+	const float bm	  = mc.bm;
+	const float p0	  = bm * (0.00001f + sinhf(mc.xi * (-log_jp > 0 ? -log_jp : 0)));
+	const float p_min = -mc.beta * p0;
+	const float Je_trial = S[0] * S[1] * S[2];
+	const float B0 = S[0] * S[0], B1 = S[1] * S[1], B2 = S[2] * S[2];
+	const float trB3   = (B0 + B1 + B2) / 3.f;
+	const float Jm23mu = mc.mu * powf(Je_trial, -2.f / 3.f);
+	const float sh0 = Jm23mu * (B0 - trB3), sh1 = Jm23mu * (B1 - trB3), sh2 = Jm23mu * (B2 - trB3);
+	const float psi_kappa_partial_J = bm * 0.5f * (Je_trial - 1.f / Je_trial);
+	const float p_trial				= -psi_kappa_partial_J * Je_trial;
+	const float y_s_half_coeff		= 3.f / 2.f * (1 + 2.f * mc.beta);
+	const float y_p_half			= (mc.msqr * (p_trial - p_min) * (p_trial - p0));
+	const float s_sqrnorm			= sh0 * sh0 + sh1 * sh1 + sh2 * sh2;
+	const float y					= (y_s_half_coeff * s_sqrnorm) + y_p_half;
+	if(p_trial > p0) {
+		const float Je_new = sqrtf(-2.f * p0 / bm + 1.f);
+		S[0] = S[1] = S[2] = powf(Je_new, 1.f / 3.f);
+		mat_diag_matT(F, U, S, V);
+		if(mc.hardening_on) log_jp += logf(Je_trial / Je_new);
+	} else if(p_trial < p_min) {
+		const float Je_new = sqrtf(-2.f * p_min / bm + 1.f);
+		S[0] = S[1] = S[2] = powf(Je_new, 1.f / 3.f);
+		mat_diag_matT(F, U, S, V);
+		if(mc.hardening_on) log_jp += logf(Je_trial / Je_new);
+	} else if(y >= 1e-4f) {
+		const float B_s_coeff = powf(Je_trial, 2.f / 3.f) / mc.mu * sqrtf(-y_p_half / y_s_half_coeff) / sqrtf(s_sqrnorm);
+		S[0]				  = sqrtf(sh0 * B_s_coeff + trB3);
+		S[1]				  = sqrtf(sh1 * B_s_coeff + trB3);
+		S[2]				  = sqrtf(sh2 * B_s_coeff + trB3);
+		mat_diag_matT(F, U, S, V);
+		if(mc.hardening_on && p0 > 1e-4f && p_trial < p0 - 1e-4f && p_trial > 1e-4f + p_min) {
+			const float p_center = (1.0f - mc.beta) * p0 / 2;
+			const float q_trial	 = sqrtf(3.f / 2.f * s_sqrnorm);
+			float d0 = p_center - p_trial, d1 = -q_trial;
+			const float dn = sqrtf(d0 * d0 + d1 * d1);
+			d0 /= dn;
+			d1 /= dn;
+			const float C  = mc.msqr * (p_center - p_min) * (p_center - p0);
+			const float B  = mc.msqr * d0 * (2 * p_center - p0 - p_min);
+			const float A  = mc.msqr * d0 * d0 + (1 + 2 * mc.beta) * d1 * d1;
+			const float sq = sqrtf(B * B - 4 * A * C);
+			const float l1 = (-B + sq) / (2 * A);
+			const float l2 = (-B - sq) / (2 * A);
+			const float p1 = p_center + l1 * d0;
+			const float p2 = p_center + l2 * d0;
+			const float p_fake		= (p_trial - p_center) * (p1 - p_center) > 0 ? p1 : p2;
+			const float tmp_Je_sqr	= (-2 * p_fake / bm + 1);
+			const float Je_new_fake = sqrtf(tmp_Je_sqr > 0 ? tmp_Je_sqr : -tmp_Je_sqr);
+			if(Je_new_fake > 1e-4f) log_jp += logf(Je_trial / Je_new_fake);
+		}
+	}
+	const float J = S[0] * S[1] * S[2];
+	float b[9];
+#pragma unroll
+	for(int j = 0; j < 3; ++j) {
+#pragma unroll
+		for(int i = 0; i < 3; ++i) b[3 * j + i] = F[i] * F[j] + F[3 + i] * F[3 + j] + F[6 + i] * F[6 + j];
+	}
+	const float twothirds = (float) (2.0 / 3.0);
+	const float bd0		  = b[0] * twothirds - (b[4] + b[8]) / 3.0f;
+	const float bd4		  = b[4] * twothirds - (b[0] + b[8]) / 3.0f;
+	const float bd8		  = b[8] * twothirds - (b[0] + b[4]) / 3.0f;
+	const float dev_b_coeff = mc.mu * powf(J, -2.f / 3.f);
+	const float i_coeff		= bm * .5f * ((J * J - 1.f) * 0.5f - logf(J));
+	PF[0]					= (dev_b_coeff * bd0 + i_coeff) * mc.volume;
+	PF[1]					= (dev_b_coeff * b[1]) * mc.volume;
+	PF[2]					= (dev_b_coeff * b[2]) * mc.volume;
+	PF[3]					= (dev_b_coeff * b[3]) * mc.volume;
+	PF[4]					= (dev_b_coeff * bd4 + i_coeff) * mc.volume;
+	PF[5]					= (dev_b_coeff * b[5]) * mc.volume;
+	PF[6]					= (dev_b_coeff * b[6]) * mc.volume;
+	PF[7]					= (dev_b_coeff * b[7]) * mc.volume;
+	PF[8]					= (dev_b_coeff * bd8 + i_coeff) * mc.volume;
+}
+
+// J-fluid (weakly compressible, Tait EOS + Newtonian viscosity), Projects/GMPM/mgmpm_kernels.cuh:476-505
+MPM_DEV float stress_jfluid(const MaterialConst& mc, float J, const float (&A)[9], float dt, float d_inv, float (&contrib)[9]) {
+	J += (A[0] + A[4] + A[8]) * dt * d_inv * J;
+	if(J < 0.1f) J = 0.1f;// reference compares with the double literal 0.1; no float lies in (0.1, 0.1f), so this is identical
+	const float voln	 = J * mc.volume;
+	const float pressure = mc.bulk * (powf(J, -mc.gamma) - 1.f);
+	const float k		 = d_inv * mc.viscosity;
+	contrib[0]			 = ((A[0] + A[0]) * k - pressure) * voln;
+	contrib[1]			 = (A[1] + A[3]) * k * voln;
+	contrib[2]			 = (A[2] + A[6]) * k * voln;
+	contrib[3]			 = (A[3] + A[1]) * k * voln;
+	contrib[4]			 = ((A[4] + A[4]) * k - pressure) * voln;
+	contrib[5]			 = (A[5] + A[7]) * k * voln;
+	contrib[6]			 = (A[6] + A[2]) * k * voln;
+	contrib[7]			 = (A[7] + A[5]) * k * voln;
+	contrib[8]			 = ((A[8] + A[8]) * k - pressure) * voln;
+	return J;
+}
+
+}// namespace mpm

@@ -1,0 +1,632 @@
+// mpm_kernels.hpp — hand-written gfx950 kernels of the MPM substep hot path.
+//
+// Design (MI355X-first, not a translation of the reference's CUDA):
+//   * wave64 everywhere: one wave == one 4x4x4 grid block (64 cells) in the grid kernels, one wave == one
+//     64-slot AoSoA particle bin in G2P2G, so every bin-stride load/store is a full 256-B row;
+//   * G2P2G workgroup = 256 threads = one particle block; the 8 neighbouring grid blocks are staged through
+//     LDS once (float4 {vx,vy,vz,-} per node -> one ds_read_b128 per stencil node), the P2G result is
+//     reduced in an LDS arena (ds_add_f32) and written back with one hardware f32 atomic per touched node;
+//   * block-level advection lists instead of the reference's cell buckets + compaction passes: a particle
+//     appends ONE 4-byte record {direction tag, slot} to the list of the block it lands in
+//     (wave-aggregated atomic for the particles that stay), and next step's G2P2G consumes that list
+//     directly through a row indirection - 8 B/particle of bookkeeping traffic instead of 24 B and three
+//     kernels fewer (reference: add_advection + cell_bucket_to_block + update_buckets);
+//   * the partition rebuild is ONE compaction kernel with wave-aggregated atomics (no scans, no host
+//     round trips): renumber blocks, rebuild the dense table, allocate bins; neighbour / exterior
+//     registration and the grid carry-over read their counts from device memory.
+//
+// Reference kernels replaced (Projects/GMPM/mgmpm_kernels.cuh): update_grid_velocity_query_max :325-420,
+// g2p2g :665-937 (+ :422-663), activate_blocks :21-34, build_particle_cell_buckets :36-68,
+// cell_bucket_to_block :70-84, compute_bin_capacity :86-94, init_adv_bucket :96-104, clear_grid :106-115,
+// register_neighbor_blocks :117-133, register_exterior_blocks :135-151, rasterize :153-219,
+// array_to_buffer :221-323, mark_active_* :939-964, update_partition :966-977, update_buckets :979-1000,
+// copy_selected_grid_blocks :1002-1020, retrieve_particle_buffer :1087-1122.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mpm_device_math.hpp"
+
+namespace mpm {
+
+constexpr int kBin		  = 64; // particles per AoSoA bin == wavefront width
+constexpr int kG2P2GThreads = 256;
+constexpr int kMaxModels  = 8;
+constexpr int kP2GStrideX = 68; // arena x stride in floats (64 + 4: spreads the 4 x-planes over LDS banks)
+constexpr int kP2GChannel = 544;// >= 7*68 + 7*8 + 7 + 1, multiple of 32
+constexpr int kStay		  = 13; // dir_offset(0,0,0), utility_funcs.hpp:25-27
+
+// status block indices (device ints, read back once per substep)
+enum { ST_PBC = 0, ST_NBC = 1, ST_EBC = 2, ST_OVERFLOW = 3, ST_LOST = 4, ST_ARENA = 5, ST_BINS0 = 8, ST_WORDS = 32 };
+
+struct GridCfg {
+	int G;		  // blocks per axis
+	int gbits;	  // log2(G)
+	int ppb;	  // advection-list capacity per block (max_ppc * 64)
+	int pid_bits; // log2(ppb)
+	int boundary; // wall zone in blocks
+	int cap;	  // block capacity
+	float dx, dx_inv, d_inv, gravity;
+};
+
+__device__ __forceinline__ bool key_ok(const GridCfg& c, int x, int y, int z) {
+	return ((unsigned) x < (unsigned) c.G) & ((unsigned) y < (unsigned) c.G) & ((unsigned) z < (unsigned) c.G);
+}
+__device__ __forceinline__ size_t key_index(const GridCfg& c, int x, int y, int z) {
+	return ((size_t) x << (2 * c.gbits)) | ((size_t) y << c.gbits) | (size_t) z;// row-major, StructuralDeclaration.h:235-251
+}
+__device__ __forceinline__ int table_query(const GridCfg& c, const int* __restrict__ table, int x, int y, int z) {
+	return key_ok(c, x, y, z) ? table[key_index(c, x, y, z)] : -1;
+}
+// Partition::insert, hash_table.cuh:118-127 (claim with CAS, then append).  Out-of-domain keys are ignored.
+__device__ __forceinline__ void table_insert(const GridCfg& c, int* table, int* keys, int* count, int x, int y, int z, int* status) {
+	if(!key_ok(c, x, y, z)) return;
+	const size_t i = key_index(c, x, y, z);
+	if(table[i] != -1) return;// cheap pre-check, most inserts hit an existing block
+	if(atomicCAS(&table[i], -1, -2) == -1) {
+		const int idx = atomicAdd(count, 1);
+		if(idx < c.cap) {
+			table[i]		 = idx;
+			keys[3 * idx]	 = x;
+			keys[3 * idx + 1] = y;
+			keys[3 * idx + 2] = z;
+		} else {
+			table[i] = -1;
+			atomicOr(&status[ST_OVERFLOW], 1);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Grid update: momentum -> velocity, gravity, slip walls, max |v|^2.   One wave per grid block, lane = cell.
+// (update_grid_velocity_query_max, mgmpm_kernels.cuh:325-420)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grid_update_kernel(GridCfg cfg, int nblocks, float* __restrict__ grid, const int* __restrict__ keys, float dt, unsigned* __restrict__ max_vel_bits) {
+	const int lane	  = threadIdx.x & 63;
+	const int blockno = blockIdx.x * 4 + (threadIdx.x >> 6);
+	float vel_sqr	  = 0.f;
+	if(blockno < nblocks) {
+		const int kx = keys[3 * blockno], ky = keys[3 * blockno + 1], kz = keys[3 * blockno + 2];
+		const bool wx = kx < cfg.boundary || kx >= cfg.G - cfg.boundary;
+		const bool wy = ky < cfg.boundary || ky >= cfg.G - cfg.boundary;
+		const bool wz = kz < cfg.boundary || kz >= cfg.G - cfg.boundary;
+		float* g		 = grid + (size_t) blockno * 256;
+		const float mass = g[lane];
+		if(mass > 0.0f) {
+			const float mass_inv = 1.f / mass;
+			float v0 = g[64 + lane], v1 = g[128 + lane], v2 = g[192 + lane];
+			v0 = wx ? 0.0f : v0 * mass_inv;
+			v1 = wy ? 0.0f : v1 * mass_inv;
+			v1 += cfg.gravity * dt;
+			v2			  = wz ? 0.0f : v2 * mass_inv;
+			g[64 + lane]  = v0;
+			g[128 + lane] = v1;
+			g[192 + lane] = v2;
+			vel_sqr		  = v0 * v0 + v1 * v1 + v2 * v2;
+		}
+		if(vel_sqr != vel_sqr) vel_sqr = __builtin_inff();// NaN -> inf signals failure (:385-388)
+	}
+#pragma unroll
+	for(int off = 32; off > 0; off >>= 1) vel_sqr = fmaxf(vel_sqr, __shfl_xor(vel_sqr, off));
+	if(lane == 0 && vel_sqr > 0.f) atomicMax(max_vel_bits, __float_as_uint(vel_sqr));// non-negative floats order as uints
+}
+
+// ------------------------------------------------------------------------------------------------------
+// G2P2G
+// ------------------------------------------------------------------------------------------------------
+struct ModelView {
+	const float* bins_src;// [bin][nch][64], laid out by the previous block numbering
+	float* bins_dst;	  // laid out by the current numbering
+	const int* binoff_src;// first bin of a block, previous numbering
+	const int* binoff_dst;// current numbering
+	const int* list_in;	  // advection records written by the previous step; row = row_of[b]
+	int* list_out;		  // records for the next step; row = destination block (current numbering)
+	const int* size;	  // particles per current block
+	const int* row_of;	  // row of list_in that belongs to current block b
+	int* out_count;		  // append counters of list_out
+	MaterialConst mc;
+};
+
+template<int MAT>
+struct MatTraits;
+template<>
+struct MatTraits<0> {
+	static constexpr int nch = 4;
+};
+template<>
+struct MatTraits<1> {
+	static constexpr int nch = 12;
+};
+template<>
+struct MatTraits<2> {
+	static constexpr int nch = 13;
+};
+template<>
+struct MatTraits<3> {
+	static constexpr int nch = 13;
+};
+
+__device__ __forceinline__ void dir_components(int dir, int& dx, int& dy, int& dz) {
+	dz = (dir % 3) - 1;
+	dy = ((dir / 3) % 3) - 1;
+	dx = (dir / 9) - 1;
+}
+
+template<int MAT>
+__global__ __launch_bounds__(kG2P2GThreads) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_table, const int* __restrict__ cur_keys, const int* __restrict__ prev_table, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, float dt, float new_dt, int* __restrict__ status) {
+	constexpr int NCH = MatTraits<MAT>::nch;
+	__shared__ float4 g2p[512];				   // node velocities of the 8x8x8 arena, {vx,vy,vz,-}
+	__shared__ float p2g[4 * kP2GChannel];	   // mass + momentum accumulators, SoA, padded strides
+	__shared__ int s_src_binoff[27], s_dst_no[27], s_nb[8];
+
+	const int tid  = threadIdx.x;
+	const int lane = tid & 63;
+	const int b	   = block_list ? block_list[blockIdx.x] : (int) blockIdx.x;
+	const int size = mv.size[b];
+	if(size == 0) return;// (:692-697)
+	const int kx = cur_keys[3 * b], ky = cur_keys[3 * b + 1], kz = cur_keys[3 * b + 2];
+
+	if(tid < 27) {
+		int ox, oy, oz;
+		dir_components(tid, ox, oy, oz);
+		const int srcno	  = table_query(cfg, prev_table, kx + ox, ky + oy, kz + oz);
+		s_src_binoff[tid] = srcno >= 0 ? mv.binoff_src[srcno] : -1;
+		s_dst_no[tid]	  = table_query(cfg, cur_table, kx - ox, ky - oy, kz - oz);
+	} else if(tid >= 64 && tid < 72) {
+		const int lb = tid - 64;
+		s_nb[lb]	 = table_query(cfg, cur_table, kx + ((lb >> 2) & 1), ky + ((lb >> 1) & 1), kz + (lb & 1));
+	}
+	for(int i = tid; i < 4 * kP2GChannel; i += kG2P2GThreads) p2g[i] = 0.f;
+	__syncthreads();
+	{// stage the 8 grid blocks: wave w loads blocks 2w, 2w+1; lane = cell -> 256-B rows (:699-727)
+		const int w	 = tid >> 6;
+		const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
+#pragma unroll
+		for(int h = 0; h < 2; ++h) {
+			const int lb	= 2 * w + h;
+			const int nb	= s_nb[lb];
+			const float* gb = grid + (size_t) (nb < 0 ? 0 : nb) * 256;
+			float4 v;
+			v.x = gb[64 + lane];
+			v.y = gb[128 + lane];
+			v.z = gb[192 + lane];
+			v.w = 0.f;
+			if(nb < 0) v.x = v.y = v.z = 0.f;
+			g2p[(cx + ((lb & 4) ? 4 : 0)) * 64 + (cy + ((lb & 2) ? 4 : 0)) * 8 + (cz + ((lb & 1) ? 4 : 0))] = v;
+		}
+	}
+	__syncthreads();
+
+	const int row		  = mv.row_of[b];
+	const int* list		  = mv.list_in + (size_t) row * cfg.ppb;
+	const float dx_inv	  = cfg.dx_inv;
+	const float scale	  = 4.f * cfg.dx_inv;// dx * D^-1 (settings.h:66): A is accumulated in cell units
+	const float mass	  = mv.mc.mass;
+	const int binoff_dst  = mv.binoff_dst[b];
+
+	for(int pidib = tid; pidib < size; pidib += kG2P2GThreads) {
+		// ---- advection record -> source bin (:747-768)
+		const int rec	  = list[pidib];
+		const int tag	  = rec >> cfg.pid_bits;
+		const int sp	  = rec & (cfg.ppb - 1);
+		const int sbin	  = s_src_binoff[tag] + (sp >> 6);
+		const float* src  = mv.bins_src + (size_t) sbin * (NCH * kBin) + (sp & 63);
+		float pos[3]	  = {src[0], src[kBin], src[2 * kBin]};
+		float st[10];// J, or F[9] (+ logJp)
+		if constexpr(MAT == 0) {
+			st[0] = src[3 * kBin];
+		} else {
+#pragma unroll
+			for(int d = 0; d < 9; ++d) st[d] = src[(3 + d) * kBin];
+			if constexpr(NCH == 13) st[9] = src[12 * kBin];
+		}
+		// ---- stencil base + weights (:774-797); offsets in cell units (exact: dx is a power of two)
+		int base[3], arena[3];
+		float fd[3], w[3][3];
+#pragma unroll
+		for(int d = 0; d < 3; ++d) {
+			const float p = pos[d] * dx_inv;
+			base[d]		  = (int) __builtin_roundf(p) - 1;
+			fd[d]		  = p - (float) base[d];
+			bspline_weight_cells(fd[d], w[d]);
+			arena[d] = ((base[d] - 1) & 3) + 1;
+		}
+		// ---- G2P gather (:801-835): vel = sum W v, A = sum W v (x_i - x_p)^T   [A in cell units]
+		float vel[3] = {0.f, 0.f, 0.f};
+		float A[9]	 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+		const float4* gbase = g2p + arena[0] * 64 + arena[1] * 8 + arena[2];
+#pragma unroll
+		for(int i = 0; i < 3; ++i) {
+#pragma unroll
+			for(int j = 0; j < 3; ++j) {
+				const float wij = w[0][i] * w[1][j];
+#pragma unroll
+				for(int k = 0; k < 3; ++k) {
+					const float W  = wij * w[2][k];
+					const float4 v = gbase[i * 64 + j * 8 + k];
+					const float px = (float) i - fd[0], py = (float) j - fd[1], pz = (float) k - fd[2];
+					const float wx = W * v.x, wy = W * v.y, wz = W * v.z;
+					vel[0] += wx;
+					vel[1] += wy;
+					vel[2] += wz;
+					A[0] += wx * px;
+					A[1] += wy * px;
+					A[2] += wz * px;
+					A[3] += wx * py;
+					A[4] += wy * py;
+					A[5] += wz * py;
+					A[6] += wx * pz;
+					A[7] += wy * pz;
+					A[8] += wz * pz;
+				}
+			}
+		}
+		// ---- advect (:838)
+#pragma unroll
+		for(int d = 0; d < 3; ++d) pos[d] += vel[d] * dt;
+		// ---- material update, store to the destination bin (coalesced: slot == pidib) (:470-663)
+		float contrib[9];
+		float* dst = mv.bins_dst + (size_t) (binoff_dst + (pidib >> 6)) * (NCH * kBin) + (pidib & 63);
+		dst[0]		  = pos[0];
+		dst[kBin]	  = pos[1];
+		dst[2 * kBin] = pos[2];
+		if constexpr(MAT == 0) {
+			float Aw[9];
+#pragma unroll
+			for(int d = 0; d < 9; ++d) Aw[d] = A[d] * cfg.dx;
+			const float J = stress_jfluid(mv.mc, st[0], Aw, dt, cfg.d_inv, contrib);
+			dst[3 * kBin] = J;
+		} else {
+			float dws[9], Fold[9], F[9];
+#pragma unroll
+			for(int d = 0; d < 9; ++d) {
+				dws[d]	= (A[d] * dt) * scale + ((d & 0x3) != 0 ? 0.f : 1.f);
+				Fold[d] = st[d];
+			}
+			matmul3(dws, Fold, F);
+			if constexpr(MAT == 1) {
+				stress_fixed_corotated(mv.mc, F, contrib);
+			} else if constexpr(MAT == 2) {
+				float lj = st[9];
+				stress_sand(mv.mc, F, lj, contrib);
+				dst[12 * kBin] = lj;
+			} else {
+				float lj = st[9];
+				stress_nacc(mv.mc, F, lj, contrib);
+				dst[12 * kBin] = lj;
+			}
+#pragma unroll
+			for(int d = 0; d < 9; ++d) dst[(3 + d) * kBin] = F[d];
+		}
+		// (:850) contrib = (A m - contrib new_dt) D^-1, pre-multiplied by dx so that P2G can stay in cell units
+		{
+			const float am = mass * cfg.dx * cfg.dx * cfg.d_inv;// A(cell units) * dx [-> world] * m * D^-1 * dx [xixp world]
+			const float cs = new_dt * cfg.d_inv * cfg.dx;
+#pragma unroll
+			for(int d = 0; d < 9; ++d) contrib[d] = A[d] * am - contrib[d] * cs;
+		}
+		// ---- new base, re-bucket (:852-866, add_advection particle_buffer.cuh:100-135)
+		int nbase[3], narena[3], dirv[3];
+		bool in_arena = true;
+#pragma unroll
+		for(int d = 0; d < 3; ++d) {
+			const float p = pos[d] * dx_inv;
+			nbase[d]	  = (int) __builtin_roundf(p) - 1;
+			fd[d]		  = p - (float) nbase[d];
+			bspline_weight_cells(fd[d], w[d]);
+			dirv[d]	  = ((base[d] - 1) >> 2) - ((nbase[d] - 1) >> 2);
+			narena[d] = arena[d] + (nbase[d] - base[d]);
+			in_arena &= (narena[d] >= 0) & (narena[d] + 2 < 8);
+		}
+		{
+			const bool dir_ok = ((unsigned) (dirv[0] + 1) < 3u) & ((unsigned) (dirv[1] + 1) < 3u) & ((unsigned) (dirv[2] + 1) < 3u);
+			const int ntag	  = dir_ok ? (dirv[0] + 1) * 9 + (dirv[1] + 1) * 3 + dirv[2] + 1 : kStay;
+			const int dno	  = dir_ok ? s_dst_no[ntag] : -1;
+			const bool stay	  = dir_ok && ntag == kStay;
+			int slot		  = -1;
+			// wave-aggregated append for the particles that stay in this block (one atomic per wave)
+			const unsigned long long m = __ballot(stay);
+			if(stay) {
+				const int leader = __ffsll((long long) m) - 1;
+				int basev		 = 0;
+				if(lane == leader) basev = atomicAdd(&mv.out_count[b], __popcll(m));
+				basev = __shfl(basev, leader);
+				slot  = basev + __popcll(m & ((1ull << lane) - 1ull));
+			} else if(dno >= 0) {
+				slot = atomicAdd(&mv.out_count[dno], 1);
+			}
+			if(dno < 0) {
+				atomicAdd(&status[ST_LOST], 1);// reference: particle silently lost (particle_buffer.cuh:105-113)
+			} else if(slot >= cfg.ppb) {
+				atomicOr(&status[ST_OVERFLOW], 2);// reference drops beyond 128 per cell (:122-130)
+			} else {
+				mv.list_out[(size_t) dno * cfg.ppb + slot] = (ntag << cfg.pid_bits) | pidib;
+			}
+		}
+		if(!in_arena) {// (:877-885) contribution discarded
+			atomicAdd(&status[ST_ARENA], 1);
+			continue;
+		}
+		// ---- P2G scatter into the LDS arena (:887-905)
+		float* pbase = p2g + narena[0] * kP2GStrideX + narena[1] * 8 + narena[2];
+		const float mv0 = mass * vel[0], mv1 = mass * vel[1], mv2 = mass * vel[2];
+#pragma unroll
+		for(int i = 0; i < 3; ++i) {
+			const float px = (float) i - fd[0];
+#pragma unroll
+			for(int j = 0; j < 3; ++j) {
+				const float py	= (float) j - fd[1];
+				const float wij = w[0][i] * w[1][j];
+				const float b0	= mv0 + contrib[0] * px + contrib[3] * py;
+				const float b1	= mv1 + contrib[1] * px + contrib[4] * py;
+				const float b2	= mv2 + contrib[2] * px + contrib[5] * py;
+#pragma unroll
+				for(int k = 0; k < 3; ++k) {
+					const float pz = (float) k - fd[2];
+					const float W  = wij * w[2][k];
+					float* node	   = pbase + i * kP2GStrideX + j * 8 + k;
+					atomicAdd(node, mass * W);
+					atomicAdd(node + kP2GChannel, (b0 + contrib[6] * pz) * W);
+					atomicAdd(node + 2 * kP2GChannel, (b1 + contrib[7] * pz) * W);
+					atomicAdd(node + 3 * kP2GChannel, (b2 + contrib[8] * pz) * W);
+				}
+			}
+		}
+	}
+	__syncthreads();
+	// ---- arena -> next grid: one hardware f32 atomic per touched node, 256-B rows (:907-936)
+	{
+		const int ch = tid >> 6;
+		const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
+#pragma unroll
+		for(int lb = 0; lb < 8; ++lb) {
+			const int nb = s_nb[lb];
+			const float val = p2g[ch * kP2GChannel + (cx + ((lb & 4) ? 4 : 0)) * kP2GStrideX + (cy + ((lb & 2) ? 4 : 0)) * 8 + (cz + ((lb & 1) ? 4 : 0))];
+			if(nb >= 0 && val != 0.f) unsafeAtomicAdd(next_grid + (size_t) nb * 256 + ch * 64 + lane, val);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Partition rebuild
+// ------------------------------------------------------------------------------------------------------
+struct RebuildModels {
+	int n;
+	const int* out_count[kMaxModels];
+	int* size[kMaxModels];
+	int* row_of[kMaxModels];
+	int* binoff[kMaxModels];// destination bin offsets for the NEXT step (new numbering)
+};
+
+// One pass replaces mark_active_particle_blocks + exclusive_scan + exclusive_scan_inverse + update_partition +
+// update_buckets + compute_bin_capacity + exclusive_scan (gmpm_simulator.cuh:436-505): blocks that received
+// particles get a new number (wave-aggregated atomic), their key goes into the new table, their bins are
+// allocated.  Order of the new numbering is arbitrary (as it is in the reference: insert order of atomics).
+__global__ __launch_bounds__(256) void compact_blocks_kernel(GridCfg cfg, int ebc, RebuildModels rm, const int* __restrict__ old_keys, int* __restrict__ new_keys, int* __restrict__ new_table, int* __restrict__ new_count, int* __restrict__ status) {
+	const int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if(b >= ebc) return;
+	int c[kMaxModels];
+	bool any = false;
+	for(int m = 0; m < rm.n; ++m) {
+		c[m] = rm.out_count[m][b];
+		any |= c[m] > 0;
+	}
+	if(!any) return;
+	const int nb = atomicAdd(new_count, 1);// the compiler turns this into one atomic per wave
+	const int kx = old_keys[3 * b], ky = old_keys[3 * b + 1], kz = old_keys[3 * b + 2];
+	new_keys[3 * nb]					  = kx;
+	new_keys[3 * nb + 1]				  = ky;
+	new_keys[3 * nb + 2]				  = kz;
+	new_table[key_index(cfg, kx, ky, kz)] = nb;
+	for(int m = 0; m < rm.n; ++m) {
+		rm.size[m][nb]	 = c[m];
+		rm.row_of[m][nb] = b;
+		const int nbins	 = (c[m] + kBin - 1) / kBin;
+		rm.binoff[m][nb] = nbins ? atomicAdd(&status[ST_BINS0 + m], nbins) : 0;
+	}
+}
+
+// register_neighbor_blocks / register_exterior_blocks (mgmpm_kernels.cuh:117-151); pbc is read from device memory.
+template<int LO, int HI>
+__global__ __launch_bounds__(256) void register_blocks_kernel(GridCfg cfg, const int* __restrict__ pbc_ptr, int* table, int* keys, int* count, int* status) {
+	const int pbc = *pbc_ptr;
+	for(int b = blockIdx.x * blockDim.x + threadIdx.x; b < pbc; b += gridDim.x * blockDim.x) {
+		const int kx = keys[3 * b], ky = keys[3 * b + 1], kz = keys[3 * b + 2];
+		for(int i = LO; i <= HI; ++i)
+			for(int j = LO; j <= HI; ++j)
+				for(int k = LO; k <= HI; ++k) table_insert(cfg, table, keys, count, kx + i, ky + j, kz + k, status);
+	}
+}
+
+// Carry the P2G result (old numbering) into the current grid (new numbering): every NEW neighbour block is written
+// exactly once - copied from its old block if it existed, zero otherwise.  Replaces clear_grid +
+// mark_active_grid_blocks + copy_selected_grid_blocks (gmpm_simulator.cuh:436-446, :536-541).  One wave per block.
+__global__ __launch_bounds__(256) void carry_grid_kernel(GridCfg cfg, const int* __restrict__ new_nbc_ptr, const int* __restrict__ new_keys, const int* __restrict__ old_table, int old_nbc, const float* __restrict__ p2g_grid, float* __restrict__ grid) {
+	const int nbc  = min(*new_nbc_ptr, cfg.cap);
+	const int lane = threadIdx.x & 63;
+	for(int nb = blockIdx.x * 4 + (threadIdx.x >> 6); nb < nbc; nb += gridDim.x * 4) {
+		const int old = table_query(cfg, old_table, new_keys[3 * nb], new_keys[3 * nb + 1], new_keys[3 * nb + 2]);
+		float4 v	  = {0.f, 0.f, 0.f, 0.f};
+		if(old >= 0 && old < old_nbc) {
+			const float* s = p2g_grid + (size_t) old * 256;
+			v			   = {s[lane], s[64 + lane], s[128 + lane], s[192 + lane]};
+		}
+		float* d	  = grid + (size_t) nb * 256;
+		d[lane]		  = v.x;
+		d[64 + lane]  = v.y;
+		d[128 + lane] = v.z;
+		d[192 + lane] = v.w;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Initial setup (gmpm_simulator.cuh:637-781)
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void particle_block_key(const GridCfg& cfg, const float* xyz, size_t i, int& bx, int& by, int& bz, int& cellx, int& celly, int& cellz) {
+	cellx = node_index(xyz[3 * i], cfg.dx_inv) - 2;
+	celly = node_index(xyz[3 * i + 1], cfg.dx_inv) - 2;
+	cellz = node_index(xyz[3 * i + 2], cfg.dx_inv) - 2;
+	bx	  = cellx / 4;// C++ truncating division as in the reference (Vec.h integer '/')
+	by	  = celly / 4;
+	bz	  = cellz / 4;
+}
+// activate_blocks, mgmpm_kernels.cuh:21-34
+__global__ void activate_blocks_kernel(GridCfg cfg, size_t n, const float* __restrict__ xyz, int* table, int* keys, int* count, int* status) {
+	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	int bx, by, bz, cx, cy, cz;
+	particle_block_key(cfg, xyz, i, bx, by, bz, cx, cy, cz);
+	table_insert(cfg, table, keys, count, bx, by, bz, status);
+}
+// build_particle_cell_buckets (:36-68) at block granularity: particle id appended to its block's list
+__global__ void bucket_particles_kernel(GridCfg cfg, size_t n, const float* __restrict__ xyz, const int* __restrict__ table, int* counts, int* ids, int* status) {
+	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	int bx, by, bz, cx, cy, cz;
+	particle_block_key(cfg, xyz, i, bx, by, bz, cx, cy, cz);
+	const int bno = table_query(cfg, table, bx, by, bz);
+	if(bno < 0) {
+		atomicAdd(&status[ST_LOST], 1);
+		return;
+	}
+	const int slot = atomicAdd(&counts[bno], 1);
+	if(slot >= cfg.ppb) {
+		atomicOr(&status[ST_OVERFLOW], 2);
+		return;
+	}
+	ids[(size_t) bno * cfg.ppb + slot] = (int) i;
+}
+// compute_bin_capacity + scan (:86-94) as one atomic allocation per block; also row_of = identity
+__global__ void init_bins_kernel(int pbc, const int* __restrict__ counts, int* size, int* row_of, int* binoff_a, int* binoff_b, int* bin_total) {
+	const int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if(b >= pbc) return;
+	const int c		= counts[b];
+	size[b]			= c;
+	row_of[b]		= b;
+	const int nbins = (c + kBin - 1) / kBin;
+	const int off	= nbins ? atomicAdd(bin_total, nbins) : 0;
+	binoff_a[b]		= off;
+	binoff_b[b]		= off;
+}
+// array_to_buffer (:221-323) + init_adv_bucket (:96-104): one workgroup per block
+__global__ __launch_bounds__(256) void fill_bins_kernel(GridCfg cfg, int nch, float log_jp0, const float* __restrict__ xyz, const int* __restrict__ ids, const int* __restrict__ size, const int* __restrict__ binoff, float* bins, int* list_in) {
+	const int b = blockIdx.x;
+	const int n = size[b];
+	for(int pidib = threadIdx.x; pidib < n; pidib += blockDim.x) {
+		const int pid = ids[(size_t) b * cfg.ppb + pidib];
+		float* dst	  = bins + (size_t) (binoff[b] + (pidib >> 6)) * (nch * kBin) + (pidib & 63);
+		dst[0]		  = xyz[3 * (size_t) pid];
+		dst[kBin]	  = xyz[3 * (size_t) pid + 1];
+		dst[2 * kBin] = xyz[3 * (size_t) pid + 2];
+		if(nch == 4) {
+			dst[3 * kBin] = 1.f;
+		} else {
+			for(int d = 0; d < 9; ++d) dst[(3 + d) * kBin] = (d % 4 == 0) ? 1.f : 0.f;
+			if(nch == 13) dst[12 * kBin] = log_jp0;
+		}
+		list_in[(size_t) b * cfg.ppb + pidib] = (kStay << cfg.pid_bits) | pidib;
+	}
+}
+// rasterize, mgmpm_kernels.cuh:153-219 (one-time, global atomics)
+__global__ void rasterize_kernel(GridCfg cfg, size_t n, const float* __restrict__ xyz, const int* __restrict__ table, float* grid, float mass, float v0x, float v0y, float v0z) {
+	const size_t pi = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(pi >= n) return;
+	int base[3];
+	float w[3][3];
+	for(int d = 0; d < 3; ++d) {
+		const float p = xyz[3 * pi + d] * cfg.dx_inv;
+		base[d]		  = (int) __builtin_roundf(p) - 1;
+		bspline_weight_cells(p - (float) base[d], w[d]);
+	}
+	for(int i = 0; i < 3; ++i)
+		for(int j = 0; j < 3; ++j)
+			for(int k = 0; k < 3; ++k) {
+				const int gx = base[0] + i, gy = base[1] + j, gz = base[2] + k;
+				const int bno = table_query(cfg, table, gx >> 2, gy >> 2, gz >> 2);
+				if(bno < 0) continue;
+				const float wm = mass * (w[0][i] * w[1][j] * w[2][k]);
+				float* g	   = grid + (size_t) bno * 256 + (gx & 3) * 16 + (gy & 3) * 4 + (gz & 3);
+				unsafeAtomicAdd(g, wm);
+				unsafeAtomicAdd(g + 64, wm * v0x);
+				unsafeAtomicAdd(g + 128, wm * v0y);
+				unsafeAtomicAdd(g + 192, wm * v0z);
+			}
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Output: retrieve_particle_buffer, mgmpm_kernels.cuh:1087-1122 (+ state for the parity tests)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void retrieve_kernel(GridCfg cfg, int nch, const int* __restrict__ cur_keys, const int* __restrict__ prev_table, const int* __restrict__ size, const int* __restrict__ row_of, const int* __restrict__ list_in, const int* __restrict__ binoff_src, const float* __restrict__ bins_src, float* xyz, float* state9, float* logjp, unsigned long long capacity, unsigned long long* counter) {
+	const int b = blockIdx.x;
+	const int n = size[b];
+	if(n == 0) return;
+	const int kx = cur_keys[3 * b], ky = cur_keys[3 * b + 1], kz = cur_keys[3 * b + 2];
+	const int* list = list_in + (size_t) row_of[b] * cfg.ppb;
+	for(int pidib = threadIdx.x; pidib < n; pidib += blockDim.x) {
+		const int rec = list[pidib];
+		int ox, oy, oz;
+		dir_components(rec >> cfg.pid_bits, ox, oy, oz);
+		const int sp	 = rec & (cfg.ppb - 1);
+		const int srcno	 = table_query(cfg, prev_table, kx + ox, ky + oy, kz + oz);
+		const float* src = bins_src + (size_t) (binoff_src[srcno] + (sp >> 6)) * (nch * kBin) + (sp & 63);
+		const unsigned long long o = atomicAdd(counter, 1ull);
+		if(o >= capacity) continue;
+		xyz[3 * o]	   = src[0];
+		xyz[3 * o + 1] = src[kBin];
+		xyz[3 * o + 2] = src[2 * kBin];
+		if(state9) {
+			if(nch == 4) {
+				state9[9 * o] = src[3 * kBin];
+				for(int d = 1; d < 9; ++d) state9[9 * o + d] = 0.f;
+			} else {
+				for(int d = 0; d < 9; ++d) state9[9 * o + d] = src[(3 + d) * kBin];
+			}
+		}
+		if(logjp) logjp[o] = nch == 13 ? src[12 * kBin] : 0.f;
+	}
+}
+
+__global__ void grid_totals_kernel(int nblocks, const float* __restrict__ grid, double* out) {
+	const int lane = threadIdx.x & 63;
+	double acc[4]  = {0, 0, 0, 0};
+	for(int b = blockIdx.x * 4 + (threadIdx.x >> 6); b < nblocks; b += gridDim.x * 4) {
+		const float* g = grid + (size_t) b * 256;
+		for(int ch = 0; ch < 4; ++ch) acc[ch] += (double) g[ch * 64 + lane];
+	}
+	for(int ch = 0; ch < 4; ++ch) {
+		double v = acc[ch];
+		for(int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+		if(lane == 0) atomicAdd(&out[ch], v);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Function-level test kernels (device math vs golden vectors)
+// ------------------------------------------------------------------------------------------------------
+__global__ void test_svd_kernel(size_t n, const float* __restrict__ Fin, float* __restrict__ out21) {
+	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	float F[9], U[9], S[3], V[9];
+	for(int d = 0; d < 9; ++d) F[d] = Fin[9 * i + d];
+	svd3(F, U, S, V);
+	for(int d = 0; d < 9; ++d) out21[21 * i + d] = U[d];
+	for(int d = 0; d < 3; ++d) out21[21 * i + 9 + d] = S[d];
+	for(int d = 0; d < 9; ++d) out21[21 * i + 12 + d] = V[d];
+}
+__global__ void test_stress_kernel(int material, MaterialConst mc, size_t n, const float* __restrict__ Fin, const float* __restrict__ ljin, float* __restrict__ out19) {
+	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	float F[9], PF[9];
+	for(int d = 0; d < 9; ++d) F[d] = Fin[9 * i + d];
+	float lj = ljin ? ljin[i] : 0.f;
+	if(material == 1)
+		stress_fixed_corotated(mc, F, PF);
+	else if(material == 2)
+		stress_sand(mc, F, lj, PF);
+	else
+		stress_nacc(mc, F, lj, PF);
+	for(int d = 0; d < 9; ++d) out19[19 * i + d] = F[d];
+	for(int d = 0; d < 9; ++d) out19[19 * i + 9 + d] = PF[d];
+	out19[19 * i + 18] = lj;
+}
+
+}// namespace mpm

@@ -1,0 +1,107 @@
+"""Deterministic synthetic scenes of BASELINE.json's configs.
+
+Particles come from the reference's lattice rule `sample_uniform_box`
+(Library/MnBase/Geometry/GeometrySampler.h:11-37): 8 particles per grid node at node +- 0.25 dx;
+spheres are that lattice clipped by |x - c| <= R.  No RNG, no Data/ files.
+"""
+import numpy as np
+
+from ._ffi import FIXED_COROTATED, J_FLUID, NACC, SAND  # noqa: F401
+
+
+def lattice_box(bits, minc, maxc):
+    """All lattice particles of nodes minc <= (i,j,k) < maxc; float32 (n,3)."""
+    dx = np.float32(1.0 / (1 << bits))
+    ax = [np.arange(minc[d], maxc[d], dtype=np.float64) for d in range(3)]
+    off = np.array([-0.25, 0.25])
+    # per axis: node*dx +- 0.25dx  (exact in fp32: dx is a power of two)
+    coords = [((a[:, None] + off[None, :]) * float(dx)).reshape(-1) for a in ax]
+    # the reference nests i,j,k then ii,jj,kk; the order of particles is irrelevant to the physics,
+    # a plain tensor product is used here
+    X, Y, Z = np.meshgrid(coords[0], coords[1], coords[2], indexing="ij")
+    out = np.empty((X.size, 3), dtype=np.float32)
+    out[:, 0] = X.reshape(-1)
+    out[:, 1] = Y.reshape(-1)
+    out[:, 2] = Z.reshape(-1)
+    return out
+
+
+def lattice_sphere(bits, center, radius_cells):
+    dx = 1.0 / (1 << bits)
+    c = np.asarray(center, dtype=np.float64)
+    r = radius_cells * dx
+    lo = np.floor((c - r) / dx).astype(int) - 1
+    hi = np.ceil((c + r) / dx).astype(int) + 2
+    pts = lattice_box(bits, lo, hi)
+    d2 = ((pts.astype(np.float64) - c[None, :]) ** 2).sum(axis=1)
+    return np.ascontiguousarray(pts[d2 <= r * r])
+
+
+def _vol(bits):
+    dx = 1.0 / (1 << bits)
+    return float(np.float32(dx * dx * dx / 8.0))
+
+
+def two_spheres(bits=7, radius_cells=9.0, gap_cells=None, speed=0.5, material=FIXED_COROTATED, youngs=5e3):
+    """C1: two elastic spheres colliding (BASELINE config 1).  Default: centres (0.40,0.5,0.5)/(0.60,0.5,0.5),
+    R = 9 dx, v = (+-0.5, 0, 0), fixed-corotated E = 5e3, nu = 0.4, rho = 1e3, vol = dx^3/8."""
+    dx = 1.0 / (1 << bits)
+    if gap_cells is None:
+        c0, c1 = (0.40, 0.5, 0.5), (0.60, 0.5, 0.5)
+    else:
+        half = (radius_cells + gap_cells / 2.0) * dx
+        c0, c1 = (0.5 - half, 0.5, 0.5), (0.5 + half, 0.5, 0.5)
+    prm = {"volume": _vol(bits), "youngs_modulus": youngs, "poisson_ratio": 0.4, "rho": 1e3}
+    return {
+        "name": "two_spheres", "bits": bits, "dt": 1e-4,
+        "config": {"max_ppc": 32},
+        "models": [
+            {"material": material, "xyz": lattice_sphere(bits, c0, radius_cells), "v0": (speed, 0.0, 0.0), "params": dict(prm)},
+            {"material": material, "xyz": lattice_sphere(bits, c1, radius_cells), "v0": (-speed, 0.0, 0.0), "params": dict(prm)},
+        ],
+    }
+
+
+def sphere_drop(bits=8, radius_cells=53.0, center=(0.5, 0.6, 0.5), material=FIXED_COROTATED):
+    """C2: one elastic sphere dropped under gravity (~5.0 M particles at bits 8, R = 53 dx)."""
+    prm = {"volume": _vol(bits)} if material != SAND else {}
+    return {"name": "sphere_drop", "bits": bits, "dt": 1e-4, "config": {"max_ppc": 32},
+            "models": [{"material": material, "xyz": lattice_sphere(bits, center, radius_cells), "v0": (0, 0, 0), "params": prm}]}
+
+
+def sand_column(bits=9, size_cells=(128, 306, 128), min_corner=None):
+    """C3: Drucker-Prager sand column collapse; at bits 9 the default box holds 128*306*128*8 = 40.1 M particles.
+    Reference sand defaults (particle_buffer.cuh:202-218) incl. its volume."""
+    if min_corner is None:
+        n = 1 << bits
+        min_corner = ((n - size_cells[0]) // 2, 12, (n - size_cells[2]) // 2)
+    lo = np.array(min_corner)
+    hi = lo + np.array(size_cells)
+    return {"name": "sand_column", "bits": bits, "dt": 1e-4, "config": {"max_ppc": 32},
+            "models": [{"material": SAND, "xyz": lattice_box(bits, lo, hi), "v0": (0, 0, 0), "params": {}}]}
+
+
+def scaled_sand_column(bits, fraction):
+    """A geometrically similar, smaller sand column (same aspect ratio) for bounded CPU samples / tests."""
+    s = fraction ** (1.0 / 3.0)
+    full = np.array([128, 306, 128]) * (1 << bits) / 512.0
+    size = np.maximum(4, np.round(full * s)).astype(int)
+    return sand_column(bits, tuple(int(x) for x in size))
+
+
+def fluid_dam(bits=10, size_cells=(256, 192, 256), min_corner=(12, 12, 12)):
+    """C5: weakly compressible J-fluid dam break (reference defaults particle_buffer.cuh:148-153)."""
+    lo = np.array(min_corner)
+    hi = lo + np.array(size_cells)
+    return {"name": "fluid_dam", "bits": bits, "dt": 1e-4, "config": {"max_ppc": 32},
+            "models": [{"material": J_FLUID, "xyz": lattice_box(bits, lo, hi), "v0": (0, 0, 0), "params": {}}]}
+
+
+def split_slabs(xyz, parts, axis=0):
+    """Static particle partition of MGSP: equal-count slabs of the initial lattice along `axis`."""
+    order = np.argsort(xyz[:, axis], kind="stable")
+    return [np.ascontiguousarray(xyz[idx]) for idx in np.array_split(order, parts)]
+
+
+def total_particles(scene):
+    return int(sum(m["xyz"].shape[0] for m in scene["models"]))

@@ -1,0 +1,189 @@
+/*
+ * claymore_amd.h — C ABI of the MI355X-native MPM substep engine (libclaymore_hip.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of penn-graphics-research/claymore:
+ *     grid update -> fused G2P2G -> sparse block-partition rebuild      (Projects/GMPM)
+ *     + static-particle-partition halo exchange                          (Projects/MGSP)
+ * The reference has no FFI layer: its kernels are C++ templates launched through
+ * Cuda::CudaContext::compute_launch (Library/MnSystem/Cuda/Cuda.h:151-184) from the two host classes
+ * GmpmSimulator (Projects/GMPM/gmpm_simulator.cuh) and MgspBenchmark (Projects/MGSP/mgsp_benchmark.cuh).
+ * Each entry point below replaces one phase of those classes; the file:line it replaces is cited.
+ *
+ * Conventions
+ *   - plain C, POD structs, caller-owned host arrays are copied during the call, the context owns
+ *     every device buffer (reference: members of GmpmSimulator, gmpm_simulator.cuh:96-141);
+ *   - every function returns an mpm_status (0 = ok); mpm_last_error() gives the text.  The reference
+ *     prints and exit()s (Library/MnSystem/Cuda/HostUtils.hpp:33-44) or abort()s on capacity overflow
+ *     (gmpm_simulator.cuh:473-476); host drivers map a non-zero status to that behaviour;
+ *   - a context is bound to one HIP device and is single-thread-affine (reference: one worker thread
+ *     per GPU, mgsp_benchmark.cuh:309-334);
+ *   - there is NO CPU fallback behind this ABI: if no HIP device is usable, mpm_create fails.
+ *
+ * The CPU oracle (oracle/, test infrastructure only) exports the same functions with the prefix
+ * mpmo_ instead of mpm_ so that tests can drive both through identical call sequences.
+ */
+#ifndef CLAYMORE_AMD_H
+#define CLAYMORE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum mpm_status {
+	MPM_OK			   = 0,
+	MPM_ERR_INVALID	   = 1, /* bad argument / call order */
+	MPM_ERR_DEVICE	   = 2, /* HIP runtime error (reference: check_cuda_errors -> exit) */
+	MPM_ERR_CAPACITY   = 3, /* block / bin / cell capacity exceeded (reference: std::abort) */
+	MPM_ERR_NONFINITE  = 4, /* inf/NaN grid velocity (reference: stops main loop, gmpm_simulator.cuh:355-358) */
+	MPM_ERR_NOT_READY  = 5
+} mpm_status;
+
+/* Projects/GMPM/settings.h:20-26 */
+typedef enum mpm_material {
+	MPM_J_FLUID			= 0,
+	MPM_FIXED_COROTATED = 1,
+	MPM_SAND			= 2,
+	MPM_NACC			= 3
+} mpm_material;
+
+/* Runtime replacement of the compile-time config:: constants (Projects/GMPM/settings.h:33-96). */
+typedef struct mpm_config {
+	int domain_bits;	 /* grid = 2^bits cells per axis on [0,1)^3; settings.h:59 DOMAIN_BITS (7..10) */
+	int max_ppc;		 /* particles per cell capacity; settings.h:75 (reference 128); power of two <= 128 */
+	int boundary_blocks; /* slip-wall zone in blocks; settings.h:63 G_BOUNDARY_CONDITION = 2 */
+	float gravity;		 /* settings.h:85 (-9.8; MGSP settings.h:108 uses -4.9) */
+	float cfl;			 /* utility_funcs.hpp:41 uses 0.5 (MGSP utility_funcs.hpp:39: 0.3) */
+	int64_t max_blocks;	 /* capacity in (exterior) blocks; settings.h:89 G_MAX_ACTIVE_BLOCK; 0 = size from the models */
+	int reserved[6];
+} mpm_config;
+
+/* Material parameter block (Projects/GMPM/particle_buffer.cuh:141-264).  Unused fields are ignored. */
+typedef struct mpm_material_params {
+	float rho;			  /* density; mass = rho * volume (particle_buffer.cuh:155-162) */
+	float volume;		  /* particle volume */
+	float youngs_modulus; /* FC / SAND / NACC */
+	float poisson_ratio;
+	float bulk;		 /* J_FLUID */
+	float gamma;	 /* J_FLUID */
+	float viscosity; /* J_FLUID */
+	float beta;		 /* SAND (1.0) / NACC (0.5) */
+	float xi;		 /* NACC hardening factor */
+	float cohesion;	 /* SAND */
+	float yield_surface;   /* SAND */
+	float msqr;			   /* NACC */
+	float log_jp0;		   /* SAND 0, NACC -0.01 */
+	int volume_correction; /* SAND */
+	int hardening_on;	   /* NACC */
+	int reserved[5];
+} mpm_material_params;
+
+/* Block / bin counts after a rebuild (gmpm_simulator.cuh:572-575 prints exactly these). */
+typedef struct mpm_counts {
+	int particle_blocks; /* partition_block_count */
+	int neighbor_blocks; /* neighbor_block_count  */
+	int exterior_blocks; /* exterior_block_count  */
+	int model_count;
+	int64_t bins[8];	  /* per model, bincount[i] */
+	int64_t particles[8]; /* per model, particles currently bucketed */
+} mpm_counts;
+
+/* Per-phase device time of the most recent substep, in milliseconds (reference CudaTimer tags,
+ * gmpm_simulator.cuh:346,400,507,526,543,576). */
+typedef struct mpm_timers {
+	float grid_update_ms;
+	float g2p2g_ms;
+	float partition_ms;
+	float halo_ms;
+	float total_ms;
+	float reserved[3];
+} mpm_timers;
+
+typedef struct mpm_ctx mpm_ctx;
+
+/* Fill cfg with the reference defaults for a grid resolution (settings.h). */
+int mpm_default_config(int domain_bits, mpm_config* cfg);
+/* Fill p with the reference defaults for a material at a resolution (particle_buffer.cuh:144-264;
+ * note the FIXED_COROTATED and SAND default volume carries the reference's 10x factor, :176,:203). */
+int mpm_default_material(int material, int domain_bits, mpm_material_params* p);
+
+/* GmpmSimulator::GmpmSimulator + initialize (gmpm_simulator.cuh:121-166), Cuda::Cuda (Cuda.cu:28-137). */
+int mpm_create(const mpm_config* cfg, int device, mpm_ctx** out);
+void mpm_destroy(mpm_ctx* ctx);
+const char* mpm_last_error(const mpm_ctx* ctx);
+
+/* init_model<M> + update_*_parameters (gmpm_simulator.cuh:168-254). xyz = n*3 floats (host). Returns the
+ * model index through *model_id. */
+int mpm_add_model(mpm_ctx* ctx, int material, const mpm_material_params* params, const float* xyz, size_t n, const float v0[3], int* model_id);
+
+/* initial_setup (gmpm_simulator.cuh:637-781): activate blocks, bucket particles, fill bins, build the
+ * neighbor/exterior partition, rasterize the initial grid. */
+int mpm_initial_setup(mpm_ctx* ctx);
+
+/* Grid-update phase (gmpm_simulator.cuh:326-347; kernel mgmpm_kernels.cuh:325-420).  *max_vel_sqr receives
+ * max |v|^2 over grid nodes (inf if a NaN was seen). */
+int mpm_grid_update(mpm_ctx* ctx, float dt, float* max_vel_sqr);
+/* compute_dt (utility_funcs.hpp:36-49) with this context's dx and CFL. */
+float mpm_compute_dt(const mpm_ctx* ctx, float max_vel, float cur_time, float next_time, float dt_default);
+/* G2P2G phase (gmpm_simulator.cuh:364-413; kernel mgmpm_kernels.cuh:665-937). */
+int mpm_g2p2g(mpm_ctx* ctx, float dt, float next_dt);
+/* Partition rebuild (gmpm_simulator.cuh:415-579), ends with the double-buffer roll. counts may be NULL. */
+int mpm_rebuild_partition(mpm_ctx* ctx, mpm_counts* counts);
+
+/* One whole substep = grid update, host dt, g2p2g, rebuild (the body of the loop gmpm_simulator.cuh:324-580).
+ * dt is the current step; *next_dt = compute_dt(sqrt(max|v|^2), step_time, frame_time, dt_default). */
+int mpm_substep(mpm_ctx* ctx, float dt, float step_time, float frame_time, float dt_default, float* next_dt, float* max_vel);
+/* Convenience for benchmarking: n substeps with a fixed dt (next_dt = dt), no host dt logic in between. */
+int mpm_run_fixed(mpm_ctx* ctx, int nsteps, float dt);
+
+/* output_model (gmpm_simulator.cuh:594-634; kernel mgmpm_kernels.cuh:1087-1122): positions of a model, order
+ * unspecified.  *n: in = capacity of xyz in particles, out = particles written. */
+int mpm_retrieve_positions(mpm_ctx* ctx, int model, float* xyz, size_t* n);
+/* Extension used by the parity tests: also the per-particle state, same order as xyz.
+ * state9: F (column-major 9 floats) for FC/SAND/NACC, or J in state9[9*i] for J_FLUID; logjp may be NULL. */
+int mpm_retrieve_state(mpm_ctx* ctx, int model, float* xyz, float* state9, float* logjp, size_t* n);
+
+int mpm_get_counts(mpm_ctx* ctx, mpm_counts* counts);
+int mpm_get_timers(mpm_ctx* ctx, mpm_timers* t);
+/* Sum over the current grid of {mass, momentum x, y, z} (the reference's sum_grid_mass debug kernel,
+ * mgmpm_kernels.cuh:1034-1037, extended to momentum); valid between rebuild and the next grid update. */
+int mpm_grid_totals(mpm_ctx* ctx, double out[4]);
+/* Dense dump of the current grid for parity tests: for every neighbor block, key (3 ints) and 256 floats
+ * {mass[64], mvx[64], mvy[64], mvz[64]} (grid_buffer.cuh:12-14 layout). *nblocks in = capacity, out = count. */
+int mpm_dump_grid(mpm_ctx* ctx, int* keys, float* blocks, size_t* nblocks);
+/* G2P2G kernel time of the last call as measured with HIP events on the compute stream. */
+int mpm_last_g2p2g_ms(mpm_ctx* ctx, float* ms);
+
+/* ---- function-level entry points used by the parity tests (device versions of the per-particle math) ---- */
+/* math::svd (Library/MnBase/Math/Matrix/svd.cuh:27-1123): F[n*9] column-major -> out[n*21] = U(9) S(3) V(9). */
+int mpm_test_svd(const float* F, size_t n, float* out21, int device);
+/* compute_stress<M> (Projects/GMPM/constitutive_models.cuh): out19 = F'(9) PF(9) logjp'(1). */
+int mpm_test_stress(int material, const mpm_material_params* p, const float* F, const float* logjp, size_t n, float* out19, int device);
+
+/* ---- multi-GPU (MGSP static particle partition, Projects/MGSP/mgsp_benchmark.cuh:661-776) ---- */
+/* Device pointer + count of this rank's neighbor-block keys (ivec3) for the all-gather of mgsp_benchmark.cuh:681-686. */
+int mpm_halo_keys(mpm_ctx* ctx, const int** dev_keys, int* count);
+/* mark_overlapping_blocks (halo_kernels.cuh:21-35): peer_keys is a DEVICE array of npeer_keys ivec3 from peer
+ * `peer`; builds this rank's send list for that peer.  *nsend receives the number of overlapping blocks. */
+int mpm_halo_tag_peer(mpm_ctx* ctx, int peer, const int* dev_peer_keys, int npeer_keys, int* nsend);
+int mpm_halo_tag_begin(mpm_ctx* ctx);
+/* collect_blockids_for_halo_reduction (halo_kernels.cuh:37-62): split particle blocks into halo / interior lists. */
+int mpm_halo_tag_end(mpm_ctx* ctx, int* halo_particle_blocks);
+/* Phases of a multi-GPU substep (mgsp_benchmark.cuh:421-465): g2p2g on the halo list, on the interior list. */
+int mpm_g2p2g_halo(mpm_ctx* ctx, float dt, float next_dt);
+int mpm_g2p2g_interior(mpm_ctx* ctx, float dt, float next_dt);
+/* collect_grid_blocks (halo_kernels.cuh:64-80): gather the blocks to send to `peer` into DEVICE buffers
+ * dev_keys (nsend*3 ints) and dev_blocks (nsend*256 floats) supplied by the caller (e.g. torch tensors). */
+int mpm_halo_collect(mpm_ctx* ctx, int peer, int* dev_keys, float* dev_blocks, int capacity_blocks, int* nsend);
+/* reduce_grid_blocks (halo_kernels.cuh:82-97): add nrecv received blocks (DEVICE buffers) into the P2G grid. */
+int mpm_halo_reduce(mpm_ctx* ctx, const int* dev_keys, const float* dev_blocks, int nrecv);
+/* HIP stream handles (as void*) so that the caller can order collectives against the engine. */
+int mpm_streams(mpm_ctx* ctx, void** compute_stream, void** comm_stream);
+int mpm_sync(mpm_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

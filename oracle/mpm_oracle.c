@@ -1,0 +1,969 @@
+/*
+ * mpm_oracle.c — TEST INFRASTRUCTURE ONLY.
+ *
+ * Serial CPU restatement (plain C99) of claymore's single-GPU substep pipeline (Projects/GMPM):
+ *     initial_setup -> { update_grid_velocity_query_max -> g2p2g -> partition rebuild }*
+ * Every stage follows the reference kernel it names, thread loops replaced by sequential loops in
+ * block/thread order (so float sums and bucket orders are one admissible outcome of the reference's
+ * atomics).  It is the parity checker for the HIP engine and the "port" CPU baseline of bench.py.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product
+ * (claymore_amd/, libclaymore_hip.so) never does.
+ *
+ * Parity pin: the per-particle functions (mpm_oracle_math.h) are checked against golden vectors produced
+ * by the reference's own code (tests/golden); the pipeline around them has no reference-run output to
+ * compare with (no nvcc / NVIDIA GPU here, and the reference has no tests) and is pinned by invariants
+ * (mass / momentum / particle-count conservation, table consistency) in tests/test_oracle_pipeline.py.
+ *
+ * Exports the C ABI of include/claymore_amd.h with the prefix mpmo_.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
+
+#include "../include/claymore_amd.h"
+#include "mpm_oracle_math.h"
+
+#define ORC_BIN 32	   /* settings.h:77 G_BIN_CAPACITY */
+#define ORC_BLOCKVOL 64 /* settings.h:70 G_BLOCKVOLUME */
+#define ORC_MAX_MODELS 8
+
+typedef struct {
+	int* index_table; /* G^3 ints, -1 = empty (hash_table.cuh:107-112) */
+	int* keys;		  /* capacity*3 */
+	int count;
+} orc_partition;
+
+typedef struct {
+	float* bins; /* [bin][channel][slot], particle_buffer.cuh:17-41 (channel stride = ORC_BIN floats) */
+	size_t bin_cap;
+	int* cell_counts;  /* [block][64] */
+	int* cellbuckets;  /* [block][64][max_ppc] */
+	int* blockbuckets; /* [block][ppb] */
+	int* bucket_sizes; /* [block] */
+	int* bin_offsets;  /* [block] */
+} orc_pbuf;
+
+typedef struct {
+	int material;
+	mpm_material_params p;
+	float mass, volume, mu, lambda, bm;
+	int nch;
+	size_t n;
+	float* xyz; /* particle array (input, and output of retrieve) */
+	float v0[3];
+	orc_pbuf buf[2];
+	int64_t bincount;
+} orc_model;
+
+typedef struct mpmo_ctx {
+	mpm_config cfg;
+	int G;	 /* blocks per axis */
+	int ppb; /* particles per block capacity = max_ppc*64 (settings.h:78) */
+	float dx, dx_inv, d_inv;
+	size_t cap; /* block capacity */
+	orc_partition part[2];
+	float* grid[2]; /* [block][4][64] */
+	int rollid;
+	int pbc, nbc, ebc;
+	int nmodels;
+	orc_model models[ORC_MAX_MODELS];
+	int *marks, *sources, *destinations, *bin_sizes;
+	int ready;
+	mpm_timers timers;
+	char err[256];
+} mpmo_ctx;
+
+static double now_ms(void) {
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+int mpmo_default_config(int domain_bits, mpm_config* cfg) {
+	if(!cfg || domain_bits < 4 || domain_bits > 10) return MPM_ERR_INVALID;
+	memset(cfg, 0, sizeof(*cfg));
+	cfg->domain_bits	 = domain_bits;
+	cfg->max_ppc		 = 128;	  /* settings.h:75 */
+	cfg->boundary_blocks = 2;	  /* settings.h:63 */
+	cfg->gravity		 = -9.8f; /* settings.h:85 */
+	cfg->cfl			 = 0.5f;  /* settings.h:53 */
+	cfg->max_blocks		 = 0;
+	return MPM_OK;
+}
+
+int mpmo_default_material(int material, int domain_bits, mpm_material_params* p) {
+	if(!p) return MPM_ERR_INVALID;
+	memset(p, 0, sizeof(*p));
+	const float n	   = (float) (1u << domain_bits);
+	p->rho			   = 1e3f;		   /* settings.h:81 */
+	p->youngs_modulus  = 5e3f;		   /* settings.h:82 */
+	p->poisson_ratio   = 0.4f;		   /* settings.h:83 */
+	const float vol1   = 1.0f / n / n / n / 8.0f;
+	const float vol10  = 10.f / n / n / n / 8.0f; /* particle_buffer.cuh:176,:203 (sic) */
+	switch(material) {
+		case MPM_J_FLUID: /* particle_buffer.cuh:148-153 */
+			p->volume	 = vol1;
+			p->bulk		 = 4e4f;
+			p->gamma	 = 7.15f;
+			p->viscosity = 0.01f;
+			break;
+		case MPM_FIXED_COROTATED: p->volume = vol10; break;
+		case MPM_SAND: /* particle_buffer.cuh:202-218 */
+			p->volume			 = vol10;
+			p->cohesion			 = 0.f;
+			p->beta				 = 1.f;
+			p->yield_surface	 = 0.816496580927726f * 2.f * 0.5f / (3.f - 0.5f);
+			p->volume_correction = 1;
+			p->log_jp0			 = 0.f;
+			break;
+		case MPM_NACC: /* particle_buffer.cuh:231-247 */
+			p->volume		= vol1;
+			p->xi			= 0.8f;
+			p->beta			= 0.5f;
+			p->msqr			= 3.423772074299613f;
+			p->hardening_on = 1;
+			p->log_jp0		= -0.01f;
+			break;
+		default: return MPM_ERR_INVALID;
+	}
+	return MPM_OK;
+}
+
+int mpmo_create(const mpm_config* cfg, int device, mpmo_ctx** out) {
+	(void) device;
+	if(!cfg || !out) return MPM_ERR_INVALID;
+	if(cfg->domain_bits < 4 || cfg->domain_bits > 10) return MPM_ERR_INVALID;
+	if(cfg->max_ppc < 1 || cfg->max_ppc > 128 || (cfg->max_ppc & (cfg->max_ppc - 1))) return MPM_ERR_INVALID;
+	mpmo_ctx* c = (mpmo_ctx*) calloc(1, sizeof(mpmo_ctx));
+	c->cfg		= *cfg;
+	c->G		= 1 << (cfg->domain_bits - 2);
+	c->ppb		= cfg->max_ppc * ORC_BLOCKVOL;
+	c->dx_inv	= (float) (1 << cfg->domain_bits); /* settings.h:60 */
+	c->dx		= 1.f / c->dx_inv;				   /* settings.h:64 */
+	c->d_inv	= 4.f * c->dx_inv * c->dx_inv;	   /* settings.h:66 */
+	*out		= c;
+	return MPM_OK;
+}
+
+static void free_pbuf(orc_pbuf* b) {
+	free(b->bins);
+	free(b->cell_counts);
+	free(b->cellbuckets);
+	free(b->blockbuckets);
+	free(b->bucket_sizes);
+	free(b->bin_offsets);
+}
+
+void mpmo_destroy(mpmo_ctx* c) {
+	if(!c) return;
+	for(int i = 0; i < 2; ++i) {
+		free(c->part[i].index_table);
+		free(c->part[i].keys);
+		free(c->grid[i]);
+	}
+	for(int m = 0; m < c->nmodels; ++m) {
+		free(c->models[m].xyz);
+		free_pbuf(&c->models[m].buf[0]);
+		free_pbuf(&c->models[m].buf[1]);
+	}
+	free(c->marks);
+	free(c->sources);
+	free(c->destinations);
+	free(c->bin_sizes);
+	free(c);
+}
+
+const char* mpmo_last_error(const mpmo_ctx* c) {
+	return c ? c->err : "null context";
+}
+
+static int fail(mpmo_ctx* c, int code, const char* msg) {
+	snprintf(c->err, sizeof(c->err), "%s", msg);
+	return code;
+}
+
+int mpmo_add_model(mpmo_ctx* c, int material, const mpm_material_params* p, const float* xyz, size_t n, const float v0[3], int* model_id) {
+	if(!c || !p || !xyz || c->ready) return MPM_ERR_INVALID;
+	if(c->nmodels >= ORC_MAX_MODELS) return fail(c, MPM_ERR_CAPACITY, "too many models");
+	orc_model* m = &c->models[c->nmodels];
+	memset(m, 0, sizeof(*m));
+	m->material = material;
+	m->p		= *p;
+	m->volume	= p->volume;
+	m->mass		= p->volume * p->rho; /* particle_buffer.cuh:158,:186,:252 */
+	const float e = p->youngs_modulus, nu = p->poisson_ratio;
+	m->lambda = e * nu / ((1 + nu) * (1 - 2 * nu)); /* particle_buffer.cuh:187 */
+	m->mu	  = e / (2 * (1 + nu));					/* :188 */
+	m->bm	  = 2.f / 3.f * (e / (2 * (1 + nu))) + (e * nu / ((1 + nu) * (1 - 2 * nu))); /* :255 */
+	m->nch	  = material == MPM_J_FLUID ? 4 : (material == MPM_FIXED_COROTATED ? 12 : 13);
+	m->n	  = n;
+	m->xyz	  = (float*) malloc(sizeof(float) * 3 * (n ? n : 1));
+	memcpy(m->xyz, xyz, sizeof(float) * 3 * n);
+	for(int d = 0; d < 3; ++d) m->v0[d] = v0 ? v0[d] : 0.f;
+	if(model_id) *model_id = c->nmodels;
+	c->nmodels++;
+	return MPM_OK;
+}
+
+/* ---- Partition (Projects/GMPM/hash_table.cuh:76-135) ---- */
+static inline int key_in_range(const mpmo_ctx* c, int x, int y, int z) {
+	return x >= 0 && y >= 0 && z >= 0 && x < c->G && y < c->G && z < c->G;
+}
+static inline size_t key_index(const mpmo_ctx* c, int x, int y, int z) {
+	return ((size_t) x * c->G + y) * c->G + z; /* CompactDomain row-major, StructuralDeclaration.h:235-251 */
+}
+static inline int part_query(const mpmo_ctx* c, const orc_partition* p, int x, int y, int z) {
+	if(!key_in_range(c, x, y, z)) return -1; /* reference: out-of-range is undefined behaviour */
+	return p->index_table[key_index(c, x, y, z)];
+}
+/* hash_table.cuh:118-127 insert */
+static inline int part_insert(mpmo_ctx* c, orc_partition* p, int x, int y, int z) {
+	if(!key_in_range(c, x, y, z)) return -1;
+	size_t i = key_index(c, x, y, z);
+	if(p->index_table[i] != -1) return -1;
+	if((size_t) p->count >= c->cap) {
+		p->count++; /* keep counting so that the caller can report the overflow */
+		return -1;
+	}
+	int idx				 = p->count++;
+	p->index_table[i]	 = idx;
+	p->keys[3 * idx + 0] = x;
+	p->keys[3 * idx + 1] = y;
+	p->keys[3 * idx + 2] = z;
+	return idx;
+}
+static void part_reset_table(mpmo_ctx* c, orc_partition* p) {
+	memset(p->index_table, 0xff, sizeof(int) * (size_t) c->G * c->G * c->G);
+}
+
+static inline float* grid_block(float* grid, int blockno) {
+	return grid + (size_t) blockno * 256; /* grid_buffer.cuh:12-14: 4 channels x 64 cells */
+}
+static inline float* bin_ptr(const orc_model* m, const orc_pbuf* b, int binno) {
+	return b->bins + (size_t) binno * m->nch * ORC_BIN;
+}
+
+/* mgmpm_kernels.cuh:106-115 clear_grid */
+static void clear_grid(float* grid, int nblocks) {
+	memset(grid, 0, sizeof(float) * 256 * (size_t) nblocks);
+}
+
+/* mgmpm_kernels.cuh:70-84 cell_bucket_to_block: round k takes the k-th particle of every cell, cells ascending */
+static void cell_bucket_to_block(mpmo_ctx* c, orc_pbuf* b, int nblocks) {
+	const int mp = c->cfg.max_ppc;
+	for(int blk = 0; blk < nblocks; ++blk) {
+		const int* counts = b->cell_counts + (size_t) blk * ORC_BLOCKVOL;
+		int* out		  = b->blockbuckets + (size_t) blk * c->ppb;
+		int size		  = 0;
+		for(int k = 0; k < mp; ++k) {
+			for(int cell = 0; cell < ORC_BLOCKVOL; ++cell) {
+				if(k < counts[cell]) out[size++] = b->cellbuckets[(size_t) blk * c->ppb + (size_t) cell * mp + k];
+			}
+		}
+		b->bucket_sizes[blk] = size;
+	}
+}
+
+/* compute_bin_capacity + exclusive scan (mgmpm_kernels.cuh:86-94, gmpm_simulator.cuh:496-503) over pbc+1 entries */
+static int64_t bin_offsets_scan(mpmo_ctx* c, orc_pbuf* b, int pbc) {
+	int64_t acc = 0;
+	for(int blk = 0; blk <= pbc; ++blk) {
+		b->bin_offsets[blk] = (int) acc;
+		if(blk < pbc) acc += (b->bucket_sizes[blk] + ORC_BIN - 1) / ORC_BIN;
+	}
+	(void) c;
+	return acc;
+}
+
+/* mgmpm_kernels.cuh:117-133 / :135-151 */
+static void register_neighbor_blocks(mpmo_ctx* c, orc_partition* p, int pbc) {
+	for(int b = 0; b < pbc; ++b) {
+		const int x = p->keys[3 * b], y = p->keys[3 * b + 1], z = p->keys[3 * b + 2];
+		for(int i = 0; i < 2; ++i)
+			for(int j = 0; j < 2; ++j)
+				for(int k = 0; k < 2; ++k) part_insert(c, p, x + i, y + j, z + k);
+	}
+}
+static void register_exterior_blocks(mpmo_ctx* c, orc_partition* p, int pbc) {
+	for(int b = 0; b < pbc; ++b) {
+		const int x = p->keys[3 * b], y = p->keys[3 * b + 1], z = p->keys[3 * b + 2];
+		for(int i = -1; i < 2; ++i)
+			for(int j = -1; j < 2; ++j)
+				for(int k = -1; k < 2; ++k) part_insert(c, p, x + i, y + j, z + k);
+	}
+}
+
+static void alloc_pbuf(mpmo_ctx* c, orc_model* m, orc_pbuf* b, size_t bin_cap) {
+	b->bin_cap		= bin_cap;
+	b->bins			= (float*) calloc(bin_cap * m->nch * ORC_BIN, sizeof(float));
+	b->cell_counts	= (int*) calloc(c->cap * ORC_BLOCKVOL, sizeof(int));
+	b->cellbuckets	= (int*) calloc(c->cap * c->ppb, sizeof(int));
+	b->blockbuckets = (int*) calloc(c->cap * c->ppb, sizeof(int));
+	b->bucket_sizes = (int*) calloc(c->cap + 1, sizeof(int));
+	b->bin_offsets	= (int*) calloc(c->cap + 1, sizeof(int));
+}
+
+/* ParticleBufferImpl::add_advection, Projects/GMPM/particle_buffer.cuh:100-135 */
+static inline void add_advection(mpmo_ctx* c, orc_pbuf* b, const orc_partition* table, int cx, int cy, int cz, int dirtag, int pidib) {
+	const int bx = cx / 4, by = cy / 4, bz = cz / 4; /* C++ truncating ivec3 division, Vec.h */
+	const int blockno = part_query(c, table, bx, by, bz);
+	if(blockno == -1) return; /* particle is lost, :105-113 */
+	const int cellno = ((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3);
+	int* cnt		 = b->cell_counts + (size_t) blockno * ORC_BLOCKVOL + cellno;
+	const int slot	 = (*cnt)++;
+	if(slot >= c->cfg.max_ppc) {
+		(*cnt)--;
+		return;
+	}
+	b->cellbuckets[(size_t) blockno * c->ppb + (size_t) cellno * c->cfg.max_ppc + slot] = (dirtag * c->ppb) | pidib;
+}
+
+/* ---- initial_setup, Projects/GMPM/gmpm_simulator.cuh:637-781 ---- */
+int mpmo_initial_setup(mpmo_ctx* c) {
+	if(!c || c->ready || c->nmodels == 0) return MPM_ERR_INVALID;
+	const int r = c->rollid, n = r ^ 1;
+	/* capacity: count distinct particle blocks first (the reference uses the compile-time G_MAX_ACTIVE_BLOCK) */
+	size_t table = (size_t) c->G * c->G * c->G;
+	if(c->cfg.max_blocks > 0) {
+		c->cap = (size_t) c->cfg.max_blocks;
+	} else {
+		unsigned char* seen = (unsigned char*) calloc(table, 1);
+		size_t pb			= 0;
+		for(int mi = 0; mi < c->nmodels; ++mi) {
+			orc_model* m = &c->models[mi];
+			for(size_t i = 0; i < m->n; ++i) {
+				int k[3];
+				for(int d = 0; d < 3; ++d) k[d] = (orc_node_index(m->xyz[3 * i + d], c->dx_inv) - 2) / 4;
+				if(!key_in_range(c, k[0], k[1], k[2])) continue;
+				size_t idx = key_index(c, k[0], k[1], k[2]);
+				if(!seen[idx]) {
+					seen[idx] = 1;
+					pb++;
+				}
+			}
+		}
+		free(seen);
+		c->cap = pb * 6 + 4096; /* room for the {-1,0,1}^3 ring and for growth */
+		if(c->cap > table) c->cap = table;
+	}
+	for(int i = 0; i < 2; ++i) {
+		c->part[i].index_table = (int*) malloc(sizeof(int) * table);
+		c->part[i].keys		   = (int*) calloc(c->cap * 3, sizeof(int));
+		c->part[i].count	   = 0;
+		part_reset_table(c, &c->part[i]);
+		c->grid[i] = (float*) calloc(c->cap * 256, sizeof(float));
+	}
+	c->marks		= (int*) calloc(c->cap + 1, sizeof(int));
+	c->sources		= (int*) calloc(c->cap + 1, sizeof(int));
+	c->destinations = (int*) calloc(c->cap + 1, sizeof(int));
+	c->bin_sizes	= (int*) calloc(c->cap + 1, sizeof(int));
+	for(int mi = 0; mi < c->nmodels; ++mi) {
+		orc_model* m   = &c->models[mi];
+		size_t bin_cap = m->n / ORC_BIN + c->cap; /* gmpm_simulator.cuh:174 */
+		alloc_pbuf(c, m, &m->buf[0], bin_cap);
+		alloc_pbuf(c, m, &m->buf[1], bin_cap);
+	}
+
+	orc_partition* P = &c->part[n];
+	/* activate_blocks, mgmpm_kernels.cuh:21-34 */
+	for(int mi = 0; mi < c->nmodels; ++mi) {
+		orc_model* m = &c->models[mi];
+		for(size_t i = 0; i < m->n; ++i) {
+			int k[3];
+			for(int d = 0; d < 3; ++d) k[d] = (orc_node_index(m->xyz[3 * i + d], c->dx_inv) - 2) / 4;
+			part_insert(c, P, k[0], k[1], k[2]);
+		}
+	}
+	c->pbc = P->count;
+	if((size_t) c->pbc > c->cap) return fail(c, MPM_ERR_CAPACITY, "Too much active blocks");
+	/* build_particle_cell_buckets, mgmpm_kernels.cuh:36-68 (into bins[rollid]) */
+	for(int mi = 0; mi < c->nmodels; ++mi) {
+		orc_model* m = &c->models[mi];
+		orc_pbuf* b	 = &m->buf[r];
+		for(size_t i = 0; i < m->n; ++i) {
+			int co[3];
+			for(int d = 0; d < 3; ++d) co[d] = orc_node_index(m->xyz[3 * i + d], c->dx_inv) - 2;
+			int blockno = part_query(c, P, co[0] / 4, co[1] / 4, co[2] / 4);
+			if(blockno < 0) continue;
+			int cellno = (co[0] & 3) * 16 + (co[1] & 3) * 4 + (co[2] & 3);
+			int* cnt   = b->cell_counts + (size_t) blockno * ORC_BLOCKVOL + cellno;
+			int slot   = (*cnt)++;
+			if(slot >= c->cfg.max_ppc) {
+				(*cnt)--;
+				continue;
+			}
+			b->cellbuckets[(size_t) blockno * c->ppb + (size_t) cellno * c->cfg.max_ppc + slot] = (int) i;
+		}
+		/* cell_bucket_to_block + bin offsets + array_to_buffer (gmpm_simulator.cuh:676-704) */
+		cell_bucket_to_block(c, b, c->pbc);
+		b->bucket_sizes[c->pbc] = 0;
+		m->bincount				= bin_offsets_scan(c, b, c->pbc);
+		if((size_t) m->bincount > b->bin_cap) return fail(c, MPM_ERR_CAPACITY, "bin capacity");
+		/* array_to_buffer, mgmpm_kernels.cuh:221-323 */
+		for(int blk = 0; blk < c->pbc; ++blk) {
+			const int cnt	  = b->bucket_sizes[blk];
+			const int* bucket = b->blockbuckets + (size_t) blk * c->ppb;
+			for(int pidib = 0; pidib < cnt; ++pidib) {
+				const int pid = bucket[pidib];
+				float* bin	  = bin_ptr(m, b, b->bin_offsets[blk] + pidib / ORC_BIN);
+				const int s	  = pidib % ORC_BIN;
+				bin[0 * ORC_BIN + s] = m->xyz[3 * pid + 0];
+				bin[1 * ORC_BIN + s] = m->xyz[3 * pid + 1];
+				bin[2 * ORC_BIN + s] = m->xyz[3 * pid + 2];
+				if(m->material == MPM_J_FLUID) {
+					bin[3 * ORC_BIN + s] = 1.0f;
+				} else {
+					for(int d = 0; d < 9; ++d) bin[(3 + d) * ORC_BIN + s] = (d % 4 == 0) ? 1.f : 0.f;
+					if(m->nch == 13) bin[12 * ORC_BIN + s] = m->p.log_jp0;
+				}
+			}
+		}
+	}
+	/* register neighbors / exterior (gmpm_simulator.cuh:706-734) */
+	register_neighbor_blocks(c, P, c->pbc);
+	c->nbc = P->count;
+	if((size_t) c->nbc > c->cap) return fail(c, MPM_ERR_CAPACITY, "Too much neighbour blocks");
+	register_exterior_blocks(c, P, c->pbc);
+	c->ebc = P->count;
+	if((size_t) c->ebc > c->cap) return fail(c, MPM_ERR_CAPACITY, "Too much exterior blocks");
+	/* copy partition + bucket metadata to the other roll (gmpm_simulator.cuh:745-759) */
+	memcpy(c->part[r].index_table, P->index_table, sizeof(int) * table);
+	memcpy(c->part[r].keys, P->keys, sizeof(int) * 3 * (size_t) c->ebc);
+	c->part[r].count = P->count;
+	for(int mi = 0; mi < c->nmodels; ++mi) {
+		orc_model* m = &c->models[mi];
+		memcpy(m->buf[n].bin_offsets, m->buf[r].bin_offsets, sizeof(int) * ((size_t) c->pbc + 1));
+		memcpy(m->buf[n].bucket_sizes, m->buf[r].bucket_sizes, sizeof(int) * (size_t) c->pbc);
+	}
+	/* rasterize, mgmpm_kernels.cuh:153-219, and init_adv_bucket :96-104 */
+	clear_grid(c->grid[0], c->nbc);
+	for(int mi = 0; mi < c->nmodels; ++mi) {
+		orc_model* m = &c->models[mi];
+		for(size_t i = 0; i < m->n; ++i) {
+			const float* pos = m->xyz + 3 * i;
+			int base[3];
+			float local[3], dws[3][3];
+			for(int d = 0; d < 3; ++d) {
+				base[d]	 = orc_node_index(pos[d], c->dx_inv) - 1;
+				local[d] = pos[d] - base[d] * c->dx;
+				orc_bspline_weight(local[d], c->dx_inv, dws[d]);
+			}
+			for(int ii = 0; ii < 3; ++ii)
+				for(int jj = 0; jj < 3; ++jj)
+					for(int kk = 0; kk < 3; ++kk) {
+						const int gx = base[0] + ii, gy = base[1] + jj, gz = base[2] + kk;
+						const float w  = dws[0][ii] * dws[1][jj] * dws[2][kk];
+						const float wm = m->mass * w;
+						const int bno  = part_query(c, &c->part[r], gx >> 2, gy >> 2, gz >> 2);
+						if(bno < 0) continue;
+						float* g		= grid_block(c->grid[0], bno);
+						const int cell	= (gx & 3) * 16 + (gy & 3) * 4 + (gz & 3);
+						g[cell] += wm;
+						g[64 + cell] += wm * m->v0[0];
+						g[128 + cell] += wm * m->v0[1];
+						g[192 + cell] += wm * m->v0[2];
+					}
+		}
+		orc_pbuf* bn = &m->buf[n];
+		for(int blk = 0; blk < c->pbc; ++blk) {
+			int* bucket = bn->blockbuckets + (size_t) blk * c->ppb;
+			for(int pidib = 0; pidib < bn->bucket_sizes[blk]; ++pidib) bucket[pidib] = (orc_dir_offset(0, 0, 0) * c->ppb) | pidib;
+		}
+	}
+	c->ready = 1;
+	return MPM_OK;
+}
+
+/* ---- update_grid_velocity_query_max, Projects/GMPM/mgmpm_kernels.cuh:325-420 ---- */
+int mpmo_grid_update(mpmo_ctx* c, float dt, float* max_vel_sqr) {
+	if(!c || !c->ready) return MPM_ERR_NOT_READY;
+	double t0				= now_ms();
+	const orc_partition* P	= &c->part[c->rollid];
+	const int bc			= c->cfg.boundary_blocks;
+	float maxv				= 0.f;
+	for(int b = 0; b < c->nbc; ++b) {
+		const int* key = P->keys + 3 * b;
+		const int wx   = key[0] < bc || key[0] >= c->G - bc;
+		const int wy   = key[1] < bc || key[1] >= c->G - bc;
+		const int wz   = key[2] < bc || key[2] >= c->G - bc;
+		float* g	   = grid_block(c->grid[0], b);
+		for(int cell = 0; cell < 64; ++cell) {
+			const float mass = g[cell];
+			float vel_sqr	 = 0.f;
+			if(mass > 0.0f) {
+				const float mass_inv = 1.f / mass;
+				float v0 = g[64 + cell], v1 = g[128 + cell], v2 = g[192 + cell];
+				v0 = wx ? 0.0f : v0 * mass_inv;
+				v1 = wy ? 0.0f : v1 * mass_inv;
+				v1 += c->cfg.gravity * dt;
+				v2 = wz ? 0.0f : v2 * mass_inv;
+				g[64 + cell]  = v0;
+				g[128 + cell] = v1;
+				g[192 + cell] = v2;
+				vel_sqr += v0 * v0;
+				vel_sqr += v1 * v1;
+				vel_sqr += v2 * v2;
+			}
+			if(isnan(vel_sqr)) vel_sqr = INFINITY;
+			if(vel_sqr > maxv) maxv = vel_sqr;
+		}
+	}
+	if(max_vel_sqr) *max_vel_sqr = maxv;
+	c->timers.grid_update_ms = (float) (now_ms() - t0);
+	return MPM_OK;
+}
+
+float mpmo_compute_dt(const mpmo_ctx* c, float max_vel, float cur_time, float next_time, float dt_default) {
+	return orc_compute_dt(max_vel, cur_time, next_time, dt_default, c->dx, c->cfg.cfl);
+}
+
+/* ---- g2p2g, Projects/GMPM/mgmpm_kernels.cuh:665-937 ---- */
+static void g2p2g_model(mpmo_ctx* c, orc_model* m, float dt, float new_dt) {
+	const int r = c->rollid, n = r ^ 1;
+	const orc_partition* cur  = &c->part[r];
+	const orc_partition* prev = &c->part[n];
+	const orc_pbuf* src		  = &m->buf[r];
+	orc_pbuf* dst			  = &m->buf[n];
+	const float dx = c->dx, dx_inv = c->dx_inv, d_inv = c->d_inv;
+	static float g2p[3][8][8][8];
+	static float p2g[4][8][8][8];
+	for(int b = 0; b < c->pbc; ++b) {
+		const int* blockid = cur->keys + 3 * b;
+		const int size	   = dst->bucket_sizes[b];
+		if(size == 0) continue;
+		int nb[8];
+		for(int lb = 0; lb < 8; ++lb) {
+			nb[lb]			= part_query(c, cur, blockid[0] + ((lb & 4) ? 1 : 0), blockid[1] + ((lb & 2) ? 1 : 0), blockid[2] + ((lb & 1) ? 1 : 0));
+			const float* gb = grid_block(c->grid[0], nb[lb]);
+			for(int cx = 0; cx < 4; ++cx)
+				for(int cy = 0; cy < 4; ++cy)
+					for(int cz = 0; cz < 4; ++cz) {
+						const int cell = cx * 16 + cy * 4 + cz;
+						const int ax = cx + ((lb & 4) ? 4 : 0), ay = cy + ((lb & 2) ? 4 : 0), az = cz + ((lb & 1) ? 4 : 0);
+						g2p[0][ax][ay][az] = gb[64 + cell];
+						g2p[1][ax][ay][az] = gb[128 + cell];
+						g2p[2][ax][ay][az] = gb[192 + cell];
+					}
+		}
+		memset(p2g, 0, sizeof(p2g));
+		for(int pidib = 0; pidib < size; ++pidib) {
+			/* advection record -> source bin (:747-768) */
+			const int advect = dst->blockbuckets[(size_t) b * c->ppb + pidib];
+			int off[3];
+			orc_dir_components(advect / c->ppb, off);
+			const int source_pidib = advect & (c->ppb - 1);
+			const int src_blockno  = part_query(c, prev, blockid[0] + off[0], blockid[1] + off[1], blockid[2] + off[2]);
+			const float* sbin	   = bin_ptr(m, src, src->bin_offsets[src_blockno] + source_pidib / ORC_BIN);
+			const int ss		   = source_pidib % ORC_BIN;
+			float pos[3]		   = {sbin[ss], sbin[ORC_BIN + ss], sbin[2 * ORC_BIN + ss]};
+			float J				   = (m->material == MPM_J_FLUID) ? sbin[3 * ORC_BIN + ss] : 0.f;
+			/* stencil base, weights (:774-797) */
+			int base_index[3], arena[3];
+			float local_pos[3], dws[3][3];
+			for(int d = 0; d < 3; ++d) {
+				base_index[d] = orc_node_index(pos[d], dx_inv) - 1;
+				local_pos[d]  = pos[d] - base_index[d] * dx;
+				orc_bspline_weight(local_pos[d], dx_inv, dws[d]);
+				arena[d] = ((base_index[d] - 1) & 3) + 1;
+			}
+			/* G2P gather (:803-835) */
+			float vel[3] = {0.f, 0.f, 0.f};
+			float A[9]	 = {0};
+			for(int i = 0; i < 3; i++)
+				for(int j = 0; j < 3; j++)
+					for(int k = 0; k < 3; k++) {
+						const float xixp[3] = {(float) i * dx - local_pos[0], (float) j * dx - local_pos[1], (float) k * dx - local_pos[2]};
+						const float W		= dws[0][i] * dws[1][j] * dws[2][k];
+						const float vi[3]	= {g2p[0][arena[0] + i][arena[1] + j][arena[2] + k], g2p[1][arena[0] + i][arena[1] + j][arena[2] + k], g2p[2][arena[0] + i][arena[1] + j][arena[2] + k]};
+						vel[0] += W * vi[0];
+						vel[1] += W * vi[1];
+						vel[2] += W * vi[2];
+						A[0] += W * vi[0] * xixp[0];
+						A[1] += W * vi[1] * xixp[0];
+						A[2] += W * vi[2] * xixp[0];
+						A[3] += W * vi[0] * xixp[1];
+						A[4] += W * vi[1] * xixp[1];
+						A[5] += W * vi[2] * xixp[1];
+						A[6] += W * vi[0] * xixp[2];
+						A[7] += W * vi[1] * xixp[2];
+						A[8] += W * vi[2] * xixp[2];
+					}
+			/* advect (:838) */
+			for(int d = 0; d < 3; ++d) pos[d] += vel[d] * dt;
+			/* material update + store (calculate_contribution_and_store_particle_data, :470-663) */
+			float contrib[9];
+			float* dbin	 = bin_ptr(m, dst, dst->bin_offsets[b] + pidib / ORC_BIN);
+			const int ds = pidib % ORC_BIN;
+			if(m->material == MPM_J_FLUID) {
+				J					 = orc_jfluid(J, A, dt, d_inv, m->volume, m->p.bulk, m->p.gamma, m->p.viscosity, contrib);
+				dbin[ds]			 = pos[0];
+				dbin[ORC_BIN + ds]	 = pos[1];
+				dbin[2 * ORC_BIN + ds] = pos[2];
+				dbin[3 * ORC_BIN + ds] = J;
+			} else {
+				float dws9[9], Fold[9], F[9];
+				for(int d = 0; d < 9; ++d) dws9[d] = A[d] * dt * d_inv + ((d & 0x3) != 0 ? 0.f : 1.f);
+				for(int d = 0; d < 9; ++d) Fold[d] = sbin[(3 + d) * ORC_BIN + ss];
+				orc_matmul3(dws9, Fold, F);
+				float log_jp = 0.f;
+				if(m->material == MPM_FIXED_COROTATED) {
+					orc_stress_fixed_corotated(m->volume, m->mu, m->lambda, F, contrib);
+				} else if(m->material == MPM_SAND) {
+					log_jp = sbin[12 * ORC_BIN + ss];
+					orc_stress_sand(m->volume, m->mu, m->lambda, m->p.cohesion, m->p.beta, m->p.yield_surface, m->p.volume_correction, F, &log_jp, contrib);
+				} else {
+					log_jp = sbin[12 * ORC_BIN + ss];
+					orc_stress_nacc(m->volume, m->mu, m->lambda, m->bm, m->p.xi, m->p.beta, m->p.msqr, m->p.hardening_on, F, &log_jp, contrib);
+				}
+				dbin[ds]			   = pos[0];
+				dbin[ORC_BIN + ds]	   = pos[1];
+				dbin[2 * ORC_BIN + ds] = pos[2];
+				for(int d = 0; d < 9; ++d) dbin[(3 + d) * ORC_BIN + ds] = F[d];
+				if(m->nch == 13) dbin[12 * ORC_BIN + ds] = log_jp;
+			}
+			/* :850 */
+			for(int d = 0; d < 9; ++d) contrib[d] = (A[d] * m->mass - contrib[d] * new_dt) * d_inv;
+			/* new base, re-bucket (:852-866) */
+			int new_base[3], narena[3], dirv[3];
+			for(int d = 0; d < 3; ++d) {
+				new_base[d]	 = orc_node_index(pos[d], dx_inv) - 1;
+				local_pos[d] = pos[d] - new_base[d] * dx;
+				dirv[d]		 = (base_index[d] - 1) / 4 - (new_base[d] - 1) / 4;
+			}
+			add_advection(c, dst, cur, new_base[0] - 1, new_base[1] - 1, new_base[2] - 1, orc_dir_offset(dirv[0], dirv[1], dirv[2]), pidib);
+			for(int d = 0; d < 3; ++d) {
+				orc_bspline_weight(local_pos[d], dx_inv, dws[d]);
+				narena[d] = (((base_index[d] - 1) & 3) + 1) + (new_base[d] - base_index[d]);
+			}
+			if(narena[0] < 0 || narena[1] < 0 || narena[2] < 0 || narena[0] + 2 >= 8 || narena[1] + 2 >= 8 || narena[2] + 2 >= 8) {
+				continue; /* :877-885: particle's grid contribution is discarded */
+			}
+			/* P2G scatter (:887-905) */
+			for(int i = 0; i < 3; i++)
+				for(int j = 0; j < 3; j++)
+					for(int k = 0; k < 3; k++) {
+						const float xp[3] = {(float) i * dx - local_pos[0], (float) j * dx - local_pos[1], (float) k * dx - local_pos[2]};
+						const float W	  = dws[0][i] * dws[1][j] * dws[2][k];
+						const float wm	  = m->mass * W;
+						p2g[0][narena[0] + i][narena[1] + j][narena[2] + k] += wm;
+						p2g[1][narena[0] + i][narena[1] + j][narena[2] + k] += wm * vel[0] + (contrib[0] * xp[0] + contrib[3] * xp[1] + contrib[6] * xp[2]) * W;
+						p2g[2][narena[0] + i][narena[1] + j][narena[2] + k] += wm * vel[1] + (contrib[1] * xp[0] + contrib[4] * xp[1] + contrib[7] * xp[2]) * W;
+						p2g[3][narena[0] + i][narena[1] + j][narena[2] + k] += wm * vel[2] + (contrib[2] * xp[0] + contrib[5] * xp[1] + contrib[8] * xp[2]) * W;
+					}
+		}
+		/* arena -> next grid (:907-936) */
+		for(int lb = 0; lb < 8; ++lb) {
+			float* gb = grid_block(c->grid[1], nb[lb]);
+			for(int ch = 0; ch < 4; ++ch)
+				for(int cx = 0; cx < 4; ++cx)
+					for(int cy = 0; cy < 4; ++cy)
+						for(int cz = 0; cz < 4; ++cz) {
+							gb[ch * 64 + cx * 16 + cy * 4 + cz] += p2g[ch][cx + ((lb & 4) ? 4 : 0)][cy + ((lb & 2) ? 4 : 0)][cz + ((lb & 1) ? 4 : 0)];
+						}
+		}
+	}
+}
+
+int mpmo_g2p2g(mpmo_ctx* c, float dt, float next_dt) {
+	if(!c || !c->ready) return MPM_ERR_NOT_READY;
+	double t0	= now_ms();
+	const int n = c->rollid ^ 1;
+	clear_grid(c->grid[1], c->nbc); /* gmpm_simulator.cuh:383 */
+	for(int mi = 0; mi < c->nmodels; ++mi) {
+		orc_model* m = &c->models[mi];
+		memset(m->buf[n].cell_counts, 0, sizeof(int) * (size_t) c->ebc * ORC_BLOCKVOL); /* :389 */
+		if((size_t) m->bincount > m->buf[n].bin_cap) return fail(c, MPM_ERR_CAPACITY, "bin capacity");
+		g2p2g_model(c, m, dt, next_dt);
+	}
+	c->timers.g2p2g_ms = (float) (now_ms() - t0);
+	return MPM_OK;
+}
+
+/* ---- partition rebuild, Projects/GMPM/gmpm_simulator.cuh:415-579 ---- */
+int mpmo_rebuild_partition(mpmo_ctx* c, mpm_counts* counts) {
+	if(!c || !c->ready) return MPM_ERR_NOT_READY;
+	double t0	= now_ms();
+	const int r = c->rollid, n = r ^ 1;
+	const int ebc = c->ebc, nbc = c->nbc;
+	/* cell_bucket_to_block over exterior blocks (:421-432) */
+	for(int mi = 0; mi < c->nmodels; ++mi) {
+		orc_pbuf* b = &c->models[mi].buf[n];
+		memset(b->bucket_sizes, 0, sizeof(int) * ((size_t) ebc + 1));
+		cell_bucket_to_block(c, b, ebc);
+		b->bucket_sizes[ebc] = 0;
+	}
+	/* mark_active_grid_blocks (mgmpm_kernels.cuh:939-952) */
+	memset(c->marks, 0, sizeof(int) * (size_t) nbc);
+	for(int b = 0; b < nbc; ++b) {
+		const float* g = grid_block(c->grid[1], b);
+		for(int cell = 0; cell < 64; ++cell)
+			if(g[cell] != 0.0f) {
+				c->marks[b] = 1;
+				break;
+			}
+	}
+	/* mark_active_particle_blocks (:954-964) OR-ed over models, exclusive scan, inverse map */
+	memset(c->sources, 0, sizeof(int) * ((size_t) ebc + 1));
+	for(int mi = 0; mi < c->nmodels; ++mi) {
+		const orc_pbuf* b = &c->models[mi].buf[n];
+		for(int blk = 0; blk <= ebc; ++blk)
+			if(b->bucket_sizes[blk] > 0) c->sources[blk] = 1;
+	}
+	{
+		int acc = 0;
+		for(int blk = 0; blk <= ebc; ++blk) {
+			c->destinations[blk] = acc;
+			acc += c->sources[blk];
+		}
+	}
+	const int new_pbc = c->destinations[ebc];
+	/* exclusive_scan_inverse, Library/MnBase/Algorithm/MappingKernels.cuh:44-55 */
+	for(int blk = 0; blk < ebc; ++blk)
+		if(c->destinations[blk] != c->destinations[blk + 1]) c->sources[c->destinations[blk]] = blk;
+	if((size_t) new_pbc > c->cap) return fail(c, MPM_ERR_CAPACITY, "Too much active blocks");
+	/* update_partition (mgmpm_kernels.cuh:966-977) */
+	orc_partition* Pn		= &c->part[n];
+	const orc_partition* Pr = &c->part[r];
+	part_reset_table(c, Pn);
+	Pn->count = new_pbc;
+	for(int b = 0; b < new_pbc; ++b) {
+		const int s			= c->sources[b];
+		Pn->keys[3 * b]		= Pr->keys[3 * s];
+		Pn->keys[3 * b + 1] = Pr->keys[3 * s + 1];
+		Pn->keys[3 * b + 2] = Pr->keys[3 * s + 2];
+		Pn->index_table[key_index(c, Pn->keys[3 * b], Pn->keys[3 * b + 1], Pn->keys[3 * b + 2])] = b;
+	}
+	/* update_buckets (:979-1000) + bin offsets (:493-505) */
+	for(int mi = 0; mi < c->nmodels; ++mi) {
+		orc_model* m	   = &c->models[mi];
+		const orc_pbuf* bn = &m->buf[n];
+		orc_pbuf* br	   = &m->buf[r];
+		for(int b = 0; b < new_pbc; ++b) {
+			const int s			= c->sources[b];
+			const int cnt		= bn->bucket_sizes[s];
+			br->bucket_sizes[b] = cnt;
+			memcpy(br->blockbuckets + (size_t) b * c->ppb, bn->blockbuckets + (size_t) s * c->ppb, sizeof(int) * (size_t) cnt);
+		}
+		br->bucket_sizes[new_pbc] = 0;
+		m->bincount				  = bin_offsets_scan(c, br, new_pbc);
+		if((size_t) m->bincount > br->bin_cap) return fail(c, MPM_ERR_CAPACITY, "bin capacity");
+	}
+	/* neighbors (:513-526) */
+	register_neighbor_blocks(c, Pn, new_pbc);
+	const int new_nbc = Pn->count;
+	if((size_t) new_nbc > c->cap) return fail(c, MPM_ERR_CAPACITY, "Too much neighbour blocks");
+	/* clear grid[0], copy_selected_grid_blocks (:536-541, kernel mgmpm_kernels.cuh:1002-1020) */
+	clear_grid(c->grid[0], ebc > new_nbc ? ebc : new_nbc);
+	for(int b = 0; b < nbc; ++b) {
+		if(!c->marks[b]) continue;
+		const int bno = part_query(c, Pn, Pr->keys[3 * b], Pr->keys[3 * b + 1], Pr->keys[3 * b + 2]);
+		if(bno == -1) continue;
+		memcpy(grid_block(c->grid[0], bno), grid_block(c->grid[1], b), sizeof(float) * 256);
+	}
+	/* exterior (:560-570) */
+	register_exterior_blocks(c, Pn, new_pbc);
+	const int new_ebc = Pn->count;
+	if((size_t) new_ebc > c->cap) return fail(c, MPM_ERR_CAPACITY, "Too much exterior blocks");
+	c->pbc	  = new_pbc;
+	c->nbc	  = new_nbc;
+	c->ebc	  = new_ebc;
+	c->rollid = n; /* :578 */
+	c->timers.partition_ms = (float) (now_ms() - t0);
+	if(counts) {
+		memset(counts, 0, sizeof(*counts));
+		counts->particle_blocks = c->pbc;
+		counts->neighbor_blocks = c->nbc;
+		counts->exterior_blocks = c->ebc;
+		counts->model_count		= c->nmodels;
+		for(int mi = 0; mi < c->nmodels; ++mi) {
+			counts->bins[mi] = c->models[mi].bincount;
+			int64_t np		 = 0;
+			for(int b = 0; b < c->pbc; ++b) np += c->models[mi].buf[c->rollid ^ 1].bucket_sizes[b];
+			counts->particles[mi] = np;
+		}
+	}
+	return MPM_OK;
+}
+
+int mpmo_get_counts(mpmo_ctx* c, mpm_counts* counts) {
+	if(!c || !c->ready || !counts) return MPM_ERR_NOT_READY;
+	memset(counts, 0, sizeof(*counts));
+	counts->particle_blocks = c->pbc;
+	counts->neighbor_blocks = c->nbc;
+	counts->exterior_blocks = c->ebc;
+	counts->model_count		= c->nmodels;
+	for(int mi = 0; mi < c->nmodels; ++mi) {
+		counts->bins[mi] = c->models[mi].bincount;
+		int64_t np		 = 0;
+		for(int b = 0; b < c->pbc; ++b) np += c->models[mi].buf[c->rollid ^ 1].bucket_sizes[b];
+		counts->particles[mi] = np;
+	}
+	return MPM_OK;
+}
+
+int mpmo_substep(mpmo_ctx* c, float dt, float step_time, float frame_time, float dt_default, float* next_dt, float* max_vel) {
+	float mv2 = 0.f;
+	int rc	  = mpmo_grid_update(c, dt, &mv2);
+	if(rc) return rc;
+	if(isinf(mv2)) return fail(c, MPM_ERR_NONFINITE, "Maximum velocity is infinity");
+	const float mv = sqrtf(mv2); /* gmpm_simulator.cuh:360 */
+	const float nd = mpmo_compute_dt(c, mv, step_time, frame_time, dt_default);
+	if(max_vel) *max_vel = mv;
+	if(next_dt) *next_dt = nd;
+	rc = mpmo_g2p2g(c, dt, nd);
+	if(rc) return rc;
+	rc = mpmo_rebuild_partition(c, NULL);
+	c->timers.total_ms = c->timers.grid_update_ms + c->timers.g2p2g_ms + c->timers.partition_ms;
+	return rc;
+}
+
+int mpmo_run_fixed(mpmo_ctx* c, int nsteps, float dt) {
+	for(int s = 0; s < nsteps; ++s) {
+		float mv2 = 0.f;
+		int rc	  = mpmo_grid_update(c, dt, &mv2);
+		if(rc) return rc;
+		if(isinf(mv2)) return fail(c, MPM_ERR_NONFINITE, "Maximum velocity is infinity");
+		rc = mpmo_g2p2g(c, dt, dt);
+		if(rc) return rc;
+		rc = mpmo_rebuild_partition(c, NULL);
+		if(rc) return rc;
+	}
+	return MPM_OK;
+}
+
+/* retrieve_particle_buffer, mgmpm_kernels.cuh:1087-1122 (+ state for the parity tests) */
+int mpmo_retrieve_state(mpmo_ctx* c, int model, float* xyz, float* state9, float* logjp, size_t* n) {
+	if(!c || !c->ready || model < 0 || model >= c->nmodels || !n) return MPM_ERR_INVALID;
+	const int r = c->rollid, nn = r ^ 1;
+	orc_model* m		= &c->models[model];
+	const orc_pbuf* cur = &m->buf[r];
+	const orc_pbuf* nxt = &m->buf[nn];
+	size_t count		= 0;
+	for(int b = 0; b < c->pbc; ++b) {
+		const int* key = c->part[r].keys + 3 * b;
+		for(int pidib = 0; pidib < nxt->bucket_sizes[b]; ++pidib) {
+			const int advect = nxt->blockbuckets[(size_t) b * c->ppb + pidib];
+			int off[3];
+			orc_dir_components(advect / c->ppb, off);
+			const int sp   = advect % c->ppb;
+			const int sblk = part_query(c, &c->part[nn], key[0] + off[0], key[1] + off[1], key[2] + off[2]);
+			const float* bin = bin_ptr(m, cur, cur->bin_offsets[sblk] + sp / ORC_BIN);
+			const int s		 = sp % ORC_BIN;
+			if(count >= *n) return fail(c, MPM_ERR_CAPACITY, "output array too small");
+			if(xyz) {
+				xyz[3 * count]	   = bin[s];
+				xyz[3 * count + 1] = bin[ORC_BIN + s];
+				xyz[3 * count + 2] = bin[2 * ORC_BIN + s];
+			}
+			if(state9) {
+				if(m->material == MPM_J_FLUID) {
+					state9[9 * count] = bin[3 * ORC_BIN + s];
+					for(int d = 1; d < 9; ++d) state9[9 * count + d] = 0.f;
+				} else {
+					for(int d = 0; d < 9; ++d) state9[9 * count + d] = bin[(3 + d) * ORC_BIN + s];
+				}
+			}
+			if(logjp) logjp[count] = (m->nch == 13) ? bin[12 * ORC_BIN + s] : 0.f;
+			count++;
+		}
+	}
+	*n = count;
+	return MPM_OK;
+}
+
+int mpmo_retrieve_positions(mpmo_ctx* c, int model, float* xyz, size_t* n) {
+	return mpmo_retrieve_state(c, model, xyz, NULL, NULL, n);
+}
+
+int mpmo_get_timers(mpmo_ctx* c, mpm_timers* t) {
+	if(!c || !t) return MPM_ERR_INVALID;
+	*t = c->timers;
+	return MPM_OK;
+}
+
+int mpmo_grid_totals(mpmo_ctx* c, double out[4]) {
+	if(!c || !c->ready) return MPM_ERR_NOT_READY;
+	for(int ch = 0; ch < 4; ++ch) out[ch] = 0.0;
+	for(int b = 0; b < c->nbc; ++b) {
+		const float* g = grid_block(c->grid[0], b);
+		for(int ch = 0; ch < 4; ++ch)
+			for(int cell = 0; cell < 64; ++cell) out[ch] += g[ch * 64 + cell];
+	}
+	return MPM_OK;
+}
+
+int mpmo_dump_grid(mpmo_ctx* c, int* keys, float* blocks, size_t* nblocks) {
+	if(!c || !c->ready || !nblocks) return MPM_ERR_NOT_READY;
+	if(*nblocks < (size_t) c->nbc) return fail(c, MPM_ERR_CAPACITY, "grid dump too small");
+	if(keys) memcpy(keys, c->part[c->rollid].keys, sizeof(int) * 3 * (size_t) c->nbc);
+	if(blocks) memcpy(blocks, c->grid[0], sizeof(float) * 256 * (size_t) c->nbc);
+	*nblocks = c->nbc;
+	return MPM_OK;
+}
+
+/* table consistency: the reference's check_table debug kernel, mgmpm_kernels.cuh:1022-1032 */
+int mpmo_check_table(mpmo_ctx* c) {
+	if(!c || !c->ready) return -1;
+	const orc_partition* P = &c->part[c->rollid];
+	int bad				   = 0;
+	for(int b = 0; b < c->ebc; ++b)
+		if(part_query(c, P, P->keys[3 * b], P->keys[3 * b + 1], P->keys[3 * b + 2]) != b) bad++;
+	return bad;
+}
+
+/* ---- function-level entry points for the golden-vector tests ---- */
+void mpmo_fn_bspline(const float* p, size_t n, float dx_inv, float* out3) {
+	for(size_t i = 0; i < n; ++i) orc_bspline_weight(p[i], dx_inv, out3 + 3 * i);
+}
+void mpmo_fn_node_index(const float* x, size_t n, float dx_inv, int* out) {
+	for(size_t i = 0; i < n; ++i) out[i] = orc_node_index(x[i], dx_inv);
+}
+int mpmo_fn_dir_offset(int dx, int dy, int dz) {
+	return orc_dir_offset(dx, dy, dz);
+}
+void mpmo_fn_dir_components(int dir, int d[3]) {
+	orc_dir_components(dir, d);
+}
+float mpmo_fn_compute_dt(float max_vel, float cur, float next, float dt_default, float dx, float cfl) {
+	return orc_compute_dt(max_vel, cur, next, dt_default, dx, cfl);
+}
+void mpmo_fn_mat(const float* a, const float* b, const float* diag, float* out36) {
+	float e[9];
+	orc_matmul3(a, b, out36);
+	orc_mat_diag_matT(out36 + 9, a, diag, b);
+	orc_mat_matT(a, e);
+	memcpy(out36 + 18, e, sizeof(e));
+	orc_deviatoric(e, out36 + 27);
+}
+int mpmo_test_svd(const float* F, size_t n, float* out21, int device) {
+	(void) device;
+	for(size_t i = 0; i < n; ++i) orc_svd3(F + 9 * i, out21 + 21 * i, out21 + 21 * i + 9, out21 + 21 * i + 12);
+	return MPM_OK;
+}
+int mpmo_test_stress(int material, const mpm_material_params* p, const float* Fin, const float* logjp, size_t n, float* out19, int device) {
+	(void) device;
+	const float e = p->youngs_modulus, nu = p->poisson_ratio;
+	const float lambda = e * nu / ((1 + nu) * (1 - 2 * nu));
+	const float mu	   = e / (2 * (1 + nu));
+	const float bm	   = 2.f / 3.f * (e / (2 * (1 + nu))) + (e * nu / ((1 + nu) * (1 - 2 * nu)));
+	for(size_t i = 0; i < n; ++i) {
+		float F[9], PF[9];
+		memcpy(F, Fin + 9 * i, sizeof(F));
+		float lj = logjp ? logjp[i] : 0.f;
+		switch(material) {
+			case MPM_FIXED_COROTATED: orc_stress_fixed_corotated(p->volume, mu, lambda, F, PF); break;
+			case MPM_SAND: orc_stress_sand(p->volume, mu, lambda, p->cohesion, p->beta, p->yield_surface, p->volume_correction, F, &lj, PF); break;
+			case MPM_NACC: orc_stress_nacc(p->volume, mu, lambda, bm, p->xi, p->beta, p->msqr, p->hardening_on, F, &lj, PF); break;
+			default: return MPM_ERR_INVALID;
+		}
+		memcpy(out19 + 19 * i, F, sizeof(F));
+		memcpy(out19 + 19 * i + 9, PF, sizeof(PF));
+		out19[19 * i + 18] = lj;
+	}
+	return MPM_OK;
+}
+/* J-fluid inline block: in = J, A[9]; out10 = J', contrib[9] */
+void mpmo_fn_jfluid(const float* J, const float* A, size_t n, float dt, float d_inv, float volume, float bulk, float gamma, float viscosity, float* out10) {
+	for(size_t i = 0; i < n; ++i) out10[10 * i] = orc_jfluid(J[i], A + 9 * i, dt, d_inv, volume, bulk, gamma, viscosity, out10 + 10 * i + 1);
+}

@@ -1,0 +1,65 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol the header declares,
+its host-only entry points agree with the oracle, and it refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from claymore_amd import _ffi
+from oracle_ffi import oracle_api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "claymore_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(_ffi.HIP_LIB_PATH)
+    names = header_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/claymore_amd.h but not exported"
+
+
+def test_ffi_table_matches_header():
+    declared = set(header_symbols())
+    bound = {"mpm_" + n for n in list(_ffi.SIGNATURES) + list(_ffi.HIP_ONLY)}
+    assert bound == declared, (sorted(bound - declared), sorted(declared - bound))
+
+
+def test_oracle_exports_same_surface():
+    api = oracle_api()
+    for n in _ffi.SIGNATURES:
+        assert hasattr(api.raw, "mpmo_" + n)
+
+
+@pytest.mark.parametrize("bits", [7, 8, 9, 10])
+def test_defaults_agree_with_oracle(bits):
+    hip = _ffi.load_hip()
+    ora = oracle_api()
+    a, b = _ffi.Config(), _ffi.Config()
+    assert hip.default_config(bits, C.byref(a)) == 0 and ora.default_config(bits, C.byref(b)) == 0
+    assert bytes(a) == bytes(b)
+    assert (a.max_ppc, a.boundary_blocks, a.cfl) == (128, 2, 0.5) and abs(a.gravity + 9.8) < 1e-6
+    for mat in range(4):
+        p, q = _ffi.MaterialParams(), _ffi.MaterialParams()
+        assert hip.default_material(mat, bits, C.byref(p)) == 0 and ora.default_material(mat, bits, C.byref(q)) == 0
+        assert bytes(p) == bytes(q)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_cpu_fallback_without_gpu():
+    hip = _ffi.load_hip()
+    cfg = _ffi.Config()
+    hip.default_config(7, C.byref(cfg))
+    ctx = C.c_void_p()
+    assert hip.create(C.byref(cfg), 0, C.byref(ctx)) == _ffi.MPM_ERR_DEVICE
+    from claymore_amd.engine import Engine, EngineError
+    with pytest.raises(EngineError):
+        Engine(domain_bits=7)
