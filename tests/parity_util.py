@@ -75,7 +75,8 @@ def grid_compare(res):
     ko, bo = res["oracle"]["grid"]
     mh = {tuple(k): i for i, k in enumerate(kh)}
     worst = 0.0
-    scale = np.abs(bo).max(axis=(0, 2))  # per channel
+    scale = np.abs(bo).max(axis=(0, 2))  # per channel; momentum channels share one scale (a channel with no
+    scale[1:] = scale[1:].max()          # net motion holds only stress-rounding noise)
     for j, k in enumerate(ko):
         i = mh.get(tuple(k))
         if i is None:
