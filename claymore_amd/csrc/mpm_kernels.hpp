@@ -3,11 +3,16 @@
 // Design (MI355X-first, not a translation of the reference's CUDA):
 //   * wave64 everywhere: one wave == one 4x4x4 grid block (64 cells) in the grid kernels, one wave == one
 //     64-slot AoSoA particle bin in G2P2G, so every bin-stride load/store is a full 256-B row;
-//   * G2P2G workgroup = 256 threads = one particle block; the 8 neighbouring grid blocks are staged through
-//     LDS once (float4 {vx,vy,vz,-} per node -> one ds_read_b128 per stencil node), the P2G result is
-//     reduced in an LDS arena (ds_add_f32) and written back with one hardware f32 atomic per touched node;
+//   * G2P2G workgroup = ONE wave = one particle block.  The 8 neighbouring grid blocks are staged through LDS
+//     once (float4 {vx,vy,vz,-} per node -> one ds_read_b96 per stencil node).  The P2G scatter is atomic-free:
+//     gfx950 serialises ds_add_f32 (193 cycles per wave-instruction, profiles/r01_lds_microbench.txt), so the
+//     advection records of a block are counting-sorted in LDS into "k-th particle of every cell" order, the 64
+//     lanes of an iteration therefore hold 64 distinct cells, and each lane read-modify-writes its 27 float4
+//     nodes {m, px, py, pz} with plain ds_read_b128/ds_write_b128 (lanes whose particle changed cell and collide
+//     with another lane's stencil base are detected through an LDS owner table and retried).  The arena is
+//     written back with one hardware f32 atomic per touched node and channel;
 //   * block-level advection lists instead of the reference's cell buckets + compaction passes: a particle
-//     appends ONE 4-byte record {direction tag, slot} to the list of the block it lands in
+//     appends ONE 4-byte record {direction tag, cell, slot} to the list of the block it lands in
 //     (wave-aggregated atomic for the particles that stay), and next step's G2P2G consumes that list
 //     directly through a row indirection - 8 B/particle of bookkeeping traffic instead of 24 B and three
 //     kernels fewer (reference: add_advection + cell_bucket_to_block + update_buckets);
@@ -29,10 +34,12 @@
 namespace mpm {
 
 constexpr int kBin		  = 64; // particles per AoSoA bin == wavefront width
-constexpr int kG2P2GThreads = 256;
+constexpr int kG2P2GThreads = 64; // ONE wave per particle block: no cross-wave LDS hazards, no barriers that wait
 constexpr int kMaxModels  = 8;
-constexpr int kP2GStrideX = 68; // arena x stride in floats (64 + 4: spreads the 4 x-planes over LDS banks)
-constexpr int kP2GChannel = 544;// >= 7*68 + 7*8 + 7 + 1, multiple of 32
+constexpr int kArenaStrideX = 68; // arena x stride in float4 nodes (64 + 4: keeps every b128 lane group on 16 distinct 16-B slots)
+constexpr int kArenaNodes	= 544;// >= 7*68 + 7*8 + 7 + 1
+constexpr int kSortChunk	= 1024;// advection records sorted per pass (a block with more particles takes several passes)
+constexpr int kSortRounds	= 128; // max particles per cell that get an exact interleaved position (settings.h:75)
 constexpr int kStay		  = 13; // dir_offset(0,0,0), utility_funcs.hpp:25-27
 
 // status block indices (device ints, read back once per substep)
@@ -107,7 +114,12 @@ __global__ __launch_bounds__(256) void grid_update_kernel(GridCfg cfg, int nbloc
 	}
 #pragma unroll
 	for(int off = 32; off > 0; off >>= 1) vel_sqr = fmaxf(vel_sqr, __shfl_xor(vel_sqr, off));
-	if(lane == 0 && vel_sqr > 0.f) atomicMax(max_vel_bits, __float_as_uint(vel_sqr));// non-negative floats order as uints
+	// non-negative floats order as uints.  One same-address atomic per wave would serialise in L2 (90 k waves = 1 ms):
+	// the running maximum only grows, so a plain (possibly stale) read filters almost all of them out.
+	if(lane == 0 && vel_sqr > 0.f) {
+		const unsigned bits = __float_as_uint(vel_sqr);
+		if(bits > __hip_atomic_load(max_vel_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_vel_bits, bits);
+	}
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -151,237 +163,337 @@ __device__ __forceinline__ void dir_components(int dir, int& dx, int& dy, int& d
 	dx = (dir / 9) - 1;
 }
 
+// P2G payload of one particle: everything the scatter needs after the material update.
+struct P2GPayload {
+	float fd[3];	 // offset from the new stencil base node, in cells
+	float mv[3];	 // mass * velocity
+	float contrib[9];// (A m - stress new_dt) D^-1 dx   (see :850)
+};
+
+// Scatter one particle per active lane into the LDS arena (float4 {mass, px, py, pz} per node) WITHOUT atomics:
+// gfx950 executes ds_add_f32 at one lane per ~3 cycles (193 cycles per wave-instruction, tools/lds_microbench),
+// a plain ds_read_b128 / 4 v_add / ds_write_b128 costs 17.  Correctness rests on two facts: (1) the caller only
+// activates lanes with pairwise distinct stencil bases, so for one stencil offset all lanes touch distinct nodes;
+// (2) a workgroup is a single wave, whose LDS operations execute in program order - the compiler barrier keeps the
+// read-modify-write of offset o ahead of the read of offset o+1, which may hit the node another lane just wrote.
+__device__ __forceinline__ void p2g_scatter_rmw(float4* __restrict__ node0, const P2GPayload& pl, float mass) {
+	float w[3][3];
+#pragma unroll
+	for(int d = 0; d < 3; ++d) bspline_weight_cells(pl.fd[d], w[d]);
+#pragma unroll
+	for(int i = 0; i < 3; ++i) {
+		const float px = (float) i - pl.fd[0];
+#pragma unroll
+		for(int j = 0; j < 3; ++j) {
+			const float py	= (float) j - pl.fd[1];
+			const float wij = w[0][i] * w[1][j];
+			const float b0	= pl.mv[0] + pl.contrib[0] * px + pl.contrib[3] * py;
+			const float b1	= pl.mv[1] + pl.contrib[1] * px + pl.contrib[4] * py;
+			const float b2	= pl.mv[2] + pl.contrib[2] * px + pl.contrib[5] * py;
+#pragma unroll
+			for(int k = 0; k < 3; ++k) {
+				const float pz = (float) k - pl.fd[2];
+				const float W  = wij * w[2][k];
+				float4* node   = node0 + i * kArenaStrideX + j * 8 + k;
+				float4 acc	   = *node;
+				acc.x += mass * W;
+				acc.y += (b0 + pl.contrib[6] * pz) * W;
+				acc.z += (b1 + pl.contrib[7] * pz) * W;
+				acc.w += (b2 + pl.contrib[8] * pz) * W;
+				*node = acc;
+				__asm__ volatile("" ::: "memory");
+			}
+		}
+	}
+}
+
+// Resolve intra-wave conflicts for one batch of payloads: lanes whose stencil base (key) is unique in the wave
+// scatter immediately; the others retry.  key < 216 (6^3 possible new cells around a block).
+__device__ __forceinline__ void p2g_resolve(float4* __restrict__ arena, int* __restrict__ owner, bool pending, int key, int nodeoff, const P2GPayload& pl, float mass, int lane) {
+	while(__any(pending)) {
+		if(pending) owner[key] = lane;
+		__syncthreads();// single-wave workgroup: orders the LDS write before the read-back (and fences the compiler)
+		const bool win = pending && owner[key] == lane;
+		__syncthreads();
+		if(win) p2g_scatter_rmw(arena + nodeoff, pl, mass);
+		pending = pending && !win;
+	}
+}
+
 template<int MAT>
-__global__ __launch_bounds__(kG2P2GThreads) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_table, const int* __restrict__ cur_keys, const int* __restrict__ prev_table, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, float dt, float new_dt, int* __restrict__ status) {
+__global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_table, const int* __restrict__ cur_keys, const int* __restrict__ prev_table, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, float dt, float new_dt, int* __restrict__ status) {
 	constexpr int NCH = MatTraits<MAT>::nch;
-	__shared__ float4 g2p[512];				   // node velocities of the 8x8x8 arena, {vx,vy,vz,-}
-	__shared__ float p2g[4 * kP2GChannel];	   // mass + momentum accumulators, SoA, padded strides
+	__shared__ float4 g2p[kArenaNodes];// node velocities of the 8x8x8 arena, {vx,vy,vz,-}, x stride 68 (bank spread)
+	__shared__ float4 p2g[kArenaNodes];// {mass, momentum} accumulators
+	__shared__ int s_sorted[kSortChunk];// advection records of the current chunk, interleaved by cell
+	__shared__ unsigned long long s_mask[kSortRounds];
+	__shared__ int s_round0[kSortRounds + 1];
+	__shared__ int s_cnt[64];
+	__shared__ int s_owner[216];
 	__shared__ int s_src_binoff[27], s_dst_no[27], s_nb[8];
 
-	const int tid  = threadIdx.x;
-	const int lane = tid & 63;
+	const int lane = threadIdx.x;
 	const int b	   = block_list ? block_list[blockIdx.x] : (int) blockIdx.x;
 	const int size = mv.size[b];
 	if(size == 0) return;// (:692-697)
 	const int kx = cur_keys[3 * b], ky = cur_keys[3 * b + 1], kz = cur_keys[3 * b + 2];
 
-	if(tid < 27) {
+	if(lane < 27) {
 		int ox, oy, oz;
-		dir_components(tid, ox, oy, oz);
-		const int srcno	  = table_query(cfg, prev_table, kx + ox, ky + oy, kz + oz);
-		s_src_binoff[tid] = srcno >= 0 ? mv.binoff_src[srcno] : -1;
-		s_dst_no[tid]	  = table_query(cfg, cur_table, kx - ox, ky - oy, kz - oz);
-	} else if(tid >= 64 && tid < 72) {
-		const int lb = tid - 64;
+		dir_components(lane, ox, oy, oz);
+		const int srcno	   = table_query(cfg, prev_table, kx + ox, ky + oy, kz + oz);
+		s_src_binoff[lane] = srcno >= 0 ? mv.binoff_src[srcno] : -1;
+		s_dst_no[lane]	   = table_query(cfg, cur_table, kx - ox, ky - oy, kz - oz);
+	} else if(lane >= 32 && lane < 40) {
+		const int lb = lane - 32;
 		s_nb[lb]	 = table_query(cfg, cur_table, kx + ((lb >> 2) & 1), ky + ((lb >> 1) & 1), kz + (lb & 1));
 	}
-	for(int i = tid; i < 4 * kP2GChannel; i += kG2P2GThreads) p2g[i] = 0.f;
+	for(int i = lane; i < kArenaNodes; i += 64) p2g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 	__syncthreads();
-	{// stage the 8 grid blocks: wave w loads blocks 2w, 2w+1; lane = cell -> 256-B rows (:699-727)
-		const int w	 = tid >> 6;
-		const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
-#pragma unroll
-		for(int h = 0; h < 2; ++h) {
-			const int lb	= 2 * w + h;
-			const int nb	= s_nb[lb];
-			const float* gb = grid + (size_t) (nb < 0 ? 0 : nb) * 256;
-			float4 v;
-			v.x = gb[64 + lane];
-			v.y = gb[128 + lane];
-			v.z = gb[192 + lane];
-			v.w = 0.f;
-			if(nb < 0) v.x = v.y = v.z = 0.f;
-			g2p[(cx + ((lb & 4) ? 4 : 0)) * 64 + (cy + ((lb & 2) ? 4 : 0)) * 8 + (cz + ((lb & 1) ? 4 : 0))] = v;
-		}
-	}
-	__syncthreads();
-
-	const int row		  = mv.row_of[b];
-	const int* list		  = mv.list_in + (size_t) row * cfg.ppb;
-	const float dx_inv	  = cfg.dx_inv;
-	const float scale	  = 4.f * cfg.dx_inv;// dx * D^-1 (settings.h:66): A is accumulated in cell units
-	const float mass	  = mv.mc.mass;
-	const int binoff_dst  = mv.binoff_dst[b];
-
-	for(int pidib = tid; pidib < size; pidib += kG2P2GThreads) {
-		// ---- advection record -> source bin (:747-768)
-		const int rec	  = list[pidib];
-		const int tag	  = rec >> cfg.pid_bits;
-		const int sp	  = rec & (cfg.ppb - 1);
-		const int sbin	  = s_src_binoff[tag] + (sp >> 6);
-		const float* src  = mv.bins_src + (size_t) sbin * (NCH * kBin) + (sp & 63);
-		float pos[3]	  = {src[0], src[kBin], src[2 * kBin]};
-		float st[10];// J, or F[9] (+ logJp)
-		if constexpr(MAT == 0) {
-			st[0] = src[3 * kBin];
-		} else {
-#pragma unroll
-			for(int d = 0; d < 9; ++d) st[d] = src[(3 + d) * kBin];
-			if constexpr(NCH == 13) st[9] = src[12 * kBin];
-		}
-		// ---- stencil base + weights (:774-797); offsets in cell units (exact: dx is a power of two)
-		int base[3], arena[3];
-		float fd[3], w[3][3];
-#pragma unroll
-		for(int d = 0; d < 3; ++d) {
-			const float p = pos[d] * dx_inv;
-			base[d]		  = (int) __builtin_roundf(p) - 1;
-			fd[d]		  = p - (float) base[d];
-			bspline_weight_cells(fd[d], w[d]);
-			arena[d] = ((base[d] - 1) & 3) + 1;
-		}
-		// ---- G2P gather (:801-835): vel = sum W v, A = sum W v (x_i - x_p)^T   [A in cell units]
-		float vel[3] = {0.f, 0.f, 0.f};
-		float A[9]	 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-		const float4* gbase = g2p + arena[0] * 64 + arena[1] * 8 + arena[2];
-#pragma unroll
-		for(int i = 0; i < 3; ++i) {
-#pragma unroll
-			for(int j = 0; j < 3; ++j) {
-				const float wij = w[0][i] * w[1][j];
-#pragma unroll
-				for(int k = 0; k < 3; ++k) {
-					const float W  = wij * w[2][k];
-					const float4 v = gbase[i * 64 + j * 8 + k];
-					const float px = (float) i - fd[0], py = (float) j - fd[1], pz = (float) k - fd[2];
-					const float wx = W * v.x, wy = W * v.y, wz = W * v.z;
-					vel[0] += wx;
-					vel[1] += wy;
-					vel[2] += wz;
-					A[0] += wx * px;
-					A[1] += wy * px;
-					A[2] += wz * px;
-					A[3] += wx * py;
-					A[4] += wy * py;
-					A[5] += wz * py;
-					A[6] += wx * pz;
-					A[7] += wy * pz;
-					A[8] += wz * pz;
-				}
-			}
-		}
-		// ---- advect (:838)
-#pragma unroll
-		for(int d = 0; d < 3; ++d) pos[d] += vel[d] * dt;
-		// ---- material update, store to the destination bin (coalesced: slot == pidib) (:470-663)
-		float contrib[9];
-		float* dst = mv.bins_dst + (size_t) (binoff_dst + (pidib >> 6)) * (NCH * kBin) + (pidib & 63);
-		dst[0]		  = pos[0];
-		dst[kBin]	  = pos[1];
-		dst[2 * kBin] = pos[2];
-		if constexpr(MAT == 0) {
-			float Aw[9];
-#pragma unroll
-			for(int d = 0; d < 9; ++d) Aw[d] = A[d] * cfg.dx;
-			const float J = stress_jfluid(mv.mc, st[0], Aw, dt, cfg.d_inv, contrib);
-			dst[3 * kBin] = J;
-		} else {
-			float dws[9], Fold[9], F[9];
-#pragma unroll
-			for(int d = 0; d < 9; ++d) {
-				dws[d]	= (A[d] * dt) * scale + ((d & 0x3) != 0 ? 0.f : 1.f);
-				Fold[d] = st[d];
-			}
-			matmul3(dws, Fold, F);
-			if constexpr(MAT == 1) {
-				stress_fixed_corotated(mv.mc, F, contrib);
-			} else if constexpr(MAT == 2) {
-				float lj = st[9];
-				stress_sand(mv.mc, F, lj, contrib);
-				dst[12 * kBin] = lj;
-			} else {
-				float lj = st[9];
-				stress_nacc(mv.mc, F, lj, contrib);
-				dst[12 * kBin] = lj;
-			}
-#pragma unroll
-			for(int d = 0; d < 9; ++d) dst[(3 + d) * kBin] = F[d];
-		}
-		// (:850) contrib = (A m - contrib new_dt) D^-1, pre-multiplied by dx so that P2G can stay in cell units
-		{
-			const float am = mass * cfg.dx * cfg.dx * cfg.d_inv;// A(cell units) * dx [-> world] * m * D^-1 * dx [xixp world]
-			const float cs = new_dt * cfg.d_inv * cfg.dx;
-#pragma unroll
-			for(int d = 0; d < 9; ++d) contrib[d] = A[d] * am - contrib[d] * cs;
-		}
-		// ---- new base, re-bucket (:852-866, add_advection particle_buffer.cuh:100-135)
-		int nbase[3], narena[3], dirv[3];
-		bool in_arena = true;
-#pragma unroll
-		for(int d = 0; d < 3; ++d) {
-			const float p = pos[d] * dx_inv;
-			nbase[d]	  = (int) __builtin_roundf(p) - 1;
-			fd[d]		  = p - (float) nbase[d];
-			bspline_weight_cells(fd[d], w[d]);
-			dirv[d]	  = ((base[d] - 1) >> 2) - ((nbase[d] - 1) >> 2);
-			narena[d] = arena[d] + (nbase[d] - base[d]);
-			in_arena &= (narena[d] >= 0) & (narena[d] + 2 < 8);
-		}
-		{
-			const bool dir_ok = ((unsigned) (dirv[0] + 1) < 3u) & ((unsigned) (dirv[1] + 1) < 3u) & ((unsigned) (dirv[2] + 1) < 3u);
-			const int ntag	  = dir_ok ? (dirv[0] + 1) * 9 + (dirv[1] + 1) * 3 + dirv[2] + 1 : kStay;
-			const int dno	  = dir_ok ? s_dst_no[ntag] : -1;
-			const bool stay	  = dir_ok && ntag == kStay;
-			int slot		  = -1;
-			// wave-aggregated append for the particles that stay in this block (one atomic per wave)
-			const unsigned long long m = __ballot(stay);
-			if(stay) {
-				const int leader = __ffsll((long long) m) - 1;
-				int basev		 = 0;
-				if(lane == leader) basev = atomicAdd(&mv.out_count[b], __popcll(m));
-				basev = __shfl(basev, leader);
-				slot  = basev + __popcll(m & ((1ull << lane) - 1ull));
-			} else if(dno >= 0) {
-				slot = atomicAdd(&mv.out_count[dno], 1);
-			}
-			if(dno < 0) {
-				atomicAdd(&status[ST_LOST], 1);// reference: particle silently lost (particle_buffer.cuh:105-113)
-			} else if(slot >= cfg.ppb) {
-				atomicOr(&status[ST_OVERFLOW], 2);// reference drops beyond 128 per cell (:122-130)
-			} else {
-				mv.list_out[(size_t) dno * cfg.ppb + slot] = (ntag << cfg.pid_bits) | pidib;
-			}
-		}
-		if(!in_arena) {// (:877-885) contribution discarded
-			atomicAdd(&status[ST_ARENA], 1);
-			continue;
-		}
-		// ---- P2G scatter into the LDS arena (:887-905)
-		float* pbase = p2g + narena[0] * kP2GStrideX + narena[1] * 8 + narena[2];
-		const float mv0 = mass * vel[0], mv1 = mass * vel[1], mv2 = mass * vel[2];
-#pragma unroll
-		for(int i = 0; i < 3; ++i) {
-			const float px = (float) i - fd[0];
-#pragma unroll
-			for(int j = 0; j < 3; ++j) {
-				const float py	= (float) j - fd[1];
-				const float wij = w[0][i] * w[1][j];
-				const float b0	= mv0 + contrib[0] * px + contrib[3] * py;
-				const float b1	= mv1 + contrib[1] * px + contrib[4] * py;
-				const float b2	= mv2 + contrib[2] * px + contrib[5] * py;
-#pragma unroll
-				for(int k = 0; k < 3; ++k) {
-					const float pz = (float) k - fd[2];
-					const float W  = wij * w[2][k];
-					float* node	   = pbase + i * kP2GStrideX + j * 8 + k;
-					atomicAdd(node, mass * W);
-					atomicAdd(node + kP2GChannel, (b0 + contrib[6] * pz) * W);
-					atomicAdd(node + 2 * kP2GChannel, (b1 + contrib[7] * pz) * W);
-					atomicAdd(node + 3 * kP2GChannel, (b2 + contrib[8] * pz) * W);
-				}
-			}
-		}
-	}
-	__syncthreads();
-	// ---- arena -> next grid: one hardware f32 atomic per touched node, 256-B rows (:907-936)
-	{
-		const int ch = tid >> 6;
-		const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
+	const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;// lane == cell of a 4x4x4 block
+	{// stage the 8 grid blocks: lane = cell -> 256-B rows per channel (:699-727)
+		float4 v[8];
 #pragma unroll
 		for(int lb = 0; lb < 8; ++lb) {
-			const int nb = s_nb[lb];
-			const float val = p2g[ch * kP2GChannel + (cx + ((lb & 4) ? 4 : 0)) * kP2GStrideX + (cy + ((lb & 2) ? 4 : 0)) * 8 + (cz + ((lb & 1) ? 4 : 0))];
-			if(nb >= 0 && val != 0.f) unsafeAtomicAdd(next_grid + (size_t) nb * 256 + ch * 64 + lane, val);
+			const int nb	= s_nb[lb];
+			const float* gb = grid + (size_t) (nb < 0 ? 0 : nb) * 256;
+			v[lb].x			= gb[64 + lane];
+			v[lb].y			= gb[128 + lane];
+			v[lb].z			= gb[192 + lane];
+			v[lb].w			= 0.f;
+			if(nb < 0) v[lb].x = v[lb].y = v[lb].z = 0.f;
+		}
+#pragma unroll
+		for(int lb = 0; lb < 8; ++lb) g2p[(cx + ((lb & 4) ? 4 : 0)) * kArenaStrideX + (cy + ((lb & 2) ? 4 : 0)) * 8 + (cz + ((lb & 1) ? 4 : 0))] = v[lb];
+	}
+
+	const int row		 = mv.row_of[b];
+	const int* list		 = mv.list_in + (size_t) row * cfg.ppb;
+	const float dx_inv	 = cfg.dx_inv;
+	const float scale	 = 4.f * cfg.dx_inv;// dx * D^-1 (settings.h:66): A is accumulated in cell units
+	const float mass	 = mv.mc.mass;
+	const int binoff_dst = mv.binoff_dst[b];
+	const int cell_shift = cfg.pid_bits;
+	const int tag_shift	 = cfg.pid_bits + 6;
+
+	for(int chunk0 = 0; chunk0 < size; chunk0 += kSortChunk) {
+		const int nrec = min(kSortChunk, size - chunk0);
+		// ---- counting sort of the chunk's records into "k-th particle of every cell" order, so that the 64 lanes
+		//      of one iteration hold particles of 64 distinct cells (replaces cell_bucket_to_block, :70-84)
+		s_cnt[lane] = 0;
+		__syncthreads();
+		int packed[kSortChunk / 64];
+#pragma unroll
+		for(int it = 0; it < kSortChunk / 64; ++it) {
+			const int idx = it * 64 + lane;
+			packed[it]	  = -1;
+			if(idx < nrec) {
+				const int rec = list[chunk0 + idx];
+				const int c	  = (rec >> cell_shift) & 63;
+				const int k	  = atomicAdd(&s_cnt[c], 1);// ds_add_rtn_u32: integer LDS atomics run at full rate
+				packed[it]	  = (rec & 0xFFFFFF) | (min(k, kSortRounds) << 24);
+			}
+		}
+		__syncthreads();
+		{
+			const int my = s_cnt[lane];
+			int maxc	 = my;
+#pragma unroll
+			for(int off = 32; off > 0; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off));
+			maxc	= min(maxc, kSortRounds);
+			int run = 0;
+			for(int k = 0; k < maxc; ++k) {
+				const unsigned long long m = __ballot(my > k);
+				if(lane == 0) {
+					s_mask[k]	= m;
+					s_round0[k] = run;
+				}
+				run += __popcll(m);
+			}
+			if(lane == 0) s_round0[kSortRounds] = run;// overflow records (k >= kSortRounds) go behind the sorted ones
+			s_cnt[lane] = 0;
+		}
+		__syncthreads();
+#pragma unroll
+		for(int it = 0; it < kSortChunk / 64; ++it) {
+			if(packed[it] != -1) {
+				const int rec = packed[it] & 0xFFFFFF;
+				const int k	  = (unsigned) packed[it] >> 24;
+				const int c	  = (rec >> cell_shift) & 63;
+				int pos;
+				if(k < kSortRounds) {
+					pos = s_round0[k] + __popcll(s_mask[k] & ((1ull << c) - 1ull));
+				} else {
+					pos = s_round0[kSortRounds] + atomicAdd(&s_cnt[0], 1);
+				}
+				s_sorted[pos] = rec;
+			}
+		}
+		__syncthreads();
+
+		for(int idx0 = 0; idx0 < nrec; idx0 += 64) {
+			const bool active = idx0 + lane < nrec;
+			const int pidib	  = chunk0 + idx0 + lane;// slot in the destination bins == position in the sorted order
+			P2GPayload pl;
+			int key = 0, nodeoff = 0;
+			bool in_arena = false;
+			if(active) {
+				// ---- advection record -> source bin (:747-768)
+				const int rec	 = s_sorted[idx0 + lane];
+				const int tag	 = rec >> tag_shift;
+				const int sp	 = rec & (cfg.ppb - 1);
+				const int sbin	 = s_src_binoff[tag] + (sp >> 6);
+				const float* src = mv.bins_src + (size_t) sbin * (NCH * kBin) + (sp & 63);
+				float pos[3]	 = {src[0], src[kBin], src[2 * kBin]};
+				float st[10];// J, or F[9] (+ logJp)
+				if constexpr(MAT == 0) {
+					st[0] = src[3 * kBin];
+				} else {
+#pragma unroll
+					for(int d = 0; d < 9; ++d) st[d] = src[(3 + d) * kBin];
+					if constexpr(NCH == 13) st[9] = src[12 * kBin];
+				}
+				// ---- stencil base + weights (:774-797); offsets in cell units (exact: dx is a power of two)
+				int base[3], arena[3];
+				float fd[3], w[3][3];
+#pragma unroll
+				for(int d = 0; d < 3; ++d) {
+					const float p = pos[d] * dx_inv;
+					base[d]		  = (int) __builtin_roundf(p) - 1;
+					fd[d]		  = p - (float) base[d];
+					bspline_weight_cells(fd[d], w[d]);
+					arena[d] = ((base[d] - 1) & 3) + 1;
+				}
+				// ---- G2P gather (:801-835): vel = sum W v, A = sum W v (x_i - x_p)^T   [A in cell units]
+				float vel[3] = {0.f, 0.f, 0.f};
+				float A[9]	 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+				const float4* gbase = g2p + arena[0] * kArenaStrideX + arena[1] * 8 + arena[2];
+#pragma unroll
+				for(int i = 0; i < 3; ++i) {
+#pragma unroll
+					for(int j = 0; j < 3; ++j) {
+						const float wij = w[0][i] * w[1][j];
+#pragma unroll
+						for(int k = 0; k < 3; ++k) {
+							const float W  = wij * w[2][k];
+							const float4 v = gbase[i * kArenaStrideX + j * 8 + k];
+							const float px = (float) i - fd[0], py = (float) j - fd[1], pz = (float) k - fd[2];
+							const float wx = W * v.x, wy = W * v.y, wz = W * v.z;
+							vel[0] += wx;
+							vel[1] += wy;
+							vel[2] += wz;
+							A[0] += wx * px;
+							A[1] += wy * px;
+							A[2] += wz * px;
+							A[3] += wx * py;
+							A[4] += wy * py;
+							A[5] += wz * py;
+							A[6] += wx * pz;
+							A[7] += wy * pz;
+							A[8] += wz * pz;
+						}
+					}
+				}
+				// ---- advect (:838)
+#pragma unroll
+				for(int d = 0; d < 3; ++d) pos[d] += vel[d] * dt;
+				// ---- material update, store to the destination bin (coalesced: slot == pidib) (:470-663)
+				float* dst = mv.bins_dst + (size_t) (binoff_dst + (pidib >> 6)) * (NCH * kBin) + (pidib & 63);
+				dst[0]		  = pos[0];
+				dst[kBin]	  = pos[1];
+				dst[2 * kBin] = pos[2];
+				if constexpr(MAT == 0) {
+					float Aw[9];
+#pragma unroll
+					for(int d = 0; d < 9; ++d) Aw[d] = A[d] * cfg.dx;
+					const float J = stress_jfluid(mv.mc, st[0], Aw, dt, cfg.d_inv, pl.contrib);
+					dst[3 * kBin] = J;
+				} else {
+					float dws[9], Fold[9], F[9];
+#pragma unroll
+					for(int d = 0; d < 9; ++d) {
+						dws[d]	= (A[d] * dt) * scale + ((d & 0x3) != 0 ? 0.f : 1.f);
+						Fold[d] = st[d];
+					}
+					matmul3(dws, Fold, F);
+					if constexpr(MAT == 1) {
+						stress_fixed_corotated(mv.mc, F, pl.contrib);
+					} else if constexpr(MAT == 2) {
+						float lj = st[9];
+						stress_sand(mv.mc, F, lj, pl.contrib);
+						dst[12 * kBin] = lj;
+					} else {
+						float lj = st[9];
+						stress_nacc(mv.mc, F, lj, pl.contrib);
+						dst[12 * kBin] = lj;
+					}
+#pragma unroll
+					for(int d = 0; d < 9; ++d) dst[(3 + d) * kBin] = F[d];
+				}
+				// (:850) contrib = (A m - contrib new_dt) D^-1, pre-multiplied by dx so that P2G can stay in cell units
+				{
+					const float am = mass * cfg.dx * cfg.dx * cfg.d_inv;
+					const float cs = new_dt * cfg.d_inv * cfg.dx;
+#pragma unroll
+					for(int d = 0; d < 9; ++d) pl.contrib[d] = A[d] * am - pl.contrib[d] * cs;
+				}
+				// ---- new base, re-bucket (:852-866, add_advection particle_buffer.cuh:100-135)
+				int nbase[3], narena[3], dirv[3];
+				in_arena = true;
+#pragma unroll
+				for(int d = 0; d < 3; ++d) {
+					const float p = pos[d] * dx_inv;
+					nbase[d]	  = (int) __builtin_roundf(p) - 1;
+					pl.fd[d]	  = p - (float) nbase[d];
+					pl.mv[d]	  = mass * vel[d];
+					dirv[d]		  = ((base[d] - 1) >> 2) - ((nbase[d] - 1) >> 2);
+					narena[d]	  = arena[d] + (nbase[d] - base[d]);
+					in_arena &= (narena[d] >= 0) & (narena[d] + 2 < 8);
+				}
+				key		= narena[0] * 36 + narena[1] * 6 + narena[2];
+				nodeoff = narena[0] * kArenaStrideX + narena[1] * 8 + narena[2];
+				const bool dir_ok = ((unsigned) (dirv[0] + 1) < 3u) & ((unsigned) (dirv[1] + 1) < 3u) & ((unsigned) (dirv[2] + 1) < 3u);
+				const int ntag	  = dir_ok ? (dirv[0] + 1) * 9 + (dirv[1] + 1) * 3 + dirv[2] + 1 : kStay;
+				const int dno	  = dir_ok ? s_dst_no[ntag] : -1;
+				const int ncell	  = (((nbase[0] - 1) & 3) << 4) | (((nbase[1] - 1) & 3) << 2) | ((nbase[2] - 1) & 3);
+				const bool stay	  = dir_ok && ntag == kStay;
+				int slot		  = -1;
+				// wave-aggregated append for the particles that stay in this block (one atomic per wave)
+				const unsigned long long m = __ballot(stay);
+				if(stay) {
+					const int leader = __ffsll((long long) m) - 1;
+					int basev		 = 0;
+					if(lane == leader) basev = atomicAdd(&mv.out_count[b], __popcll(m));
+					basev = __shfl(basev, leader);
+					slot  = basev + __popcll(m & ((1ull << lane) - 1ull));
+				} else if(dno >= 0) {
+					slot = atomicAdd(&mv.out_count[dno], 1);
+				}
+				if(dno < 0) {
+					atomicAdd(&status[ST_LOST], 1);// reference: particle silently lost (particle_buffer.cuh:105-113)
+				} else if(slot >= cfg.ppb) {
+					atomicOr(&status[ST_OVERFLOW], 2);// reference drops beyond 128 per cell (:122-130)
+				} else {
+					mv.list_out[(size_t) dno * cfg.ppb + slot] = (ntag << tag_shift) | (ncell << cell_shift) | pidib;
+				}
+				if(!in_arena) atomicAdd(&status[ST_ARENA], 1);// (:877-885) contribution discarded
+			}
+			// ---- P2G scatter into the LDS arena (:887-905), conflict-free read-modify-write
+			p2g_resolve(p2g, s_owner, in_arena, in_arena ? key : 0, in_arena ? nodeoff : 0, pl, mass, lane);
+		}
+		__syncthreads();
+	}
+	// ---- arena -> next grid: one hardware f32 atomic per touched node, 256-B rows (:907-936)
+#pragma unroll
+	for(int lb = 0; lb < 8; ++lb) {
+		const int nb   = s_nb[lb];
+		const float4 v = p2g[(cx + ((lb & 4) ? 4 : 0)) * kArenaStrideX + (cy + ((lb & 2) ? 4 : 0)) * 8 + (cz + ((lb & 1) ? 4 : 0))];
+		if(nb >= 0) {
+			float* g = next_grid + (size_t) nb * 256 + lane;
+			if(v.x != 0.f) unsafeAtomicAdd(g, v.x);
+			if(v.y != 0.f) unsafeAtomicAdd(g + 64, v.y);
+			if(v.z != 0.f) unsafeAtomicAdd(g + 128, v.z);
+			if(v.w != 0.f) unsafeAtomicAdd(g + 192, v.w);
 		}
 	}
 }
@@ -523,7 +635,9 @@ __global__ __launch_bounds__(256) void fill_bins_kernel(GridCfg cfg, int nch, fl
 			for(int d = 0; d < 9; ++d) dst[(3 + d) * kBin] = (d % 4 == 0) ? 1.f : 0.f;
 			if(nch == 13) dst[12 * kBin] = log_jp0;
 		}
-		list_in[(size_t) b * cfg.ppb + pidib] = (kStay << cfg.pid_bits) | pidib;
+		const int cx = node_index(xyz[3 * (size_t) pid], cfg.dx_inv) - 2, cy = node_index(xyz[3 * (size_t) pid + 1], cfg.dx_inv) - 2, cz = node_index(xyz[3 * (size_t) pid + 2], cfg.dx_inv) - 2;
+		const int cell = ((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3);
+		list_in[(size_t) b * cfg.ppb + pidib] = (kStay << (cfg.pid_bits + 6)) | (cell << cfg.pid_bits) | pidib;
 	}
 }
 // rasterize, mgmpm_kernels.cuh:153-219 (one-time, global atomics)
@@ -564,7 +678,7 @@ __global__ __launch_bounds__(256) void retrieve_kernel(GridCfg cfg, int nch, con
 	for(int pidib = threadIdx.x; pidib < n; pidib += blockDim.x) {
 		const int rec = list[pidib];
 		int ox, oy, oz;
-		dir_components(rec >> cfg.pid_bits, ox, oy, oz);
+		dir_components(rec >> (cfg.pid_bits + 6), ox, oy, oz);
 		const int sp	 = rec & (cfg.ppb - 1);
 		const int srcno	 = table_query(cfg, prev_table, kx + ox, ky + oy, kz + oz);
 		const float* src = bins_src + (size_t) (binoff_src[srcno] + (sp >> 6)) * (nch * kBin) + (sp & 63);
