@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -63,6 +64,7 @@ struct mpm_ctx {
 	double* d_totals	  = nullptr;
 	unsigned long long* d_counter = nullptr;
 	bool ready = false;
+	int ablate = 0;// MPM_G2P2G_ABLATE (profiling only)
 	mpm_timers timers {};
 	float last_g2p2g_ms = 0.f;
 	// halo state (MGSP)
@@ -185,6 +187,7 @@ int mpm_create(const mpm_config* cfg, int device, mpm_ctx** out) {
 	mpm_ctx* ctx = new mpm_ctx();
 	ctx->cfg	 = *cfg;
 	ctx->device	 = device;
+	if(const char* e = getenv("MPM_G2P2G_ABLATE")) ctx->ablate = atoi(e);
 	GridCfg& g	 = ctx->g;
 	g.gbits		 = cfg->domain_bits - 2;
 	g.G			 = 1 << g.gbits;
@@ -448,7 +451,21 @@ static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, in
 	switch(m.material) {
 		case MPM_J_FLUID: g2p2g_kernel<0><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_table, cur_keys, prev_table, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
 		case MPM_FIXED_COROTATED: g2p2g_kernel<1><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_table, cur_keys, prev_table, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
-		case MPM_SAND: g2p2g_kernel<2><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_table, cur_keys, prev_table, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
+		case MPM_SAND:
+			switch(ctx->ablate) {// profiling builds only (MPM_G2P2G_ABLATE), see mpm_kernels.hpp
+#define MPM_ABL(n) \
+	case n: g2p2g_kernel<2, n><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_table, cur_keys, prev_table, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
+				MPM_ABL(1)
+				MPM_ABL(2)
+				MPM_ABL(4)
+				MPM_ABL(8)
+				MPM_ABL(3)
+				MPM_ABL(7)
+				MPM_ABL(15)
+#undef MPM_ABL
+				default: g2p2g_kernel<2><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_table, cur_keys, prev_table, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
+			}
+			break;
 		default: g2p2g_kernel<3><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_table, cur_keys, prev_table, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
 	}
 }

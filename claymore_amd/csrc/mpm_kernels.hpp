@@ -39,7 +39,9 @@ constexpr int kMaxModels  = 8;
 constexpr int kArenaStrideX = 68; // arena x stride in float4 nodes (64 + 4: keeps every b128 lane group on 16 distinct 16-B slots)
 constexpr int kArenaNodes	= 544;// >= 7*68 + 7*8 + 7 + 1
 constexpr int kSortChunk	= 1024;// advection records sorted per pass (a block with more particles takes several passes)
-constexpr int kSortRounds	= 128; // max particles per cell that get an exact interleaved position (settings.h:75)
+constexpr int kSortRounds	= 32;  // particles per cell (per chunk) that get an exact interleaved position; more -> appended behind
+constexpr int kG2PStrideX	= 52;  // G2P arena holds only nodes 1..6 of the 8^3 arena (the gather never touches 0 and 7):
+constexpr int kG2PNodes		= 312; // index (x-1)*52 + (y-1)*8 + (z-1); 52 = 48 + 4 keeps ds_read_b96 lane groups conflict-free
 constexpr int kStay		  = 13; // dir_offset(0,0,0), utility_funcs.hpp:25-27
 
 // status block indices (device ints, read back once per substep)
@@ -220,10 +222,13 @@ __device__ __forceinline__ void p2g_resolve(float4* __restrict__ arena, int* __r
 	}
 }
 
-template<int MAT>
+// ABL: ablation mask for profiling builds (0 in production): 1 skip the P2G scatter, 2 skip the stress (SVD),
+// 4 skip the G2P gather, 8 skip the interleave sort, 16 skip the particle stores.  Values are kept live with
+// empty asm statements so that the compiler cannot delete upstream work.
+template<int MAT, int ABL = 0>
 __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_table, const int* __restrict__ cur_keys, const int* __restrict__ prev_table, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, float dt, float new_dt, int* __restrict__ status) {
 	constexpr int NCH = MatTraits<MAT>::nch;
-	__shared__ float4 g2p[kArenaNodes];// node velocities of the 8x8x8 arena, {vx,vy,vz,-}, x stride 68 (bank spread)
+	__shared__ float4 g2p[kG2PNodes];// node velocities {vx,vy,vz,-} of arena nodes 1..6 per axis
 	__shared__ float4 p2g[kArenaNodes];// {mass, momentum} accumulators
 	__shared__ int s_sorted[kSortChunk];// advection records of the current chunk, interleaved by cell
 	__shared__ unsigned long long s_mask[kSortRounds];
@@ -264,7 +269,10 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 			if(nb < 0) v[lb].x = v[lb].y = v[lb].z = 0.f;
 		}
 #pragma unroll
-		for(int lb = 0; lb < 8; ++lb) g2p[(cx + ((lb & 4) ? 4 : 0)) * kArenaStrideX + (cy + ((lb & 2) ? 4 : 0)) * 8 + (cz + ((lb & 1) ? 4 : 0))] = v[lb];
+		for(int lb = 0; lb < 8; ++lb) {
+			const int ax = cx + ((lb & 4) ? 4 : 0) - 1, ay = cy + ((lb & 2) ? 4 : 0) - 1, az = cz + ((lb & 1) ? 4 : 0) - 1;
+			if(((unsigned) ax < 6u) & ((unsigned) ay < 6u) & ((unsigned) az < 6u)) g2p[ax * kG2PStrideX + ay * 8 + az] = v[lb];
+		}
 	}
 
 	const int row		 = mv.row_of[b];
@@ -280,6 +288,10 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 		const int nrec = min(kSortChunk, size - chunk0);
 		// ---- counting sort of the chunk's records into "k-th particle of every cell" order, so that the 64 lanes
 		//      of one iteration hold particles of 64 distinct cells (replaces cell_bucket_to_block, :70-84)
+		if constexpr(ABL & 8) {
+			for(int idx = lane; idx < nrec; idx += 64) s_sorted[idx] = list[chunk0 + idx];
+			__syncthreads();
+		} else {
 		s_cnt[lane] = 0;
 		__syncthreads();
 		int packed[kSortChunk / 64];
@@ -330,6 +342,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 			}
 		}
 		__syncthreads();
+		}
 
 		for(int idx0 = 0; idx0 < nrec; idx0 += 64) {
 			const bool active = idx0 + lane < nrec;
@@ -367,7 +380,12 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 				// ---- G2P gather (:801-835): vel = sum W v, A = sum W v (x_i - x_p)^T   [A in cell units]
 				float vel[3] = {0.f, 0.f, 0.f};
 				float A[9]	 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-				const float4* gbase = g2p + arena[0] * kArenaStrideX + arena[1] * 8 + arena[2];
+				const float4* gbase = g2p + (arena[0] - 1) * kG2PStrideX + (arena[1] - 1) * 8 + (arena[2] - 1);
+				if constexpr(ABL & 4) {
+					const float4 v = gbase[0];
+					vel[0] = v.x * w[0][0]; vel[1] = v.y * w[1][1]; vel[2] = v.z * w[2][2];
+					A[0] = v.x * fd[0]; A[4] = v.y * fd[1]; A[8] = v.z * fd[2];
+				} else
 #pragma unroll
 				for(int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -376,7 +394,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 #pragma unroll
 						for(int k = 0; k < 3; ++k) {
 							const float W  = wij * w[2][k];
-							const float4 v = gbase[i * kArenaStrideX + j * 8 + k];
+							const float4 v = gbase[i * kG2PStrideX + j * 8 + k];
 							const float px = (float) i - fd[0], py = (float) j - fd[1], pz = (float) k - fd[2];
 							const float wx = W * v.x, wy = W * v.y, wz = W * v.z;
 							vel[0] += wx;
@@ -416,7 +434,11 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 						Fold[d] = st[d];
 					}
 					matmul3(dws, Fold, F);
-					if constexpr(MAT == 1) {
+					if constexpr(ABL & 2) {
+#pragma unroll
+						for(int d = 0; d < 9; ++d) pl.contrib[d] = F[d] * mv.mc.mu;
+						if constexpr(NCH == 13) dst[12 * kBin] = st[9];
+					} else if constexpr(MAT == 1) {
 						stress_fixed_corotated(mv.mc, F, pl.contrib);
 					} else if constexpr(MAT == 2) {
 						float lj = st[9];
@@ -479,7 +501,14 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 				if(!in_arena) atomicAdd(&status[ST_ARENA], 1);// (:877-885) contribution discarded
 			}
 			// ---- P2G scatter into the LDS arena (:887-905), conflict-free read-modify-write
-			p2g_resolve(p2g, s_owner, in_arena, in_arena ? key : 0, in_arena ? nodeoff : 0, pl, mass, lane);
+			if constexpr(ABL & 1) {
+#pragma unroll
+				for(int d = 0; d < 9; ++d) __asm__ volatile("" ::"v"(pl.contrib[d]));
+#pragma unroll
+				for(int d = 0; d < 3; ++d) __asm__ volatile("" ::"v"(pl.fd[d]), "v"(pl.mv[d]));
+				__asm__ volatile("" ::"v"(key), "v"(nodeoff));
+			} else
+				p2g_resolve(p2g, s_owner, in_arena, in_arena ? key : 0, in_arena ? nodeoff : 0, pl, mass, lane);
 		}
 		__syncthreads();
 	}

@@ -6,7 +6,7 @@ import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(os.path.join(root, "claymore_amd", "csrc"))
-r = subprocess.run("hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -Wno-unused-value "
+r = subprocess.run("hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -Wno-unused-value -fno-slp-vectorize "
                    "-Rpass-analysis=kernel-resource-usage -o libclaymore_hip.so claymore_hip.hip", shell=True, capture_output=True, text=True)
 lines = r.stderr.split("\n")
 pat = sys.argv[1] if len(sys.argv) > 1 else "g2p2g"
