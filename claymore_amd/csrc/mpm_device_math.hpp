@@ -358,33 +358,38 @@ MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, 
 #pragma unroll
 	for(int i = 0; i < 3; i++) epsilon_hat[i] = epsilon[i] - (trace_epsilon / 3.0f);
 	const float epsilon_hat_norm = sqrtf(epsilon_hat[0] * epsilon_hat[0] + epsilon_hat[1] * epsilon_hat[1] + epsilon_hat[2] * epsilon_hat[2]);
+	// log(New_S) is needed below; New_S = exp(H), so H itself is used instead of logf(expf(H)) (the reference's
+	// round trip, constitutive_models.cuh:311, differs from H by one rounding of expf: ~6e-8 absolute)
+	float lnS[3];
 	bool rebuild = false;
 	if(trace_epsilon >= 0.0f) {// case II: cone tip
 		New_S[0] = New_S[1] = New_S[2] = expf(mc.cohesion);
-		rebuild						   = true;
+		lnS[0] = lnS[1] = lnS[2] = mc.cohesion;
+		rebuild					 = true;
 		if(mc.volume_correction) log_jp = mc.beta * sum_epsilon + log_jp;
 	} else if(mc.mu != 0.f) {
 		log_jp					= 0.f;
 		const float delta_gamma = epsilon_hat_norm + (3.0f * mc.lambda + scaled_mu) / scaled_mu * trace_epsilon * mc.yield_surface;
-		float H[3];
 		if(delta_gamma <= 0.f) {// case I: inside the cone
 #pragma unroll
-			for(int i = 0; i < 3; i++) H[i] = epsilon[i] + mc.cohesion;
+			for(int i = 0; i < 3; i++) lnS[i] = epsilon[i] + mc.cohesion;
 		} else {// case III: project to the cone surface
+			const float r = delta_gamma / epsilon_hat_norm;
 #pragma unroll
-			for(int i = 0; i < 3; i++) H[i] = epsilon[i] - (delta_gamma / epsilon_hat_norm) * epsilon_hat[i] + mc.cohesion;
+			for(int i = 0; i < 3; i++) lnS[i] = epsilon[i] - r * epsilon_hat[i] + mc.cohesion;
 		}
 #pragma unroll
-		for(int i = 0; i < 3; i++) New_S[i] = expf(H[i]);
+		for(int i = 0; i < 3; i++) New_S[i] = expf(lnS[i]);
 		rebuild = true;
+	} else {
+		lnS[0] = lnS[1] = lnS[2] = -__builtin_inff();// reference: logf(0) when mu == 0 (:298-300)
 	}
 	if(rebuild) mat_diag_matT(F, U, New_S, V);
-	const float ls0 = logf(New_S[0]), ls1 = logf(New_S[1]), ls2 = logf(New_S[2]);
-	const float trace_log_S = ls0 + ls1 + ls2;
+	const float trace_log_S = lnS[0] + lnS[1] + lnS[2];
 	float P_hat[3];
-	P_hat[0] = (scaled_mu * ls0 + mc.lambda * trace_log_S) / New_S[0];
-	P_hat[1] = (scaled_mu * ls1 + mc.lambda * trace_log_S) / New_S[1];
-	P_hat[2] = (scaled_mu * ls2 + mc.lambda * trace_log_S) / New_S[2];
+	P_hat[0] = (scaled_mu * lnS[0] + mc.lambda * trace_log_S) / New_S[0];
+	P_hat[1] = (scaled_mu * lnS[1] + mc.lambda * trace_log_S) / New_S[1];
+	P_hat[2] = (scaled_mu * lnS[2] + mc.lambda * trace_log_S) / New_S[2];
 	float P[9];
 	mat_diag_matT(P, U, P_hat, V);
 	P_Ft_vol(P, F, mc.volume, PF);

@@ -344,28 +344,43 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 		__syncthreads();
 		}
 
+		// particle data of the NEXT iteration is requested before the current one is computed (software prefetch:
+		// the gather loads have ~2 us of HBM latency and only two waves share a SIMD)
+		float nx_pos[3], nx_st[10];
+		int nx_tag = 0;
+		auto fetch = [&](int idx0) {
+			if(idx0 + lane < nrec) {
+				const int rec	 = s_sorted[idx0 + lane];
+				nx_tag			 = rec >> tag_shift;
+				const int sp	 = rec & (cfg.ppb - 1);
+				const int sbin	 = s_src_binoff[nx_tag] + (sp >> 6);
+				const float* src = mv.bins_src + (size_t) sbin * (NCH * kBin) + (sp & 63);
+				nx_pos[0]		 = src[0];
+				nx_pos[1]		 = src[kBin];
+				nx_pos[2]		 = src[2 * kBin];
+				if constexpr(MAT == 0) {
+					nx_st[0] = src[3 * kBin];
+				} else {
+#pragma unroll
+					for(int d = 0; d < 9; ++d) nx_st[d] = src[(3 + d) * kBin];
+					if constexpr(NCH == 13) nx_st[9] = src[12 * kBin];
+				}
+			}
+		};
+		fetch(0);
 		for(int idx0 = 0; idx0 < nrec; idx0 += 64) {
 			const bool active = idx0 + lane < nrec;
 			const int pidib	  = chunk0 + idx0 + lane;// slot in the destination bins == position in the sorted order
 			P2GPayload pl;
 			int key = 0, nodeoff = 0;
 			bool in_arena = false;
-			if(active) {
-				// ---- advection record -> source bin (:747-768)
-				const int rec	 = s_sorted[idx0 + lane];
-				const int tag	 = rec >> tag_shift;
-				const int sp	 = rec & (cfg.ppb - 1);
-				const int sbin	 = s_src_binoff[tag] + (sp >> 6);
-				const float* src = mv.bins_src + (size_t) sbin * (NCH * kBin) + (sp & 63);
-				float pos[3]	 = {src[0], src[kBin], src[2 * kBin]};
-				float st[10];// J, or F[9] (+ logJp)
-				if constexpr(MAT == 0) {
-					st[0] = src[3 * kBin];
-				} else {
+			// ---- advection record -> source bin (:747-768): data was requested one iteration ago
+			float pos[3] = {nx_pos[0], nx_pos[1], nx_pos[2]};
+			float st[10];// J, or F[9] (+ logJp)
 #pragma unroll
-					for(int d = 0; d < 9; ++d) st[d] = src[(3 + d) * kBin];
-					if constexpr(NCH == 13) st[9] = src[12 * kBin];
-				}
+			for(int d = 0; d < 10; ++d) st[d] = nx_st[d];
+			fetch(idx0 + 64);
+			if(active) {
 				// ---- stencil base + weights (:774-797); offsets in cell units (exact: dx is a power of two)
 				int base[3], arena[3];
 				float fd[3], w[3][3];
