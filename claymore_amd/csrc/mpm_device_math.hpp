@@ -52,6 +52,11 @@ MPM_DEV void P_Ft_vol(const float (&P)[9], const float (&F)[9], float volume, fl
 	}
 }
 
+// v_rcp_f32 (1 ulp).  The reference binary is built with --use_fast_math (CMake-Utils/setup_cuda.cmake:50), i.e. with
+// approximate division itself; IEEE division costs ~10 VALU instructions on gfx950 and G2P2G is VALU-bound.
+MPM_DEV float rcp_fast(float x) {
+	return __builtin_amdgcn_rcpf(x);
+}
 MPM_DEV float rsqrt_approx(float x) {
 	return __builtin_amdgcn_rsqf(x);// v_rsq_f32, ~1 ulp; the algorithm re-normalises (svd.cuh:210-215)
 }
@@ -356,8 +361,8 @@ MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, 
 	const float trace_epsilon = sum_epsilon + log_jp;
 	float epsilon_hat[3];
 #pragma unroll
-	for(int i = 0; i < 3; i++) epsilon_hat[i] = epsilon[i] - (trace_epsilon / 3.0f);
-	const float epsilon_hat_norm = sqrtf(epsilon_hat[0] * epsilon_hat[0] + epsilon_hat[1] * epsilon_hat[1] + epsilon_hat[2] * epsilon_hat[2]);
+	for(int i = 0; i < 3; i++) epsilon_hat[i] = epsilon[i] - (trace_epsilon * (1.0f / 3.0f));
+	const float epsilon_hat_norm = __builtin_amdgcn_sqrtf(epsilon_hat[0] * epsilon_hat[0] + epsilon_hat[1] * epsilon_hat[1] + epsilon_hat[2] * epsilon_hat[2]);
 	// log(New_S) is needed below; New_S = exp(H), so H itself is used instead of logf(expf(H)) (the reference's
 	// round trip, constitutive_models.cuh:311, differs from H by one rounding of expf: ~6e-8 absolute)
 	float lnS[3];
@@ -369,12 +374,12 @@ MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, 
 		if(mc.volume_correction) log_jp = mc.beta * sum_epsilon + log_jp;
 	} else if(mc.mu != 0.f) {
 		log_jp					= 0.f;
-		const float delta_gamma = epsilon_hat_norm + (3.0f * mc.lambda + scaled_mu) / scaled_mu * trace_epsilon * mc.yield_surface;
+		const float delta_gamma = epsilon_hat_norm + (3.0f * mc.lambda + scaled_mu) * rcp_fast(scaled_mu) * trace_epsilon * mc.yield_surface;
 		if(delta_gamma <= 0.f) {// case I: inside the cone
 #pragma unroll
 			for(int i = 0; i < 3; i++) lnS[i] = epsilon[i] + mc.cohesion;
 		} else {// case III: project to the cone surface
-			const float r = delta_gamma / epsilon_hat_norm;
+			const float r = delta_gamma * rcp_fast(epsilon_hat_norm);
 #pragma unroll
 			for(int i = 0; i < 3; i++) lnS[i] = epsilon[i] - r * epsilon_hat[i] + mc.cohesion;
 		}
@@ -387,9 +392,9 @@ MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, 
 	if(rebuild) mat_diag_matT(F, U, New_S, V);
 	const float trace_log_S = lnS[0] + lnS[1] + lnS[2];
 	float P_hat[3];
-	P_hat[0] = (scaled_mu * lnS[0] + mc.lambda * trace_log_S) / New_S[0];
-	P_hat[1] = (scaled_mu * lnS[1] + mc.lambda * trace_log_S) / New_S[1];
-	P_hat[2] = (scaled_mu * lnS[2] + mc.lambda * trace_log_S) / New_S[2];
+	P_hat[0] = (scaled_mu * lnS[0] + mc.lambda * trace_log_S) * rcp_fast(New_S[0]);
+	P_hat[1] = (scaled_mu * lnS[1] + mc.lambda * trace_log_S) * rcp_fast(New_S[1]);
+	P_hat[2] = (scaled_mu * lnS[2] + mc.lambda * trace_log_S) * rcp_fast(New_S[2]);
 	float P[9];
 	mat_diag_matT(P, U, P_hat, V);
 	P_Ft_vol(P, F, mc.volume, PF);

@@ -400,30 +400,45 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 					const float4 v = gbase[0];
 					vel[0] = v.x * w[0][0]; vel[1] = v.y * w[1][1]; vel[2] = v.z * w[2][2];
 					A[0] = v.x * fd[0]; A[4] = v.y * fd[1]; A[8] = v.z * fd[2];
-				} else
+				} else {
+					// tensor-product evaluation: reduce along z, then y, then x (fewer multiplies than 27 x 16; the
+					// summation order differs from the reference's node loop by rounding only)
+					float wp[3][3];// w * (node - particle) per axis
 #pragma unroll
-				for(int i = 0; i < 3; ++i) {
+					for(int d = 0; d < 3; ++d) {
 #pragma unroll
-					for(int j = 0; j < 3; ++j) {
-						const float wij = w[0][i] * w[1][j];
+						for(int t = 0; t < 3; ++t) wp[d][t] = w[d][t] * ((float) t - fd[d]);
+					}
 #pragma unroll
-						for(int k = 0; k < 3; ++k) {
-							const float W  = wij * w[2][k];
-							const float4 v = gbase[i * kG2PStrideX + j * 8 + k];
-							const float px = (float) i - fd[0], py = (float) j - fd[1], pz = (float) k - fd[2];
-							const float wx = W * v.x, wy = W * v.y, wz = W * v.z;
-							vel[0] += wx;
-							vel[1] += wy;
-							vel[2] += wz;
-							A[0] += wx * px;
-							A[1] += wy * px;
-							A[2] += wz * px;
-							A[3] += wx * py;
-							A[4] += wy * py;
-							A[5] += wz * py;
-							A[6] += wx * pz;
-							A[7] += wy * pz;
-							A[8] += wz * pz;
+					for(int i = 0; i < 3; ++i) {
+						float u0[3] = {0.f, 0.f, 0.f}, uy[3] = {0.f, 0.f, 0.f}, uz[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+						for(int j = 0; j < 3; ++j) {
+							const float4 v0 = gbase[i * kG2PStrideX + j * 8 + 0];
+							const float4 v1 = gbase[i * kG2PStrideX + j * 8 + 1];
+							const float4 v2 = gbase[i * kG2PStrideX + j * 8 + 2];
+							const float t0x = w[2][0] * v0.x + w[2][1] * v1.x + w[2][2] * v2.x;
+							const float t0y = w[2][0] * v0.y + w[2][1] * v1.y + w[2][2] * v2.y;
+							const float t0z = w[2][0] * v0.z + w[2][1] * v1.z + w[2][2] * v2.z;
+							const float t1x = wp[2][0] * v0.x + wp[2][1] * v1.x + wp[2][2] * v2.x;
+							const float t1y = wp[2][0] * v0.y + wp[2][1] * v1.y + wp[2][2] * v2.y;
+							const float t1z = wp[2][0] * v0.z + wp[2][1] * v1.z + wp[2][2] * v2.z;
+							u0[0] += w[1][j] * t0x;
+							u0[1] += w[1][j] * t0y;
+							u0[2] += w[1][j] * t0z;
+							uy[0] += wp[1][j] * t0x;
+							uy[1] += wp[1][j] * t0y;
+							uy[2] += wp[1][j] * t0z;
+							uz[0] += w[1][j] * t1x;
+							uz[1] += w[1][j] * t1y;
+							uz[2] += w[1][j] * t1z;
+						}
+#pragma unroll
+						for(int d = 0; d < 3; ++d) {
+							vel[d] += w[0][i] * u0[d];
+							A[d] += wp[0][i] * u0[d];
+							A[3 + d] += w[0][i] * uy[d];
+							A[6 + d] += w[0][i] * uz[d];
 						}
 					}
 				}
