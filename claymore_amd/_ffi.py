@@ -65,17 +65,20 @@ SIGNATURES = {
     "test_svd": (_i, [_vp, _sz, _vp, _i]),
     "test_stress": (_i, [_i, _P(MaterialParams), _vp, _vp, _sz, _vp, _i]),
 }
-# entry points only the HIP library has (multi-GPU + stream plumbing + kernel timing)
-HIP_ONLY = {
-    "last_g2p2g_ms": (_i, [_vp, _fp]),
-    "halo_keys": (_i, [_vp, _P(_vp), _ip]),
+HALO = {
+    "halo_keys": (_i, [_vp, _vp, _i, _ip]),
     "halo_tag_begin": (_i, [_vp]),
-    "halo_tag_peer": (_i, [_vp, _i, _vp, _i, _ip]),
-    "halo_tag_end": (_i, [_vp, _ip]),
+    "halo_tag_peer": (_i, [_vp, _i, _vp, _i]),
+    "halo_tag_end": (_i, [_vp, _ip, _ip]),
     "g2p2g_halo": (_i, [_vp, _f, _f]),
     "g2p2g_interior": (_i, [_vp, _f, _f]),
-    "halo_collect": (_i, [_vp, _i, _vp, _vp, _i, _ip]),
-    "halo_reduce": (_i, [_vp, _vp, _vp, _i]),
+    "halo_collect": (_i, [_vp, _i, _i, _vp, _vp, _i, _ip]),
+    "halo_reduce": (_i, [_vp, _i, _vp, _vp, _i]),
+}
+SIGNATURES.update(HALO)
+# entry points only the HIP library has (stream plumbing + kernel timing)
+HIP_ONLY = {
+    "last_g2p2g_ms": (_i, [_vp, _fp]),
     "streams": (_i, [_vp, _P(_vp), _P(_vp)]),
     "sync": (_i, [_vp]),
 }

@@ -41,6 +41,7 @@ struct Model {
 	int* row_of		 = nullptr;
 	int* out_count	 = nullptr;
 	int64_t bincount = 0;
+	int64_t bucketed = 0;// particles currently in the advection lists (device-counted at each rebuild)
 	int list_in		 = 0;// which list buffer g2p2g reads next
 };
 
@@ -51,7 +52,7 @@ struct mpm_ctx {
 	GridCfg g {};
 	int device = 0;
 	hipStream_t s_compute = nullptr, s_comm = nullptr;
-	hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_g0 = nullptr, ev_g1 = nullptr, ev_comm = nullptr;
+	hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_g0 = nullptr, ev_g1 = nullptr, ev_comm = nullptr, ev_halo = nullptr;
 	Partition part[2];
 	float* grid[2] = {nullptr, nullptr};
 	int rollid	   = 0;
@@ -72,6 +73,8 @@ struct mpm_ctx {
 	int* d_halo_list   = nullptr;// particle blocks touching an overlap block
 	int* d_inner_list  = nullptr;
 	int* d_halo_counts = nullptr;// [0]=halo blocks, [1]=interior blocks, [2+peer]=send count for peer
+	int* h_halo_counts = nullptr;// pinned mirror
+	bool halo_tagged   = false;
 	int* d_send_ids[32] = {nullptr};
 	int n_halo = 0, n_inner = 0;
 	int send_count[32] = {0};
@@ -209,6 +212,7 @@ int mpm_create(const mpm_config* cfg, int device, mpm_ctx** out) {
 	hipEventCreate(&ctx->ev_g0);
 	hipEventCreate(&ctx->ev_g1);
 	hipEventCreateWithFlags(&ctx->ev_comm, hipEventDisableTiming);
+	hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming);
 	*out = ctx;
 	return MPM_OK;
 }
@@ -250,6 +254,8 @@ void mpm_destroy(mpm_ctx* ctx) {
 	hipEventDestroy(ctx->ev_g0);
 	hipEventDestroy(ctx->ev_g1);
 	hipEventDestroy(ctx->ev_comm);
+	hipEventDestroy(ctx->ev_halo);
+	if(ctx->h_halo_counts) hipHostFree(ctx->h_halo_counts);
 	hipStreamDestroy(ctx->s_compute);
 	hipStreamDestroy(ctx->s_comm);
 	delete ctx;
@@ -380,6 +386,7 @@ int mpm_initial_setup(mpm_ctx* ctx) {
 	ctx->ebc = ctx->h_status[ST_EBC];
 	for(size_t mi = 0; mi < ctx->models.size(); ++mi) {
 		ctx->models[mi].bincount = ctx->h_status[ST_BINS0 + mi];
+		ctx->models[mi].bucketed = (int64_t) ctx->models[mi].n;
 		if((size_t) ctx->models[mi].bincount > ctx->models[mi].bin_cap) return fail(ctx, MPM_ERR_CAPACITY, "bin capacity");
 	}
 	// copy the partition to the other roll (gmpm_simulator.cuh:745-748): previous numbering == current numbering
@@ -511,7 +518,7 @@ static int launch_rebuild(mpm_ctx* ctx) {
 	const size_t table = (size_t) g.G * g.G * g.G;
 	HIP_TRY(hipMemsetAsync(Pn.table, 0xff, sizeof(int) * table, s));// reset_table, hash_table.cuh:110-112
 	HIP_TRY(hipMemsetAsync(Pn.count, 0, sizeof(int), s));
-	HIP_TRY(hipMemsetAsync(&ctx->d_status[ST_BINS0], 0, sizeof(int) * kMaxModels, s));
+	HIP_TRY(hipMemsetAsync(&ctx->d_status[ST_BINS0], 0, sizeof(int) * 2 * kMaxModels, s));// bin totals + particle totals
 	RebuildModels rm {};
 	rm.n = (int) ctx->models.size();
 	for(int mi = 0; mi < rm.n; ++mi) {
@@ -544,6 +551,7 @@ static int finish_rebuild(mpm_ctx* ctx, mpm_counts* counts) {
 	for(size_t mi = 0; mi < ctx->models.size(); ++mi) {
 		Model& m   = ctx->models[mi];
 		m.bincount = ctx->h_status[ST_BINS0 + mi];
+		m.bucketed = ctx->h_status[ST_PART0 + mi];
 		if((size_t) m.bincount > m.bin_cap) return fail(ctx, MPM_ERR_CAPACITY, "bin capacity exceeded");
 		m.list_in ^= 1;
 	}
@@ -645,14 +653,9 @@ int mpm_get_counts(mpm_ctx* ctx, mpm_counts* counts) {
 	counts->neighbor_blocks = ctx->nbc;
 	counts->exterior_blocks = ctx->ebc;
 	counts->model_count		= (int) ctx->models.size();
-	HIP_TRY(hipSetDevice(ctx->device));
-	std::vector<int> sizes((size_t) ctx->pbc + 1);
 	for(size_t mi = 0; mi < ctx->models.size(); ++mi) {
-		counts->bins[mi] = ctx->models[mi].bincount;
-		HIP_TRY(hipMemcpy(sizes.data(), ctx->models[mi].size, sizeof(int) * (size_t) ctx->pbc, hipMemcpyDeviceToHost));
-		int64_t np = 0;
-		for(int b = 0; b < ctx->pbc; ++b) np += sizes[b];
-		counts->particles[mi] = np;
+		counts->bins[mi]	  = ctx->models[mi].bincount;
+		counts->particles[mi] = ctx->models[mi].bucketed;
 	}
 	return MPM_OK;
 }

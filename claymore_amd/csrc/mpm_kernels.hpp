@@ -45,7 +45,7 @@ constexpr int kG2PNodes		= 312; // index (x-1)*52 + (y-1)*8 + (z-1); 52 = 48 + 4
 constexpr int kStay		  = 13; // dir_offset(0,0,0), utility_funcs.hpp:25-27
 
 // status block indices (device ints, read back once per substep)
-enum { ST_PBC = 0, ST_NBC = 1, ST_EBC = 2, ST_OVERFLOW = 3, ST_LOST = 4, ST_ARENA = 5, ST_BINS0 = 8, ST_WORDS = 32 };
+enum { ST_PBC = 0, ST_NBC = 1, ST_EBC = 2, ST_OVERFLOW = 3, ST_LOST = 4, ST_ARENA = 5, ST_BINS0 = 8, ST_PART0 = 16, ST_WORDS = 32 };
 
 struct GridCfg {
 	int G;		  // blocks per axis
@@ -574,12 +574,18 @@ struct RebuildModels {
 // allocated.  Order of the new numbering is arbitrary (as it is in the reference: insert order of atomics).
 __global__ __launch_bounds__(256) void compact_blocks_kernel(GridCfg cfg, int ebc, RebuildModels rm, const int* __restrict__ old_keys, int* __restrict__ new_keys, int* __restrict__ new_table, int* __restrict__ new_count, int* __restrict__ status) {
 	const int b = blockIdx.x * blockDim.x + threadIdx.x;
-	if(b >= ebc) return;
 	int c[kMaxModels];
 	bool any = false;
 	for(int m = 0; m < rm.n; ++m) {
-		c[m] = rm.out_count[m][b];
+		c[m] = b < ebc ? rm.out_count[m][b] : 0;
 		any |= c[m] > 0;
+	}
+	// particles per model (the reference's "total number of particles" check, gmpm_simulator.cuh:617): one atomic per wave
+	for(int m = 0; m < rm.n; ++m) {
+		int t = c[m];
+#pragma unroll
+		for(int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+		if((threadIdx.x & 63) == 0 && t) atomicAdd(&status[ST_PART0 + m], t);
 	}
 	if(!any) return;
 	const int nb = atomicAdd(new_count, 1);// the compiler turns this into one atomic per wave

@@ -1,0 +1,250 @@
+"""MGSP: static-particle-partition multi-GPU driver (Projects/MGSP/mgsp_benchmark.cuh:361-776), one process per
+GPU over torch.distributed (backend "nccl" == RCCL over xGMI; "gloo" on CPU in the tests).
+
+Each rank owns a fixed subset of the particles for the whole run (reference: one model per device,
+mgsp_benchmark.cuh:240-253) and builds its own sparse partition and grid wherever those particles are.  Grids of
+different ranks overlap only in blocks touched by particles of both.  Per substep:
+
+  grid update (redundant but identical on every owner of a shared block)
+  G2P2G on the halo particle blocks                                       (compute stream)
+  collect shared grid blocks -> ONE all-to-all-v -> reduce into own grid   (comm stream, overlaps with ...)
+  G2P2G on the interior particle blocks                                    (compute stream)
+  partition rebuild
+  halo tagging: ONE all-gather of neighbor-block keys -> overlap marks, send lists, halo/interior split
+
+The reference moves the same data with pairwise cudaMemcpyPeerAsync (halo_buffer.cuh:54-59) and copies of the key
+lists to every peer (mgsp_benchmark.cuh:681-686); on MI355X the all-to-all-v is a grouped send/recv that drives all
+seven xGMI links of a GPU at once, and the exchange is symmetric (a block shared with p is sent to p and received
+from p), so receive counts equal send counts and no count exchange is needed.
+
+The class is generic over the engine API (`api`): the product uses the HIP library with CUDA tensors; the tests run
+the very same logic on CPU tensors with the oracle's API and the gloo backend.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _ffi, scenes
+from .engine import EngineError, build_engine
+
+ROW = 3 + 256  # one halo record: key (3 x int32) + grid block (4 x 64 x f32)
+
+
+def partition_scene(scene, rank, world, axis=0):
+    """Static particle partition: every model is cut into `world` equal-count slabs of the initial lattice."""
+    sc = dict(scene)
+    sc["models"] = []
+    for m in scene["models"]:
+        part = scenes.split_slabs(m["xyz"], world, axis)[rank]
+        mm = dict(m)
+        mm["xyz"] = part
+        sc["models"].append(mm)
+    return sc
+
+
+class TorchDistComm:
+    """The three collectives of MGSP on torch.distributed (RCCL on GPUs, gloo in the CPU tests)."""
+
+    def all_reduce_max(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+
+    def all_gather(self, out, inp):
+        dist.all_gather_into_tensor(out, inp)
+
+    def all_to_all(self, recv, send, splits):
+        dist.all_to_all_single(recv, send, splits, splits)
+
+
+class MgspRank:
+    def __init__(self, scene, rank, world, device=0, api=None, gravity=None, cfl=None, comm=None):
+        self.rank, self.world = rank, world
+        self.comm = comm if comm is not None else TorchDistComm()
+        self.hip = api is None
+        self.api = api if api is not None else _ffi.load_hip()
+        local = partition_scene(scene, rank, world)
+        if gravity is not None:
+            local.setdefault("config", {})["gravity"] = gravity
+        if cfl is not None:
+            local.setdefault("config", {})["cfl"] = cfl
+        self.n_local = scenes.total_particles(local)
+        self.eng = build_engine(local, device=device, api=self.api)
+        self.ctx = self.eng.ctx
+        self.tdev = torch.device("cuda", device) if self.hip else torch.device("cpu")
+        self.pad = 0            # padded key-list length of the tagging all-gather
+        self.send_counts = [0] * world
+        self.buf_send = self.buf_recv = None
+        self._comm_stream = self._compute_stream = None
+        if self.hip:
+            cs, ms = C.c_void_p(), C.c_void_p()
+            self._check(self.api.streams(self.ctx, C.byref(cs), C.byref(ms)))
+            self._compute_stream = torch.cuda.ExternalStream(cs.value, device=self.tdev)
+            self._comm_stream = torch.cuda.ExternalStream(ms.value, device=self.tdev)
+        self._t = {"g2p2g": 0.0, "steps": 0}
+
+    # ---- helpers ----------------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(rc, self.api.last_error(self.ctx).decode())
+
+    def _on(self, stream):
+        """Make torch (and therefore the RCCL collectives it enqueues) use one of the engine's own HIP streams."""
+        return torch.cuda.stream(stream) if self.hip else _Null()
+
+    def close(self):
+        self.eng.close()
+
+    # ---- setup ------------------------------------------------------------------------------------------
+    def initial_setup(self):
+        self.eng.initial_setup()
+        self._tag()
+        self._exchange(gid=0)  # initial rasterised grids are summed once (mgsp_benchmark.cuh:653-654)
+        if self.hip:
+            self._check(self.api.sync(self.ctx))
+
+    # ---- halo tagging (mgsp_benchmark.cuh:661-720) --------------------------------------------------------
+    def _tag(self):
+        api, ctx, w = self.api, self.ctx, self.world
+        n = self.eng.counts().neighbor_blocks
+        if self.pad == 0:  # first call: agree on a padded length (every later length is derived from gathered counts)
+            t = torch.tensor([n], dtype=torch.int32, device=self.tdev)
+            with self._on(self._compute_stream):
+                self.comm.all_reduce_max(t)
+            self.pad = int(1.25 * int(t.item())) + 64
+        while True:
+            pad = self.pad  # identical on all ranks by construction
+            with self._on(self._compute_stream):
+                mine = torch.zeros((pad, 3), dtype=torch.int32, device=self.tdev)
+                cnt = C.c_int(0)
+                self._check(api.halo_keys(ctx, C.c_void_p(mine[1:].data_ptr()), pad - 1, C.byref(cnt)))
+                mine[0, 0] = cnt.value          # row 0 carries the true count (keys are truncated if it exceeds pad-1)
+                allk = torch.empty((w * pad, 3), dtype=torch.int32, device=self.tdev)
+                self.comm.all_gather(allk, mine)
+                head = allk.view(w, pad, 3)[:, 0, 0].cpu()
+            counts = [int(head[p]) for p in range(w)]
+            need = max(counts) + 1
+            if need > pad:  # some rank outgrew the padding: every rank sees it and repeats with the same larger length
+                self.pad = int(1.25 * need) + 64
+                continue
+            if need > 0.9 * pad:
+                self.pad = int(1.25 * need) + 64  # grow ahead of time (takes effect at the next tagging)
+            break
+        self._check(api.halo_tag_begin(ctx))
+        for p in range(w):
+            if p != self.rank:
+                seg = allk[p * pad + 1:]
+                self._check(api.halo_tag_peer(ctx, p, C.c_void_p(seg.data_ptr()), counts[p]))
+        nh = C.c_int(0)
+        sc = (C.c_int * 32)()
+        self._check(api.halo_tag_end(ctx, C.byref(nh), sc))
+        self.send_counts = [int(sc[p]) if p != self.rank else 0 for p in range(w)]
+        self.n_halo_blocks = nh.value
+        self._keep = allk  # keep the gathered keys alive until the tagging kernels have run
+
+    # ---- halo exchange (mgsp_benchmark.cuh:723-776) ---------------------------------------------------------
+    def _exchange(self, gid, overlap_with=None):
+        """collect -> all-to-all-v -> reduce on the comm stream; `overlap_with` (the interior G2P2G launch) is issued
+        on the compute stream right after the transfer has been enqueued (mgsp_benchmark.cuh:449-466)."""
+        api, ctx, w = self.api, self.ctx, self.world
+        total = sum(self.send_counts)
+        splits = [ROW * c for c in self.send_counts]
+        need = max(ROW * total, 1)
+        if self.buf_send is None or self.buf_send.numel() < need:
+            self.buf_send = torch.empty(int(need * 1.5) + ROW, dtype=torch.float32, device=self.tdev)
+            self.buf_recv = torch.empty_like(self.buf_send)
+        send, recv = self.buf_send[: ROW * total], self.buf_recv[: ROW * total]
+        off = 0
+        for p in range(w):
+            c = self.send_counts[p]
+            if c:
+                base = send.data_ptr() + 4 * off
+                ns = C.c_int(0)
+                self._check(api.halo_collect(ctx, p, gid, C.c_void_p(base), C.c_void_p(base + 12 * c), c, C.byref(ns)))
+                assert ns.value == c
+            off += ROW * c
+        with self._on(self._comm_stream):
+            self.comm.all_to_all(recv, send, splits)  # symmetric exchange: recv counts == send counts
+        if overlap_with is not None:
+            overlap_with()
+        off = 0
+        for p in range(w):
+            c = self.send_counts[p]
+            if c:
+                base = recv.data_ptr() + 4 * off
+                self._check(api.halo_reduce(ctx, gid, C.c_void_p(base), C.c_void_p(base + 12 * c), c))
+            off += ROW * c
+        if total == 0:  # nothing shared: still order the compute stream behind the comm stream
+            self._check(api.halo_reduce(ctx, gid, None, None, 0))
+
+    # ---- one substep (mgsp_benchmark.cuh:361-559) -------------------------------------------------------------
+    def _advance(self, dt, next_dt):
+        api, ctx = self.api, self.ctx
+        self._check(api.g2p2g_halo(ctx, dt, next_dt))
+        self._exchange(1, overlap_with=lambda: self._check(api.g2p2g_interior(ctx, dt, next_dt)))
+        self._check(api.rebuild_partition(ctx, None))
+        self._tag()
+
+    def substep(self, dt, next_dt):
+        mv = C.c_float(0)
+        self._check(self.api.grid_update(self.ctx, dt, C.byref(mv)))
+        self._advance(dt, next_dt)
+        return mv.value
+
+    def run_fixed(self, nsteps, dt):
+        for _ in range(nsteps):
+            mv = self.substep(dt, dt)
+            if not np.isfinite(mv):
+                raise EngineError(_ffi.MPM_ERR_NONFINITE, "Maximum velocity is infinity")
+            if self.hip:
+                self._t["g2p2g"] += self.eng.last_g2p2g_ms()
+            self._t["steps"] += 1
+
+    def run_adaptive(self, nsteps, dt0, dt_default, frame_time=1.0 / 24.0):
+        """Adaptive dt as mgsp_benchmark.cuh:410-418: the CFL limit uses the maximum over all ranks."""
+        t, cur, dts = 0.0, dt0, []
+        for _ in range(nsteps):
+            api, ctx = self.api, self.ctx
+            mv2 = C.c_float(0)
+            self._check(api.grid_update(ctx, cur, C.byref(mv2)))
+            m = torch.tensor([mv2.value], dtype=torch.float32, device=self.tdev)
+            self.comm.all_reduce_max(m)   # host max over GPUs in the reference
+            mv = float(np.sqrt(m.item()))
+            nd = self.eng.compute_dt(mv, t, frame_time, dt_default)
+            self._advance(cur, nd)
+            t += cur
+            dts.append(cur)
+            cur = nd
+        return dts
+
+    # ---- reporting ---------------------------------------------------------------------------------------------
+    @property
+    def g2p2g_ms_avg(self):
+        return self._t["g2p2g"] / max(self._t["steps"], 1)
+
+    def phase_ms(self):
+        return {"g2p2g_ms": self.g2p2g_ms_avg, "halo_blocks_sent": int(sum(self.send_counts)), "halo_particle_blocks": int(self.n_halo_blocks)}
+
+    def block_counts(self):
+        c = self.eng.counts()
+        return {"particle": c.particle_blocks, "neighbor": c.neighbor_blocks, "exterior": c.exterior_blocks}
+
+    def local_state(self):
+        return [self.eng.retrieve_state(m) for m in range(len(self.eng.models))]
+
+    def gather_state(self):
+        """All particles of all ranks on every rank (tests): list per model of (xyz, state9, logjp)."""
+        out = []
+        for xyz, st, lj in self.local_state():
+            objs = [None] * self.world
+            dist.all_gather_object(objs, (xyz, st, lj))
+            out.append(tuple(np.concatenate([o[i] for o in objs]) for i in range(3)))
+        return out
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -162,23 +162,31 @@ int mpm_test_svd(const float* F, size_t n, float* out21, int device);
 /* compute_stress<M> (Projects/GMPM/constitutive_models.cuh): out19 = F'(9) PF(9) logjp'(1). */
 int mpm_test_stress(int material, const mpm_material_params* p, const float* F, const float* logjp, size_t n, float* out19, int device);
 
-/* ---- multi-GPU (MGSP static particle partition, Projects/MGSP/mgsp_benchmark.cuh:661-776) ---- */
-/* Device pointer + count of this rank's neighbor-block keys (ivec3) for the all-gather of mgsp_benchmark.cuh:681-686. */
-int mpm_halo_keys(mpm_ctx* ctx, const int** dev_keys, int* count);
-/* mark_overlapping_blocks (halo_kernels.cuh:21-35): peer_keys is a DEVICE array of npeer_keys ivec3 from peer
- * `peer`; builds this rank's send list for that peer.  *nsend receives the number of overlapping blocks. */
-int mpm_halo_tag_peer(mpm_ctx* ctx, int peer, const int* dev_peer_keys, int npeer_keys, int* nsend);
+/* ---- multi-GPU (MGSP static particle partition, Projects/MGSP/mgsp_benchmark.cuh:661-776) ----
+ * One context per rank/GPU owns a fixed particle subset; grids of different ranks overlap only in blocks touched by
+ * particles of both.  All buffers named dev_* are DEVICE pointers supplied by the caller (e.g. torch tensors) so that
+ * the transport (RCCL all-gather / all-to-all over xGMI) stays outside this library.  The exchange kernels run on the
+ * context's comm stream, ordered against the compute stream with events inside the library. */
+/* Copy this rank's neighbor-block keys (ivec3, count = neighbor_blocks) into dev_keys: the payload of the all-gather
+ * that replaces the pairwise cudaMemcpyAsync of mgsp_benchmark.cuh:681-686.  At most capacity_blocks keys are copied;
+ * *count always receives the true number, so a caller with a too small buffer can retry. */
+int mpm_halo_keys(mpm_ctx* ctx, int* dev_keys, int capacity_blocks, int* count);
+/* reset_overlap_marks / reset counts (mgsp_benchmark.cuh:690-692). */
 int mpm_halo_tag_begin(mpm_ctx* ctx);
-/* collect_blockids_for_halo_reduction (halo_kernels.cuh:37-62): split particle blocks into halo / interior lists. */
-int mpm_halo_tag_end(mpm_ctx* ctx, int* halo_particle_blocks);
-/* Phases of a multi-GPU substep (mgsp_benchmark.cuh:421-465): g2p2g on the halo list, on the interior list. */
+/* mark_overlapping_blocks (halo_kernels.cuh:21-35): dev_peer_keys = npeer_keys ivec3 of peer `peer` (0..31); marks this
+ * rank's neighbor blocks that the peer also owns and builds the send list for that peer. */
+int mpm_halo_tag_peer(mpm_ctx* ctx, int peer, const int* dev_peer_keys, int npeer_keys);
+/* collect_blockids_for_halo_reduction (halo_kernels.cuh:37-62): split the particle blocks into halo / interior lists and
+ * read the per-peer send counts back.  send_counts (host, 32 ints, may be NULL) receives them. */
+int mpm_halo_tag_end(mpm_ctx* ctx, int* halo_particle_blocks, int* send_counts);
+/* Phases of a multi-GPU substep (mgsp_benchmark.cuh:421-465): clears + g2p2g on the halo list, then on the interior list. */
 int mpm_g2p2g_halo(mpm_ctx* ctx, float dt, float next_dt);
 int mpm_g2p2g_interior(mpm_ctx* ctx, float dt, float next_dt);
-/* collect_grid_blocks (halo_kernels.cuh:64-80): gather the blocks to send to `peer` into DEVICE buffers
- * dev_keys (nsend*3 ints) and dev_blocks (nsend*256 floats) supplied by the caller (e.g. torch tensors). */
-int mpm_halo_collect(mpm_ctx* ctx, int peer, int* dev_keys, float* dev_blocks, int capacity_blocks, int* nsend);
-/* reduce_grid_blocks (halo_kernels.cuh:82-97): add nrecv received blocks (DEVICE buffers) into the P2G grid. */
-int mpm_halo_reduce(mpm_ctx* ctx, const int* dev_keys, const float* dev_blocks, int nrecv);
+/* collect_grid_blocks (halo_kernels.cuh:64-80): gather the blocks shared with `peer` from grid `gid` (1 = this step's
+ * P2G target, 0 = current grid, used once after initial_setup) into dev_keys (n*3 ints) / dev_blocks (n*256 floats). */
+int mpm_halo_collect(mpm_ctx* ctx, int peer, int gid, int* dev_keys, float* dev_blocks, int capacity_blocks, int* nsend);
+/* reduce_grid_blocks (halo_kernels.cuh:82-97): add nrecv received blocks into grid `gid` (hardware f32 atomics). */
+int mpm_halo_reduce(mpm_ctx* ctx, int gid, const int* dev_keys, const float* dev_blocks, int nrecv);
 /* HIP stream handles (as void*) so that the caller can order collectives against the engine. */
 int mpm_streams(mpm_ctx* ctx, void** compute_stream, void** comm_stream);
 int mpm_sync(mpm_ctx* ctx);

@@ -69,6 +69,13 @@ typedef struct mpmo_ctx {
 	orc_model models[ORC_MAX_MODELS];
 	int *marks, *sources, *destinations, *bin_sizes;
 	int ready;
+	/* MGSP halo state (Projects/MGSP/hash_table.cuh:24-69, halo_buffer.cuh) */
+	int* overlap;
+	int *halo_list, *inner_list;
+	int n_halo, n_inner;
+	int* send_ids[32];
+	int send_count[32];
+	int halo_tagged;
 	mpm_timers timers;
 	char err[256];
 } mpmo_ctx;
@@ -519,7 +526,7 @@ float mpmo_compute_dt(const mpmo_ctx* c, float max_vel, float cur_time, float ne
 }
 
 /* ---- g2p2g, Projects/GMPM/mgmpm_kernels.cuh:665-937 ---- */
-static void g2p2g_model(mpmo_ctx* c, orc_model* m, float dt, float new_dt) {
+static void g2p2g_model(mpmo_ctx* c, orc_model* m, float dt, float new_dt, const int* block_list, int nlist) {
 	const int r = c->rollid, n = r ^ 1;
 	const orc_partition* cur  = &c->part[r];
 	const orc_partition* prev = &c->part[n];
@@ -528,7 +535,8 @@ static void g2p2g_model(mpmo_ctx* c, orc_model* m, float dt, float new_dt) {
 	const float dx = c->dx, dx_inv = c->dx_inv, d_inv = c->d_inv;
 	static float g2p[3][8][8][8];
 	static float p2g[4][8][8][8];
-	for(int b = 0; b < c->pbc; ++b) {
+	for(int bi = 0; bi < (block_list ? nlist : c->pbc); ++bi) {
+		const int b		   = block_list ? block_list[bi] : bi;
 		const int* blockid = cur->keys + 3 * b;
 		const int size	   = dst->bucket_sizes[b];
 		if(size == 0) continue;
@@ -674,9 +682,107 @@ int mpmo_g2p2g(mpmo_ctx* c, float dt, float next_dt) {
 		orc_model* m = &c->models[mi];
 		memset(m->buf[n].cell_counts, 0, sizeof(int) * (size_t) c->ebc * ORC_BLOCKVOL); /* :389 */
 		if((size_t) m->bincount > m->buf[n].bin_cap) return fail(c, MPM_ERR_CAPACITY, "bin capacity");
-		g2p2g_model(c, m, dt, next_dt);
+		g2p2g_model(c, m, dt, next_dt, NULL, 0);
 	}
 	c->timers.g2p2g_ms = (float) (now_ms() - t0);
+	return MPM_OK;
+}
+
+/* ---- MGSP halo path: Projects/MGSP/halo_kernels.cuh, mgsp_benchmark.cuh:421-465, :661-776 ---- */
+int mpmo_halo_keys(mpmo_ctx* c, int* keys, int capacity_blocks, int* count) {
+	if(!c || !c->ready) return MPM_ERR_NOT_READY;
+	const int ncopy = c->nbc < capacity_blocks ? c->nbc : capacity_blocks;
+	memcpy(keys, c->part[c->rollid].keys, sizeof(int) * 3 * (size_t) ncopy);
+	if(count) *count = c->nbc;
+	return MPM_OK;
+}
+int mpmo_halo_tag_begin(mpmo_ctx* c) {
+	if(!c || !c->ready) return MPM_ERR_NOT_READY;
+	if(!c->overlap) {
+		c->overlap	  = (int*) calloc(c->cap + 1, sizeof(int));
+		c->halo_list  = (int*) calloc(c->cap + 1, sizeof(int));
+		c->inner_list = (int*) calloc(c->cap + 1, sizeof(int));
+	}
+	memset(c->overlap, 0, sizeof(int) * ((size_t) c->nbc + 1));
+	for(int p = 0; p < 32; ++p) c->send_count[p] = 0;
+	c->halo_tagged = 0;
+	return MPM_OK;
+}
+/* mark_overlapping_blocks, halo_kernels.cuh:21-35 (restricted to blocks that are neighbor blocks on both sides) */
+int mpmo_halo_tag_peer(mpmo_ctx* c, int peer, const int* peer_keys, int n) {
+	if(!c || !c->ready || !c->overlap || peer < 0 || peer >= 32) return MPM_ERR_INVALID;
+	if(!c->send_ids[peer]) c->send_ids[peer] = (int*) calloc(c->cap + 1, sizeof(int));
+	for(int i = 0; i < n; ++i) {
+		const int b = part_query(c, &c->part[c->rollid], peer_keys[3 * i], peer_keys[3 * i + 1], peer_keys[3 * i + 2]);
+		if(b >= 0 && b < c->nbc) {
+			c->overlap[b] |= 1 << peer;
+			c->send_ids[peer][c->send_count[peer]++] = b;
+		}
+	}
+	return MPM_OK;
+}
+/* collect_blockids_for_halo_reduction, halo_kernels.cuh:37-62 */
+int mpmo_halo_tag_end(mpmo_ctx* c, int* halo_particle_blocks, int* send_counts) {
+	if(!c || !c->ready || !c->overlap) return MPM_ERR_INVALID;
+	const orc_partition* P = &c->part[c->rollid];
+	c->n_halo = c->n_inner = 0;
+	for(int b = 0; b < c->pbc; ++b) {
+		int halo = 0;
+		for(int i = 0; i < 2; ++i)
+			for(int j = 0; j < 2; ++j)
+				for(int k = 0; k < 2; ++k) {
+					const int nb = part_query(c, P, P->keys[3 * b] + i, P->keys[3 * b + 1] + j, P->keys[3 * b + 2] + k);
+					if(nb >= 0 && c->overlap[nb]) halo = 1;
+				}
+		if(halo)
+			c->halo_list[c->n_halo++] = b;
+		else
+			c->inner_list[c->n_inner++] = b;
+	}
+	if(halo_particle_blocks) *halo_particle_blocks = c->n_halo;
+	if(send_counts)
+		for(int p = 0; p < 32; ++p) send_counts[p] = c->send_count[p];
+	c->halo_tagged = 1;
+	return MPM_OK;
+}
+int mpmo_g2p2g_halo(mpmo_ctx* c, float dt, float next_dt) {
+	if(!c || !c->ready || !c->halo_tagged) return MPM_ERR_NOT_READY;
+	const int n = c->rollid ^ 1;
+	clear_grid(c->grid[1], c->nbc);
+	for(int mi = 0; mi < c->nmodels; ++mi) {
+		orc_model* m = &c->models[mi];
+		memset(m->buf[n].cell_counts, 0, sizeof(int) * (size_t) c->ebc * ORC_BLOCKVOL);
+		g2p2g_model(c, m, dt, next_dt, c->halo_list, c->n_halo);
+	}
+	return MPM_OK;
+}
+int mpmo_g2p2g_interior(mpmo_ctx* c, float dt, float next_dt) {
+	if(!c || !c->ready || !c->halo_tagged) return MPM_ERR_NOT_READY;
+	for(int mi = 0; mi < c->nmodels; ++mi) g2p2g_model(c, &c->models[mi], dt, next_dt, c->inner_list, c->n_inner);
+	return MPM_OK;
+}
+/* collect_grid_blocks, halo_kernels.cuh:64-80 */
+int mpmo_halo_collect(mpmo_ctx* c, int peer, int gid, int* keys, float* blocks, int capacity_blocks, int* nsend) {
+	if(!c || !c->ready || !c->halo_tagged || peer < 0 || peer >= 32 || gid < 0 || gid > 1) return MPM_ERR_INVALID;
+	const int n = c->send_count[peer];
+	if(nsend) *nsend = n;
+	if(n > capacity_blocks) return fail(c, MPM_ERR_CAPACITY, "halo send buffer too small");
+	for(int i = 0; i < n; ++i) {
+		const int b = c->send_ids[peer][i];
+		memcpy(keys + 3 * i, c->part[c->rollid].keys + 3 * b, sizeof(int) * 3);
+		memcpy(blocks + (size_t) i * 256, grid_block(c->grid[gid], b), sizeof(float) * 256);
+	}
+	return MPM_OK;
+}
+/* reduce_grid_blocks, halo_kernels.cuh:82-97 */
+int mpmo_halo_reduce(mpmo_ctx* c, int gid, const int* keys, const float* blocks, int nrecv) {
+	if(!c || !c->ready || gid < 0 || gid > 1) return MPM_ERR_INVALID;
+	for(int i = 0; i < nrecv; ++i) {
+		const int b = part_query(c, &c->part[c->rollid], keys[3 * i], keys[3 * i + 1], keys[3 * i + 2]);
+		if(b < 0 || b >= c->nbc) continue;
+		float* g = grid_block(c->grid[gid], b);
+		for(int k = 0; k < 256; ++k) g[k] += blocks[(size_t) i * 256 + k];
+	}
 	return MPM_OK;
 }
 

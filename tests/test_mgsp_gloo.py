@@ -1,0 +1,127 @@
+"""Multi-process path of the MGSP driver on CPU: world_size 2 and 3 over gloo, with the CPU oracle as the engine
+behind the same claymore_amd.mgsp.MgspRank logic the GPUs run.  The N-rank result must equal the 1-rank result
+(sums of shared grid blocks only change the float summation order)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scene(kind):
+    from claymore_amd import _ffi, scenes
+    if kind == "collide":
+        return scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=0.5, speed=2.0, youngs=2e4)
+    if kind == "apart":      # ranks share no grid block for the first steps, then meet
+        return scenes.two_spheres(bits=6, radius_cells=4.0, gap_cells=6.0, speed=6.0)
+    if kind == "sand":
+        sc = scenes.sphere_drop(bits=6, radius_cells=6.0, center=(0.5, 0.3, 0.5), material=_ffi.SAND)
+        sc["models"][0]["params"] = {}
+        return sc
+    raise ValueError(kind)
+
+
+def _worker(rank, world, port, kind, nsteps, adaptive, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from claymore_amd.mgsp import MgspRank
+    from oracle_ffi import oracle_api
+    sim = MgspRank(_scene(kind), rank, world, api=oracle_api())
+    sim.initial_setup()
+    shared = []
+    if adaptive:
+        dts = sim.run_adaptive(nsteps, 1e-4, 2e-3)
+    else:
+        dts = None
+        for _ in range(nsteps):
+            sim.substep(1e-4, 1e-4)
+            shared.append(sum(sim.send_counts))
+    state = sim.gather_state()
+    tot = sim.eng.grid_totals()
+    if rank == 0:
+        q.put((state, shared, dts, tot))
+    sim.close()
+    dist.destroy_process_group()
+
+
+def _run(world, kind, nsteps, adaptive=False):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, nsteps, adaptive, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return out
+
+
+def _single(kind, nsteps, adaptive=False):
+    from claymore_amd.engine import build_engine
+    from oracle_ffi import oracle_api
+    eng = build_engine(_scene(kind), api=oracle_api())
+    eng.initial_setup()
+    dts = None
+    if adaptive:
+        t, cur, dts = 0.0, 1e-4, []
+        for _ in range(nsteps):
+            nd, mv = eng.substep(cur, t, 1.0 / 24.0, 2e-3)
+            t += cur
+            dts.append(cur)
+            cur = nd
+    else:
+        eng.run_fixed(nsteps, 1e-4)
+    st = [eng.retrieve_state(m) for m in range(len(eng.models))]
+    eng.close()
+    return st, dts
+
+
+def _compare(multi, single, tol=1e-5):
+    from parity_util import match
+    for (xm, sm, lm), (xs, ss, ls) in zip(multi, single):
+        assert xm.shape == xs.shape
+        idx, d = match(xs.astype(np.float64), xm.astype(np.float64))
+        rel = np.abs(xm[idx].astype(np.float64) - xs).max(axis=1) / np.abs(xs).max(axis=1)
+        assert rel.max() < tol, rel.max()
+        assert np.abs(sm[idx] - ss).max() < 1e-4
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_collision_equals_single_rank(world):
+    state, shared, _, _ = _run(world, "collide", 40)
+    single, _ = _single("collide", 40)
+    _compare(state, single)
+    assert max(shared) > 0           # the ranks did exchange halo blocks
+
+
+def test_ranks_meet_later_world2():
+    """Model slabs of one sphere always overlap; additionally check the sand model and a late first contact."""
+    state, shared, _, _ = _run(2, "sand", 25)
+    single, _ = _single("sand", 25)
+    _compare(state, single)
+
+
+def test_adaptive_dt_uses_global_max_world2():
+    state, _, dts, _ = _run(2, "apart", 12, adaptive=True)
+    single, dts1 = _single("apart", 12, adaptive=True)
+    assert np.allclose(dts, dts1, rtol=1e-4)
+    _compare(state, single)
