@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--scene", default="sand40m", choices=["sand40m", "sphere5m", "spheres50k"])
     ap.add_argument("--fraction", type=float, default=1.0, help="debug: shrink the sand column")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mgsp", action="store_true", help="debug: drive the multi-GPU code path even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -99,13 +100,16 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_mgsp = world > 1 or args.mgsp
+    if use_mgsp:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as g
     if rank == 0:
         g.build_hip()
-    if world > 1:
+    if use_mgsp:
         dist.barrier()
 
     from claymore_amd import scenes
@@ -114,7 +118,7 @@ def main():
     material = sc["models"][0]["material"]
     dt = sc["dt"]
 
-    if world == 1:
+    if not use_mgsp:
         from claymore_amd.engine import build_engine
         eng = build_engine(sc, device=local_rank)
         eng.initial_setup()
@@ -170,10 +174,10 @@ def main():
                          "kernel": "g2p2g_kernel", "bytes_per_particle": bpp, "particles_per_launch": n_rank,
                          "kernel_ms": g2p2g_ms},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.mgsp:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
-    if world > 1:
+    if use_mgsp:
         dist.destroy_process_group()
 
 

@@ -74,6 +74,10 @@ HALO = {
     "g2p2g_interior": (_i, [_vp, _f, _f]),
     "halo_collect": (_i, [_vp, _i, _i, _vp, _vp, _i, _ip]),
     "halo_reduce": (_i, [_vp, _i, _vp, _vp, _i]),
+    "mgsp_begin": (_i, [_vp, _f, _f]),
+    "mgsp_rebuild_export": (_i, [_vp, _vp, _i]),
+    "mgsp_tag": (_i, [_vp, _vp, _i, _i, _i]),
+    "mgsp_end": (_i, [_vp, _ip, _ip, _ip, _fp]),
 }
 SIGNATURES.update(HALO)
 # entry points only the HIP library has (stream plumbing + kernel timing)

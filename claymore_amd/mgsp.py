@@ -179,13 +179,45 @@ class MgspRank:
 
     # ---- one substep (mgsp_benchmark.cuh:361-559) -------------------------------------------------------------
     def _advance(self, dt, next_dt):
+        """Phase-by-phase variant (one host synchronisation per phase, like the reference's issue()/sync())."""
         api, ctx = self.api, self.ctx
         self._check(api.g2p2g_halo(ctx, dt, next_dt))
         self._exchange(1, overlap_with=lambda: self._check(api.g2p2g_interior(ctx, dt, next_dt)))
         self._check(api.rebuild_partition(ctx, None))
         self._tag()
 
+    def _key_buffers(self):
+        if getattr(self, "_kb_pad", None) != self.pad:
+            with self._on(self._compute_stream):
+                self._kb_mine = torch.zeros((self.pad, 3), dtype=torch.int32, device=self.tdev)
+                self._kb_all = torch.zeros((self.world * self.pad, 3), dtype=torch.int32, device=self.tdev)
+            self._kb_pad = self.pad
+        return self._kb_mine, self._kb_all
+
     def substep(self, dt, next_dt):
+        """Fused variant: everything is enqueued, ONE host synchronisation at the end (mpm_mgsp_end)."""
+        api, ctx = self.api, self.ctx
+        self._check(api.mgsp_begin(ctx, dt, next_dt))
+        self._exchange(1, overlap_with=lambda: self._check(api.g2p2g_interior(ctx, dt, next_dt)))
+        pad = self.pad
+        mine, allk = self._key_buffers()
+        with self._on(self._compute_stream):
+            self._check(api.mgsp_rebuild_export(ctx, C.c_void_p(mine.data_ptr()), pad))
+            self.comm.all_gather(allk, mine)
+        self._check(api.mgsp_tag(ctx, C.c_void_p(allk.data_ptr()), pad, self.world, self.rank))
+        sc, nh, mx, mv = (C.c_int * 32)(), C.c_int(0), C.c_int(0), C.c_float(0)
+        self._check(api.mgsp_end(ctx, sc, C.byref(nh), C.byref(mx), C.byref(mv)))
+        if mx.value > pad:      # a key list was truncated (same verdict on every rank): tag again with a larger padding
+            self.pad = int(1.25 * mx.value) + 64
+            self._tag()
+        else:
+            if mx.value > 0.9 * pad:
+                self.pad = int(1.25 * mx.value) + 64
+            self.send_counts = [int(sc[p]) if p != self.rank else 0 for p in range(self.world)]
+            self.n_halo_blocks = nh.value
+        return mv.value
+
+    def substep_phased(self, dt, next_dt):
         mv = C.c_float(0)
         self._check(self.api.grid_update(self.ctx, dt, C.byref(mv)))
         self._advance(dt, next_dt)

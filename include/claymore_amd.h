@@ -187,6 +187,24 @@ int mpm_g2p2g_interior(mpm_ctx* ctx, float dt, float next_dt);
 int mpm_halo_collect(mpm_ctx* ctx, int peer, int gid, int* dev_keys, float* dev_blocks, int capacity_blocks, int* nsend);
 /* reduce_grid_blocks (halo_kernels.cuh:82-97): add nrecv received blocks into grid `gid` (hardware f32 atomics). */
 int mpm_halo_reduce(mpm_ctx* ctx, int gid, const int* dev_keys, const float* dev_blocks, int nrecv);
+/* ---- fused multi-GPU substep: the same phases with ONE host synchronisation per substep ----
+ * (the phase-by-phase calls above synchronise once each, like the reference's issue()/sync() barriers,
+ * mgsp_benchmark.cuh:336-356; at 5 M particles per GPU that costs more than the kernels.)
+ *   mpm_mgsp_begin        : grid update (no read-back) + clears + G2P2G on the halo list
+ *   mpm_halo_collect xN, all-to-all-v, mpm_g2p2g_interior, mpm_halo_reduce xN      (as above)
+ *   mpm_mgsp_rebuild_export: partition rebuild launches + padded key export for the all-gather: dev_keys holds
+ *                            pad_rows rows of 3 ints, row 0 = {neighbor-block count, 0, 0}, rows 1.. = keys
+ *   all-gather of the padded key lists (caller)
+ *   mpm_mgsp_tag          : overlap marks / send lists / halo split from the gathered lists (world*pad_rows rows),
+ *                            all sizes read on the device
+ *   mpm_mgsp_end          : the one synchronisation: counts, send counts (32), halo block count, max |v|^2 of this
+ *                            step's grid update; rolls the double buffers.  *max_peer_rows = largest key-list length
+ *                            (+1) any rank exported: if it exceeds pad_rows the caller re-tags with a larger pad. */
+int mpm_mgsp_begin(mpm_ctx* ctx, float dt, float next_dt);
+int mpm_mgsp_rebuild_export(mpm_ctx* ctx, int* dev_keys, int pad_rows);
+int mpm_mgsp_tag(mpm_ctx* ctx, const int* dev_all_keys, int pad_rows, int world, int rank);
+int mpm_mgsp_end(mpm_ctx* ctx, int* send_counts, int* halo_particle_blocks, int* max_peer_rows, float* max_vel_sqr);
+
 /* HIP stream handles (as void*) so that the caller can order collectives against the engine. */
 int mpm_streams(mpm_ctx* ctx, void** compute_stream, void** comm_stream);
 int mpm_sync(mpm_ctx* ctx);

@@ -76,6 +76,8 @@ typedef struct mpmo_ctx {
 	int* send_ids[32];
 	int send_count[32];
 	int halo_tagged;
+	float last_max_vel_sqr;
+	int peer_rows_max;
 	mpm_timers timers;
 	char err[256];
 } mpmo_ctx;
@@ -1005,6 +1007,45 @@ int mpmo_dump_grid(mpmo_ctx* c, int* keys, float* blocks, size_t* nblocks) {
 	if(keys) memcpy(keys, c->part[c->rollid].keys, sizeof(int) * 3 * (size_t) c->nbc);
 	if(blocks) memcpy(blocks, c->grid[0], sizeof(float) * 256 * (size_t) c->nbc);
 	*nblocks = c->nbc;
+	return MPM_OK;
+}
+
+/* fused substep API (include/claymore_amd.h): synchronous here, so built from the phase functions */
+int mpmo_mgsp_begin(mpmo_ctx* c, float dt, float next_dt) {
+	int rc = mpmo_grid_update(c, dt, &c->last_max_vel_sqr);
+	if(rc) return rc;
+	return mpmo_g2p2g_halo(c, dt, next_dt);
+}
+int mpmo_mgsp_rebuild_export(mpmo_ctx* c, int* keys, int pad_rows) {
+	int rc = mpmo_rebuild_partition(c, NULL);
+	if(rc) return rc;
+	memset(keys, 0, sizeof(int) * 3 * (size_t) pad_rows);
+	keys[0]		= c->nbc;
+	const int n = c->nbc < pad_rows - 1 ? c->nbc : pad_rows - 1;
+	memcpy(keys + 3, c->part[c->rollid].keys, sizeof(int) * 3 * (size_t) n);
+	return MPM_OK;
+}
+int mpmo_mgsp_tag(mpmo_ctx* c, const int* all_keys, int pad_rows, int world, int rank) {
+	int rc = mpmo_halo_tag_begin(c);
+	if(rc) return rc;
+	c->peer_rows_max = 0;
+	for(int p = 0; p < world; ++p) {
+		const int* rows = all_keys + (size_t) 3 * pad_rows * p;
+		if(rows[0] + 1 > c->peer_rows_max) c->peer_rows_max = rows[0] + 1;
+		if(p == rank) continue;
+		const int n = rows[0] < pad_rows - 1 ? rows[0] : pad_rows - 1;
+		rc			= mpmo_halo_tag_peer(c, p, rows + 3, n);
+		if(rc) return rc;
+	}
+	return mpmo_halo_tag_end(c, NULL, NULL);
+}
+int mpmo_mgsp_end(mpmo_ctx* c, int* send_counts, int* halo_particle_blocks, int* max_peer_rows, float* max_vel_sqr) {
+	if(!c || !c->ready) return MPM_ERR_NOT_READY;
+	if(send_counts)
+		for(int p = 0; p < 32; ++p) send_counts[p] = c->send_count[p];
+	if(halo_particle_blocks) *halo_particle_blocks = c->n_halo;
+	if(max_peer_rows) *max_peer_rows = c->peer_rows_max;
+	if(max_vel_sqr) *max_vel_sqr = c->last_max_vel_sqr;
 	return MPM_OK;
 }
 

@@ -36,7 +36,7 @@ def _scene(kind):
     raise ValueError(kind)
 
 
-def _worker(rank, world, port, kind, nsteps, adaptive, q):
+def _worker(rank, world, port, kind, nsteps, adaptive, q, phased=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -51,7 +51,7 @@ def _worker(rank, world, port, kind, nsteps, adaptive, q):
     else:
         dts = None
         for _ in range(nsteps):
-            sim.substep(1e-4, 1e-4)
+            (sim.substep_phased if phased else sim.substep)(1e-4, 1e-4)
             shared.append(sum(sim.send_counts))
     state = sim.gather_state()
     tot = sim.eng.grid_totals()
@@ -61,11 +61,11 @@ def _worker(rank, world, port, kind, nsteps, adaptive, q):
     dist.destroy_process_group()
 
 
-def _run(world, kind, nsteps, adaptive=False):
+def _run(world, kind, nsteps, adaptive=False, phased=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, nsteps, adaptive, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, nsteps, adaptive, q, phased)) for r in range(world)]
     for p in procs:
         p.start()
     out = q.get(timeout=300)
@@ -111,6 +111,13 @@ def test_collision_equals_single_rank(world):
     single, _ = _single("collide", 40)
     _compare(state, single)
     assert max(shared) > 0           # the ranks did exchange halo blocks
+
+
+def test_phased_variant_world2():
+    """The phase-by-phase API (one sync per phase, the reference's issue()/sync() structure) gives the same result."""
+    state, shared, _, _ = _run(2, "collide", 30, phased=True)
+    single, _ = _single("collide", 30)
+    _compare(state, single)
 
 
 def test_ranks_meet_later_world2():

@@ -65,7 +65,7 @@ class _RankComm:
         self._done()
 
 
-def _run_threads(scene, world, nsteps, dt):
+def _run_threads(scene, world, nsteps, dt, phased=False):
     group = ThreadComm(world)
     results, errors = [None] * world, []
 
@@ -75,7 +75,7 @@ def _run_threads(scene, world, nsteps, dt):
             sim.initial_setup()
             shared = 0
             for _ in range(nsteps):
-                sim.substep(dt, dt)
+                (sim.substep_phased if phased else sim.substep)(dt, dt)
                 shared = max(shared, sum(sim.send_counts))
             results[rank] = (sim.local_state(), shared, sim.n_halo_blocks)
             sim.close()
@@ -92,8 +92,8 @@ def _run_threads(scene, world, nsteps, dt):
     return results
 
 
-@pytest.mark.parametrize("world,kind", [(2, "collide"), (4, "collide"), (2, "sand")])
-def test_multi_context_equals_oracle(world, kind):
+@pytest.mark.parametrize("world,kind,phased", [(2, "collide", False), (4, "collide", False), (2, "sand", False), (2, "collide", True)])
+def test_multi_context_equals_oracle(world, kind, phased):
     if kind == "collide":
         sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=0.5, speed=2.0, youngs=2e4)
         nsteps = 60
@@ -101,7 +101,7 @@ def test_multi_context_equals_oracle(world, kind):
         sc = scenes.sphere_drop(bits=6, radius_cells=6.0, center=(0.5, 0.3, 0.5), material=_ffi.SAND)
         sc["models"][0]["params"] = {}
         nsteps = 30
-    res = _run_threads(sc, world, nsteps, 1e-4)
+    res = _run_threads(sc, world, nsteps, 1e-4, phased)
     assert max(r[1] for r in res) > 0          # halo blocks were exchanged
     assert max(r[2] for r in res) > 0          # and some particle blocks went through the halo-first pass
     ora = run_engine(sc, nsteps, 1e-4, api=oracle_api())
