@@ -1,0 +1,36 @@
+// host_selftest.cpp — exercises the pieces of the host drivers that need no GPU (JSON reader, lattice sampler, BGEO
+// writer).  usage: host_selftest <out.bgeo>  -> prints "json_ok <n_models> <dt>", "sphere <count>", "bgeo <bytes>"
+#include <cstring>
+#include <iostream>
+
+#include "mini_json.hpp"
+#include "particle_io.hpp"
+
+int main(int argc, char** argv) {
+	const char* text = R"({"simulation": {"gpuid": 0, "fps": 1200, "frames": 2, "default_dt": 5e-6},
+	  "models": [{"type": "particle", "file": "two_dragons.sdf", "constitutive": "jfluid", "offset": [0.1, 0.1, 0.1],
+	              "span": [1.0, 1.0, 1.0], "velocity": [0.0, -1.0, 0.0], "nested": {"a": [true, false, null, "s\"q"]}},
+	             {"file": "sphere", "constitutive": "sand", "offset": [0.2, 0.1, 0.2], "span": [1, 1, 1], "velocity": [0, -1e0, 0]}]})";
+	auto doc = mj::parse(text);
+	std::cout << "json_ok " << (*doc)["models"].arr.size() << " " << (*doc)["simulation"]["default_dt"].number() << " "
+			  << (*doc)["models"][0]["nested"]["a"][3].string() << " " << (*doc)["models"][1]["velocity"][1].number() << "\n";
+	bool threw = false;
+	try {
+		mj::parse("{\"a\": [1, 2}");
+	} catch(const std::exception&) {
+		threw = true;
+	}
+	std::cout << "json_bad " << (threw ? "rejected" : "accepted") << "\n";
+	const float dx = 1.f / 64.f;
+	const int lo[3] = {20, 20, 20}, hi[3] = {44, 44, 44};
+	auto pts = pio::sample_lattice(dx, lo, hi, [&](const std::array<float, 3>& p) {
+		const float a = p[0] - 0.5f, b = p[1] - 0.5f, c = p[2] - 0.5f;
+		return a * a + b * b + c * c <= (5 * dx) * (5 * dx);
+	});
+	std::cout << "sphere " << pts.size() << "\n";
+	if(argc > 1) {
+		const float xyz[6] = {0.25f, 0.5f, 0.75f, -1.5f, 2.0f, 3.25f};
+		std::cout << "bgeo " << (pio::write_bgeo(argv[1], xyz, 2) ? "written" : "failed") << "\n";
+	}
+	return 0;
+}
