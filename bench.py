@@ -174,6 +174,13 @@ def main():
                          "kernel": "g2p2g_kernel", "bytes_per_particle": bpp, "particles_per_launch": n_rank,
                          "kernel_ms": g2p2g_ms},
         }
+        # measured HBM traffic of the same kernel on the same workload (PMC passes are separate runs, see profiles/)
+        tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if world == 1 and args.scene == "sand40m" and args.fraction >= 1.0 and os.path.exists(tf):
+            t = json.load(open(tf))
+            out["roofline"]["traffic"] = t["traffic_bytes"]
+            out["roofline"]["traffic_source"] = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated)"
+            out["roofline"]["algorithmic_bytes"] = n_rank * bpp
         if world == 1 and not args.no_cpu_baseline and not args.mgsp:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
