@@ -71,8 +71,12 @@ MPM_DEV float rsqrt_newton(float x) {
 	return t1 - t3;
 }
 
-// One Jacobi conjugation, Library/MnBase/Math/Matrix/svd.cuh:167-252 (and its two index-permuted copies).
-MPM_DEV void jacobi_conj(float& s11, float& s21, float& s22, float& s31, float& s32, float& s33, float& qx, float& qy, float& qz, float& qs) {
+// One Jacobi conjugation, Library/MnBase/Math/Matrix/svd.cuh:167-252 (and its two index-permuted copies): same
+// approximate Givens angle (rsqrt-normalised (ch, sh), pi/8 fallback).  Two deliberate simplifications, both exact
+// in exact arithmetic and ~1e-7 in fp32: (1) columns p, q of V are rotated directly instead of accumulating a
+// quaternion that is normalised and expanded afterwards (:236-252, :475-530); (2) the compensation factors
+// (sh^2 + ch^2), which equal 1 up to the rsqrt rounding, are dropped (:219-223).
+MPM_DEV void jacobi_conj(float& s11, float& s21, float& s22, float& s31, float& s32, float& s33, float (&vp)[3], float (&vq)[3]) {
 	float sh   = s21 * 0.5f;
 	float tmp5 = s11 - s22;
 	float tmp2 = sh * sh;
@@ -81,59 +85,32 @@ MPM_DEV void jacobi_conj(float& s11, float& s21, float& s22, float& s31, float& 
 	float ch   = m ? tmp5 : 1.0f;
 	float tmp1 = sh * sh;
 	tmp2	   = ch * ch;
-	float tmp3 = tmp1 + tmp2;
-	float tmp4 = rsqrt_approx(tmp3);
+	const float tmp4 = rsqrt_approx(tmp1 + tmp2);
 	sh		   = tmp4 * sh;
 	ch		   = tmp4 * ch;
-	tmp1	   = 5.8284273147583007813f * tmp1;
-	m		   = tmp2 <= tmp1;
+	m		   = tmp2 <= 5.8284273147583007813f * tmp1;
 	sh		   = m ? __uint_as_float(1053028117u) : sh;// sin(pi/8)
 	ch		   = m ? __uint_as_float(1064076127u) : ch;// cos(pi/8)
-	tmp1	   = sh * sh;
-	tmp2	   = ch * ch;
-	float c	   = tmp2 - tmp1;
-	float s	   = ch * sh;
-	s		   = s + s;
-	tmp3	   = tmp1 + tmp2;
-	s33		   = s33 * tmp3;
-	s31		   = s31 * tmp3;
-	s32		   = s32 * tmp3;
-	s33		   = s33 * tmp3;
-	tmp1	   = s * s31;
-	tmp2	   = s * s32;
-	s31		   = c * s31;
-	s32		   = c * s32;
-	s31		   = tmp2 + s31;
-	s32		   = s32 - tmp1;
-	tmp2	   = s * s;
-	tmp1	   = s22 * tmp2;
-	tmp3	   = s11 * tmp2;
-	tmp4	   = c * c;
-	s11		   = s11 * tmp4;
-	s22		   = s22 * tmp4;
-	s11		   = s11 + tmp1;
-	s22		   = s22 + tmp3;
-	tmp4	   = tmp4 - tmp2;
-	tmp2	   = s21 + s21;
-	s21		   = s21 * tmp4;
-	tmp4	   = c * s;
-	tmp2	   = tmp2 * tmp4;
-	tmp5	   = tmp5 * tmp4;
-	s11		   = s11 + tmp2;
-	s21		   = s21 - tmp5;
-	s22		   = s22 - tmp2;
-	tmp1	   = sh * qx;
-	tmp2	   = sh * qy;
-	tmp3	   = sh * qz;
-	sh		   = sh * qs;
-	qs		   = ch * qs;
-	qx		   = ch * qx;
-	qy		   = ch * qy;
-	qz		   = ch * qz;
-	qz		   = qz + sh;
-	qs		   = qs - tmp3;
-	qx		   = qx + tmp2;
-	qy		   = qy - tmp1;
+	const float c = ch * ch - sh * sh;
+	const float s = 2.f * ch * sh;
+	// Givens conjugation of the symmetric matrix
+	const float t31 = s * s31, t32 = s * s32;
+	s31				= c * s31 + t32;
+	s32				= c * s32 - t31;
+	const float ss = s * s, cc = c * c, cs = c * s;
+	const float n11 = s11 * cc + s22 * ss;
+	const float n22 = s22 * cc + s11 * ss;
+	const float t2	= (s21 + s21) * cs;
+	s21				= s21 * (cc - ss) - tmp5 * cs;
+	s11				= n11 + t2;
+	s22				= n22 - t2;
+	// V <- V G
+#pragma unroll
+	for(int r = 0; r < 3; ++r) {
+		const float a = vp[r], b = vq[r];
+		vp[r]		  = c * a + s * b;
+		vq[r]		  = c * b - s * a;
+	}
 }
 
 MPM_DEV void cond_swap(bool c, float& x, float& y) {
@@ -182,142 +159,97 @@ MPM_DEV void qr_givens(float apiv, float aqpiv, float& ap1, float& ap2, float& a
 }
 
 // math::svd, Library/MnBase/Math/Matrix/svd.cuh:27-1123.  Column-major F, U, V.
+// Same algorithm as the reference (4 cyclic Jacobi sweeps on F^T F, columns sorted by norm with V kept a rotation,
+// sigma_3 carrying the sign of det F).  U and Sigma come from B = F V: when B is well conditioned its columns are
+// sigma_i u_i, so they are normalised directly (sigma_i = |b_i|, sign of sigma_3 from det B); the reference's Givens
+// QR (:771-1122) is kept as the path for ill-conditioned B (sigma_3 < 1e-3 sigma_1), where normalising would divide
+// by ~0.  Deviation from the reference's QR result is of the order of the Jacobi residual of the reference itself
+// (tests/test_parity_gpu.py, tools note in DESIGN.md section 6).
 MPM_DEV void svd3(const float (&F)[9], float (&U)[9], float (&S)[3], float (&V)[9]) {
-	float a11 = F[0], a21 = F[1], a31 = F[2], a12 = F[3], a22 = F[4], a32 = F[5], a13 = F[6], a23 = F[7], a33 = F[8];
-	float s11 = a11 * a11 + a21 * a21 + a31 * a31;
-	float s21 = a12 * a11 + a22 * a21 + a32 * a31;
-	float s31 = a13 * a11 + a23 * a21 + a33 * a31;
-	float s22 = a12 * a12 + a22 * a22 + a32 * a32;
-	float s32 = a13 * a12 + a23 * a22 + a33 * a32;
-	float s33 = a13 * a13 + a23 * a23 + a33 * a33;
-	float qs = 1.f, qx = 0.f, qy = 0.f, qz = 0.f;
+	float s11 = F[0] * F[0] + F[1] * F[1] + F[2] * F[2];
+	float s21 = F[3] * F[0] + F[4] * F[1] + F[5] * F[2];
+	float s31 = F[6] * F[0] + F[7] * F[1] + F[8] * F[2];
+	float s22 = F[3] * F[3] + F[4] * F[4] + F[5] * F[5];
+	float s32 = F[6] * F[3] + F[7] * F[4] + F[8] * F[5];
+	float s33 = F[6] * F[6] + F[7] * F[7] + F[8] * F[8];
+	float v1[3] = {1.f, 0.f, 0.f}, v2[3] = {0.f, 1.f, 0.f}, v3[3] = {0.f, 0.f, 1.f};
 #pragma unroll
 	for(int it = 0; it < 4; ++it) {
-		jacobi_conj(s11, s21, s22, s31, s32, s33, qx, qy, qz, qs);
-		jacobi_conj(s22, s32, s33, s21, s31, s11, qy, qz, qx, qs);
-		jacobi_conj(s33, s31, s11, s32, s21, s22, qz, qx, qy, qs);
+		jacobi_conj(s11, s21, s22, s31, s32, s33, v1, v2);
+		jacobi_conj(s22, s32, s33, s21, s31, s11, v2, v3);
+		jacobi_conj(s33, s31, s11, s32, s21, s22, v3, v1);
 	}
-	// normalise the quaternion (svd.cuh:475-498) and expand it to V (:500-530)
-	{
-		const float n = rsqrt_newton(qs * qs + qx * qx + qy * qy + qz * qz);
-		qs *= n;
-		qx *= n;
-		qy *= n;
-		qz *= n;
+	// B = F V (svd.cuh:532-588), columns b1 b2 b3
+	float b1[3], b2[3], b3[3];
+#pragma unroll
+	for(int r = 0; r < 3; ++r) {
+		b1[r] = F[r] * v1[0] + F[3 + r] * v1[1] + F[6 + r] * v1[2];
+		b2[r] = F[r] * v2[0] + F[3 + r] * v2[1] + F[6 + r] * v2[2];
+		b3[r] = F[r] * v3[0] + F[3 + r] * v3[1] + F[6 + r] * v3[2];
 	}
-	float tmp1 = qx * qx, tmp2 = qy * qy, tmp3 = qz * qz;
-	float v11 = qs * qs;
-	float v22 = v11 - tmp1;
-	float v33 = v22 - tmp2;
-	v33		  = v33 + tmp3;
-	v22		  = v22 + tmp2;
-	v22		  = v22 - tmp3;
-	v11		  = v11 + tmp1;
-	v11		  = v11 - tmp2;
-	v11		  = v11 - tmp3;
-	tmp1	  = qx + qx;
-	tmp2	  = qy + qy;
-	tmp3	  = qz + qz;
-	float v32 = qs * tmp1;
-	float v13 = qs * tmp2;
-	float v21 = qs * tmp3;
-	tmp1	  = qy * tmp1;
-	tmp2	  = qz * tmp2;
-	tmp3	  = qx * tmp3;
-	float v12 = tmp1 - v21;
-	float v23 = tmp2 - v32;
-	float v31 = tmp3 - v13;
-	v21		  = tmp1 + v21;
-	v32		  = tmp2 + v32;
-	v13		  = tmp3 + v13;
-	// B = A V (svd.cuh:532-588)
-#define MPM_ROWV(x1, x2, x3)                          \
-	{                                                 \
-		const float o1 = x1, o2 = x2, o3 = x3;        \
-		x1 = v11 * o1 + v21 * o2 + v31 * o3;          \
-		x2 = v12 * o1 + v22 * o2 + v32 * o3;          \
-		x3 = v13 * o1 + v23 * o2 + v33 * o3;          \
+	float n1 = b1[0] * b1[0] + b1[1] * b1[1] + b1[2] * b1[2];
+	float n2 = b2[0] * b2[0] + b2[1] * b2[1] + b2[2] * b2[2];
+	float n3 = b3[0] * b3[0] + b3[1] * b3[1] + b3[2] * b3[2];
+	// sort columns by squared norm, descending; a swap negates one column so that V stays a rotation (svd.cuh:590-770)
+#define MPM_SWAPCOL(c, x, y, nx, ny, neg)                         \
+	{                                                             \
+		const float sg = (c) ? -1.f : 1.f;                        \
+		_Pragma("unroll") for(int r = 0; r < 3; ++r) {            \
+			cond_swap(c, b##x[r], b##y[r]);                       \
+			cond_swap(c, v##x[r], v##y[r]);                       \
+			b##neg[r] *= sg;                                      \
+			v##neg[r] *= sg;                                      \
+		}                                                         \
+		cond_swap(c, nx, ny);                                     \
 	}
-	MPM_ROWV(a11, a12, a13)
-	MPM_ROWV(a21, a22, a23)
-	MPM_ROWV(a31, a32, a33)
-#undef MPM_ROWV
-	// sort columns by squared norm, descending, keeping V a rotation (svd.cuh:590-770)
-	tmp1 = a11 * a11 + a21 * a21 + a31 * a31;
-	tmp2 = a12 * a12 + a22 * a22 + a32 * a32;
-	tmp3 = a13 * a13 + a23 * a23 + a33 * a33;
-	{
-		bool c = tmp1 < tmp2;
-		cond_swap(c, a11, a12);
-		cond_swap(c, a21, a22);
-		cond_swap(c, a31, a32);
-		cond_swap(c, v11, v12);
-		cond_swap(c, v21, v22);
-		cond_swap(c, v31, v32);
-		cond_swap(c, tmp1, tmp2);
-		float neg = c ? -1.f : 1.f;
-		a12 *= neg;
-		a22 *= neg;
-		a32 *= neg;
-		v12 *= neg;
-		v22 *= neg;
-		v32 *= neg;
-		c = tmp1 < tmp3;
-		cond_swap(c, a11, a13);
-		cond_swap(c, a21, a23);
-		cond_swap(c, a31, a33);
-		cond_swap(c, v11, v13);
-		cond_swap(c, v21, v23);
-		cond_swap(c, v31, v33);
-		cond_swap(c, tmp1, tmp3);
-		neg = c ? -1.f : 1.f;
-		a11 *= neg;
-		a21 *= neg;
-		a31 *= neg;
-		v11 *= neg;
-		v21 *= neg;
-		v31 *= neg;
-		c = tmp2 < tmp3;
-		cond_swap(c, a12, a13);
-		cond_swap(c, a22, a23);
-		cond_swap(c, a32, a33);
-		cond_swap(c, v12, v13);
-		cond_swap(c, v22, v23);
-		cond_swap(c, v32, v33);
-		neg = c ? -1.f : 1.f;
-		a13 *= neg;
-		a23 *= neg;
-		a33 *= neg;
-		v13 *= neg;
-		v23 *= neg;
-		v33 *= neg;
+	MPM_SWAPCOL(n1 < n2, 1, 2, n1, n2, 2)
+	MPM_SWAPCOL(n1 < n3, 1, 3, n1, n3, 1)
+	MPM_SWAPCOL(n2 < n3, 2, 3, n2, n3, 3)
+#undef MPM_SWAPCOL
+#pragma unroll
+	for(int r = 0; r < 3; ++r) {
+		V[r]	 = v1[r];
+		V[3 + r] = v2[r];
+		V[6 + r] = v3[r];
 	}
-	// QR by three Givens rotations (svd.cuh:772-1090)
-	float u11 = 1.f, u12 = 0.f, u13 = 0.f, u21 = 0.f, u22 = 1.f, u23 = 0.f, u31 = 0.f, u32 = 0.f, u33 = 1.f;
-	qr_givens(a11, a21, a11, a12, a13, a21, a22, a23, u11, u21, u31, u12, u22, u32);
-	qr_givens(a11, a31, a11, a12, a13, a31, a32, a33, u11, u21, u31, u13, u23, u33);
-	qr_givens(a22, a32, a21, a22, a23, a31, a32, a33, u12, u22, u32, u13, u23, u33);
-	U[0] = u11;
-	U[1] = u21;
-	U[2] = u31;
-	U[3] = u12;
-	U[4] = u22;
-	U[5] = u32;
-	U[6] = u13;
-	U[7] = u23;
-	U[8] = u33;
-	V[0] = v11;
-	V[1] = v21;
-	V[2] = v31;
-	V[3] = v12;
-	V[4] = v22;
-	V[5] = v32;
-	V[6] = v13;
-	V[7] = v23;
-	V[8] = v33;
-	S[0] = a11;
-	S[1] = a22;
-	S[2] = a33;
+	if(n3 > 1e-6f * n1) {
+		// well conditioned: u_i = b_i / sigma_i
+		const float det = b1[0] * (b2[1] * b3[2] - b2[2] * b3[1]) - b2[0] * (b1[1] * b3[2] - b1[2] * b3[1]) + b3[0] * (b1[1] * b2[2] - b1[2] * b2[1]);
+		const float i1 = rsqrt_newton(n1), i2 = rsqrt_newton(n2);
+		float i3	   = rsqrt_newton(n3);
+		S[0]		   = n1 * i1;
+		S[1]		   = n2 * i2;
+		S[2]		   = n3 * i3;
+		if(det < 0.f) {
+			S[2] = -S[2];
+			i3	 = -i3;
+		}
+#pragma unroll
+		for(int r = 0; r < 3; ++r) {
+			U[r]	 = b1[r] * i1;
+			U[3 + r] = b2[r] * i2;
+			U[6 + r] = b3[r] * i3;
+		}
+	} else {
+		// ill conditioned: the reference's QR by three Givens rotations (svd.cuh:772-1090)
+		float a11 = b1[0], a21 = b1[1], a31 = b1[2], a12 = b2[0], a22 = b2[1], a32 = b2[2], a13 = b3[0], a23 = b3[1], a33 = b3[2];
+		float u11 = 1.f, u12 = 0.f, u13 = 0.f, u21 = 0.f, u22 = 1.f, u23 = 0.f, u31 = 0.f, u32 = 0.f, u33 = 1.f;
+		qr_givens(a11, a21, a11, a12, a13, a21, a22, a23, u11, u21, u31, u12, u22, u32);
+		qr_givens(a11, a31, a11, a12, a13, a31, a32, a33, u11, u21, u31, u13, u23, u33);
+		qr_givens(a22, a32, a21, a22, a23, a31, a32, a33, u12, u22, u32, u13, u23, u33);
+		U[0] = u11;
+		U[1] = u21;
+		U[2] = u31;
+		U[3] = u12;
+		U[4] = u22;
+		U[5] = u32;
+		U[6] = u13;
+		U[7] = u23;
+		U[8] = u33;
+		S[0] = a11;
+		S[1] = a22;
+		S[2] = a33;
+	}
 }
 
 // Material constants passed by value to the kernels (Projects/GMPM/particle_buffer.cuh:141-264)
