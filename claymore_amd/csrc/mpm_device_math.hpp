@@ -173,11 +173,17 @@ MPM_DEV void svd3(const float (&F)[9], float (&U)[9], float (&S)[3], float (&V)[
 	float s32 = F[6] * F[3] + F[7] * F[4] + F[8] * F[5];
 	float s33 = F[6] * F[6] + F[7] * F[7] + F[8] * F[8];
 	float v1[3] = {1.f, 0.f, 0.f}, v2[3] = {0.f, 1.f, 0.f}, v3[3] = {0.f, 0.f, 1.f};
-#pragma unroll
+	// The reference always runs 4 sweeps (svd.cuh:167).  Cyclic Jacobi converges quadratically, so once every
+	// off-diagonal entry of every lane is below 1e-7 of the diagonal a further sweep only rotates by angles whose
+	// effect on U Sigma V^T is below fp32 resolution; the remaining sweeps are skipped for the whole wave then.
+#pragma unroll 1
 	for(int it = 0; it < 4; ++it) {
 		jacobi_conj(s11, s21, s22, s31, s32, s33, v1, v2);
 		jacobi_conj(s22, s32, s33, s21, s31, s11, v2, v3);
 		jacobi_conj(s33, s31, s11, s32, s21, s22, v3, v1);
+		const float off = fmaxf(fmaxf(fabsf(s21), fabsf(s31)), fabsf(s32));
+		const float dia = fminf(fminf(fabsf(s11), fabsf(s22)), fabsf(s33));
+		if(__all(off <= 1e-7f * dia)) break;
 	}
 	// B = F V (svd.cuh:532-588), columns b1 b2 b3
 	float b1[3], b2[3], b3[3];

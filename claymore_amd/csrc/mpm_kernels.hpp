@@ -39,7 +39,9 @@ constexpr int kMaxModels  = 8;
 constexpr int kArenaStrideX = 68; // arena x stride in float4 nodes (64 + 4: keeps every b128 lane group on 16 distinct 16-B slots)
 constexpr int kArenaNodes	= 544;// >= 7*68 + 7*8 + 7 + 1
 constexpr int kSortChunk	= 1024;// advection records sorted per pass (a block with more particles takes several passes)
-constexpr int kSortRounds	= 32;  // particles per cell (per chunk) that get an exact interleaved position; more -> appended behind
+constexpr int kSortRounds	= 24;  // particles per key (per chunk) that get an exact interleaved position; more -> appended behind
+constexpr int kSortKeys		= 216; // sort key = PREDICTED stencil base of the particle in the arena of its block (6^3 values)
+constexpr int kKeyBits		= 8;
 constexpr int kG2PStrideX	= 52;  // G2P arena holds only nodes 1..6 of the 8^3 arena (the gather never touches 0 and 7):
 constexpr int kG2PNodes		= 312; // index (x-1)*52 + (y-1)*8 + (z-1); 52 = 48 + 4 keeps ds_read_b96 lane groups conflict-free
 constexpr int kStay		  = 13; // dir_offset(0,0,0), utility_funcs.hpp:25-27
@@ -224,11 +226,11 @@ __device__ __forceinline__ void p2g_scatter_rmw(float4* __restrict__ node0, cons
 
 // Resolve intra-wave conflicts for one batch of payloads: lanes whose stencil base (key) is unique in the wave
 // scatter immediately; the others retry.  key < 216 (6^3 possible new cells around a block).
-__device__ __forceinline__ void p2g_resolve(float4* __restrict__ arena, int* __restrict__ owner, bool pending, int key, int nodeoff, const P2GPayload& pl, float mass, int lane) {
+__device__ __forceinline__ void p2g_resolve(float4* __restrict__ arena, unsigned char* __restrict__ owner, bool pending, int key, int nodeoff, const P2GPayload& pl, float mass, int lane) {
 	while(__any(pending)) {
-		if(pending) owner[key] = lane;
+		if(pending) owner[key] = (unsigned char) lane;
 		__syncthreads();// single-wave workgroup: orders the LDS write before the read-back (and fences the compiler)
-		const bool win = pending && owner[key] == lane;
+		const bool win = pending && (int) owner[key] == lane;
 		__syncthreads();
 		if(win) p2g_scatter_rmw(arena + nodeoff, pl, mass);
 		pending = pending && !win;
@@ -244,10 +246,11 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 	__shared__ float4 g2p[kG2PNodes];// node velocities {vx,vy,vz,-} of arena nodes 1..6 per axis
 	__shared__ float4 p2g[kArenaNodes];// {mass, momentum} accumulators
 	__shared__ int s_sorted[kSortChunk];// advection records of the current chunk, interleaved by cell
-	__shared__ unsigned long long s_mask[kSortRounds];
-	__shared__ int s_round0[kSortRounds + 1];
-	__shared__ int s_cnt[64];
-	__shared__ int s_owner[216];
+	__shared__ unsigned long long s_mask[kSortRounds][4];// per round: which of the 216 keys still have a k-th particle
+	__shared__ int s_round0[kSortRounds + 1];			  // first sorted position of round k
+	__shared__ unsigned s_wordoff[kSortRounds];			  // packed prefix of the four mask words' popcounts (3 x 8 bit)
+	__shared__ int s_cnt[256 - 32];// 216 keys used
+	__shared__ unsigned char s_owner[216];
 	__shared__ int s_src_binoff[27], s_dst_no[27], s_nb[8];
 
 	const int lane = threadIdx.x;
@@ -294,8 +297,9 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 	const float scale	 = 4.f * cfg.dx_inv;// dx * D^-1 (settings.h:66): A is accumulated in cell units
 	const float mass	 = mv.mc.mass;
 	const int binoff_dst = mv.binoff_dst[b];
-	const int cell_shift = cfg.pid_bits;
-	const int tag_shift	 = cfg.pid_bits + 6;
+	const int key_shift = cfg.pid_bits;
+	const int tag_shift = cfg.pid_bits + kKeyBits;
+	const unsigned rec_mask = (1u << (tag_shift + 5)) - 1u;
 
 	for(int chunk0 = 0; chunk0 < size; chunk0 += kSortChunk) {
 		const int nrec = min(kSortChunk, size - chunk0);
@@ -305,35 +309,50 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 			for(int idx = lane; idx < nrec; idx += 64) s_sorted[idx] = list[chunk0 + idx];
 			__syncthreads();
 		} else {
-		s_cnt[lane] = 0;
+		// The sort key is the stencil base the particle is PREDICTED to have after this step's advection (computed one
+		// step ago from x + v dt, exact for > 99.9 % of the particles), so the 64 lanes of an iteration scatter to 64
+		// distinct stencil bases and the conflict-retry pass below almost never runs.
+#pragma unroll
+		for(int q = 0; q < 4; ++q)
+			if(lane + 64 * q < 224) s_cnt[lane + 64 * q] = 0;
 		__syncthreads();
-		int packed[kSortChunk / 64];
+		unsigned packed[kSortChunk / 64];
 #pragma unroll
 		for(int it = 0; it < kSortChunk / 64; ++it) {
 			const int idx = it * 64 + lane;
-			packed[it]	  = -1;
+			packed[it]	  = 0u;
 			if(idx < nrec) {
-				const int rec = list[chunk0 + idx];
-				const int c	  = (rec >> cell_shift) & 63;
-				const int k	  = atomicAdd(&s_cnt[c], 1);// ds_add_rtn_u32: integer LDS atomics run at full rate
-				packed[it]	  = (rec & 0xFFFFFF) | (min(k, kSortRounds) << 24);
+				const unsigned rec = (unsigned) list[chunk0 + idx] & rec_mask;
+				const int c		   = (rec >> key_shift) & 255;
+				const int k		   = atomicAdd(&s_cnt[c], 1);// ds_add_rtn_u32: integer LDS atomics run at full rate
+				packed[it]		   = rec | ((unsigned) min(k, kSortRounds) << 26);
 			}
 		}
 		__syncthreads();
 		{
-			const int my = s_cnt[lane];
-			int maxc	 = my;
+			int my[4];
+			int maxc = 0;
+#pragma unroll
+			for(int q = 0; q < 4; ++q) {
+				my[q] = lane + 64 * q < 224 ? s_cnt[lane + 64 * q] : 0;
+				maxc  = max(maxc, my[q]);
+			}
 #pragma unroll
 			for(int off = 32; off > 0; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off));
 			maxc	= min(maxc, kSortRounds);
 			int run = 0;
 			for(int k = 0; k < maxc; ++k) {
-				const unsigned long long m = __ballot(my > k);
+				const unsigned long long m0 = __ballot(my[0] > k), m1 = __ballot(my[1] > k), m2 = __ballot(my[2] > k), m3 = __ballot(my[3] > k);
+				const int p0 = __popcll(m0), p1 = p0 + __popcll(m1), p2 = p1 + __popcll(m2);
 				if(lane == 0) {
-					s_mask[k]	= m;
-					s_round0[k] = run;
+					s_mask[k][0] = m0;
+					s_mask[k][1] = m1;
+					s_mask[k][2] = m2;
+					s_mask[k][3] = m3;
+					s_wordoff[k] = (unsigned) p0 << 8 | (unsigned) p1 << 16 | (unsigned) p2 << 24;
+					s_round0[k]	 = run;
 				}
-				run += __popcll(m);
+				run += p2 + __popcll(m3);
 			}
 			if(lane == 0) s_round0[kSortRounds] = run;// overflow records (k >= kSortRounds) go behind the sorted ones
 			s_cnt[lane] = 0;
@@ -341,17 +360,18 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 		__syncthreads();
 #pragma unroll
 		for(int it = 0; it < kSortChunk / 64; ++it) {
-			if(packed[it] != -1) {
-				const int rec = packed[it] & 0xFFFFFF;
-				const int k	  = (unsigned) packed[it] >> 24;
-				const int c	  = (rec >> cell_shift) & 63;
+			if(it * 64 + lane < nrec) {
+				const unsigned rec = packed[it] & rec_mask;
+				const int k		   = packed[it] >> 26;
+				const int c		   = (rec >> key_shift) & 255;
 				int pos;
 				if(k < kSortRounds) {
-					pos = s_round0[k] + __popcll(s_mask[k] & ((1ull << c) - 1ull));
+					const int w = c >> 6;
+					pos			= s_round0[k] + (int) ((s_wordoff[k] >> (8 * w)) & 255u) + __popcll(s_mask[k][w] & ((1ull << (c & 63)) - 1ull));
 				} else {
 					pos = s_round0[kSortRounds] + atomicAdd(&s_cnt[0], 1);
 				}
-				s_sorted[pos] = rec;
+				s_sorted[pos] = (int) rec;
 			}
 		}
 		__syncthreads();
@@ -520,7 +540,15 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 				const bool dir_ok = ((unsigned) (dirv[0] + 1) < 3u) & ((unsigned) (dirv[1] + 1) < 3u) & ((unsigned) (dirv[2] + 1) < 3u);
 				const int ntag	  = dir_ok ? (dirv[0] + 1) * 9 + (dirv[1] + 1) * 3 + dirv[2] + 1 : kStay;
 				const int dno	  = dir_ok ? s_dst_no[ntag] : -1;
-				const int ncell	  = (((nbase[0] - 1) & 3) << 4) | (((nbase[1] - 1) & 3) << 2) | ((nbase[2] - 1) & 3);
+				// sort key for the NEXT step: predicted stencil base after one more advection with the current velocity,
+				// expressed in the arena of the block the particle is in after THIS step (clamped to the 6^3 range)
+				int pkey = 0;
+#pragma unroll
+				for(int d = 0; d < 3; ++d) {
+					const int pb = (int) __builtin_roundf((pos[d] + vel[d] * new_dt) * dx_inv) - 1;
+					const int nk = min(max(((nbase[d] - 1) & 3) + 1 + (pb - nbase[d]), 0), 5);
+					pkey		 = pkey * 6 + nk;
+				}
 				const bool stay	  = dir_ok && ntag == kStay;
 				int slot		  = -1;
 				// wave-aggregated append for the particles that stay in this block (one atomic per wave)
@@ -539,7 +567,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 				} else if(slot >= cfg.ppb) {
 					atomicOr(&status[ST_OVERFLOW], 2);// reference drops beyond 128 per cell (:122-130)
 				} else {
-					mv.list_out[(size_t) dno * cfg.ppb + slot] = (ntag << tag_shift) | (ncell << cell_shift) | pidib;
+					mv.list_out[(size_t) dno * cfg.ppb + slot] = (ntag << tag_shift) | (pkey << key_shift) | pidib;
 				}
 				if(!in_arena) atomicAdd(&status[ST_ARENA], 1);// (:877-885) contribution discarded
 			}
@@ -714,8 +742,8 @@ __global__ __launch_bounds__(256) void fill_bins_kernel(GridCfg cfg, int nch, fl
 			if(nch == 13) dst[12 * kBin] = log_jp0;
 		}
 		const int cx = node_index(xyz[3 * (size_t) pid], cfg.dx_inv) - 2, cy = node_index(xyz[3 * (size_t) pid + 1], cfg.dx_inv) - 2, cz = node_index(xyz[3 * (size_t) pid + 2], cfg.dx_inv) - 2;
-		const int cell = ((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3);
-		list_in[(size_t) b * cfg.ppb + pidib] = (kStay << (cfg.pid_bits + 6)) | (cell << cfg.pid_bits) | pidib;
+		const int key = (((cx & 3) + 1) * 6 + ((cy & 3) + 1)) * 6 + ((cz & 3) + 1);// stencil base in the block's arena (no motion predicted)
+		list_in[(size_t) b * cfg.ppb + pidib] = (kStay << (cfg.pid_bits + kKeyBits)) | (key << cfg.pid_bits) | pidib;
 	}
 }
 // rasterize, mgmpm_kernels.cuh:153-219 (one-time, global atomics)
@@ -756,7 +784,7 @@ __global__ __launch_bounds__(256) void retrieve_kernel(GridCfg cfg, int nch, con
 	for(int pidib = threadIdx.x; pidib < n; pidib += blockDim.x) {
 		const int rec = list[pidib];
 		int ox, oy, oz;
-		dir_components(rec >> (cfg.pid_bits + 6), ox, oy, oz);
+		dir_components(rec >> (cfg.pid_bits + kKeyBits), ox, oy, oz);
 		const int sp	 = rec & (cfg.ppb - 1);
 		const int srcno	 = table_query(cfg, prev_table, kx + ox, ky + oy, kz + oz);
 		const float* src = bins_src + (size_t) (binoff_src[srcno] + (sp >> 6)) * (nch * kBin) + (sp & 63);
