@@ -193,10 +193,13 @@ struct P2GPayload {
 // activates lanes with pairwise distinct stencil bases, so for one stencil offset all lanes touch distinct nodes;
 // (2) a workgroup is a single wave, whose LDS operations execute in program order - the compiler barrier keeps the
 // read-modify-write of offset o ahead of the read of offset o+1, which may hit the node another lane just wrote.
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void p2g_scatter_rmw(float4* __restrict__ node0, const P2GPayload& pl, float mass) {
 	float w[3][3];
 #pragma unroll
 	for(int d = 0; d < 3; ++d) bspline_weight_cells(pl.fd[d], w[d]);
+	// packed fp32 (v_pk_fma_f32) on the naturally paired halves of the float4 node: {m, px} and {py, pz}
+	const v2f c12 = {pl.contrib[7], pl.contrib[8]};
 #pragma unroll
 	for(int i = 0; i < 3; ++i) {
 		const float px = (float) i - pl.fd[0];
@@ -205,19 +208,20 @@ __device__ __forceinline__ void p2g_scatter_rmw(float4* __restrict__ node0, cons
 			const float py	= (float) j - pl.fd[1];
 			const float wij = w[0][i] * w[1][j];
 			const float b0	= pl.mv[0] + pl.contrib[0] * px + pl.contrib[3] * py;
-			const float b1	= pl.mv[1] + pl.contrib[1] * px + pl.contrib[4] * py;
-			const float b2	= pl.mv[2] + pl.contrib[2] * px + pl.contrib[5] * py;
+			v2f b12			= {pl.mv[1] + pl.contrib[1] * px + pl.contrib[4] * py, pl.mv[2] + pl.contrib[2] * px + pl.contrib[5] * py};
 #pragma unroll
 			for(int k = 0; k < 3; ++k) {
 				const float pz = (float) k - pl.fd[2];
 				const float W  = wij * w[2][k];
 				float4* node   = node0 + i * kArenaStrideX + j * 8 + k;
 				float4 acc	   = *node;
-				acc.x += mass * W;
-				acc.y += (b0 + pl.contrib[6] * pz) * W;
-				acc.z += (b1 + pl.contrib[7] * pz) * W;
-				acc.w += (b2 + pl.contrib[8] * pz) * W;
-				*node = acc;
+				v2f m0		   = {mass, b0 + pl.contrib[6] * pz};
+				v2f t12		   = c12 * pz + b12;
+				v2f a01		   = {acc.x, acc.y};
+				v2f a23		   = {acc.z, acc.w};
+				a01			   = m0 * W + a01;
+				a23			   = t12 * W + a23;
+				*node		   = make_float4(a01.x, a01.y, a23.x, a23.y);
 				__asm__ volatile("" ::: "memory");
 			}
 		}

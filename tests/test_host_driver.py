@@ -73,3 +73,22 @@ def test_gmpm_executable_matches_engine(tmp_path):
             idx, _ = match(a.astype(np.float64), b.astype(np.float64))
             assert np.abs(a - b[idx]).max() < 1e-6
     eng.close()
+
+
+@pytest.mark.gpu
+def test_mgsp_executable_same_device(tmp_path):
+    """The in-process multi-context driver (reference structure: one process, N devices) on one GPU: two lattice boxes
+    one cell apart share halo blocks; particle counts are conserved and the centroids fall with MGSP's gravity."""
+    import __graft_entry__ as g
+    g.build_host()
+    out = subprocess.check_output([os.path.join(HOST, "mgsp"), "--devices", "2", "--same-device", "--bits", "7", "--frames", "2",
+                                   "--fps", "100", "--out", str(tmp_path)], text=True)
+    assert out.count("total number of particles") == 4
+    for d in (0, 1):
+        p0 = read_bgeo(tmp_path / f"model_dev[{d}]_frame[0].bgeo")
+        p2 = read_bgeo(tmp_path / f"model_dev[{d}]_frame[2].bgeo")
+        assert p0.shape == p2.shape and p0.shape[0] == 27 ** 3 * 8
+        t = 2 / 100.0
+        dy = p2[:, 1].astype(np.float64).mean() - p0[:, 1].astype(np.float64).mean()
+        assert abs(dy - (-0.5 * 4.9 * t * t)) < 0.03 * 0.5 * 4.9 * t * t    # free fall under -9.8 * 0.5 (settings.h:108)
+        assert abs(p2[:, 0].mean() - p0[:, 0].mean()) < 1e-4
