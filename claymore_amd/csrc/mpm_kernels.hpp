@@ -228,6 +228,119 @@ __device__ __forceinline__ void p2g_scatter_rmw(float4* __restrict__ node0, cons
 	}
 }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// Tensor-product B-spline gather of one particle per lane (:801-835): vel = sum W v, A = sum W v (x_i - x_p)^T in cell
+// units.  With FUSED the 27 read-modify-write steps of the PREVIOUS iteration's scatter are issued in between (3 per
+// (i,j) group): each step is an LDS round trip whose latency is otherwise exposed (the steps are ordered - see
+// p2g_scatter_rmw - so they cannot overlap each other), while the gather is pure VALU work plus independent LDS reads.
+// The arena accesses are volatile vector accesses: the compiler keeps their order, everything else floats around them.
+template<bool FUSED>
+__device__ __forceinline__ void gather_and_scatter(const float4* __restrict__ gbase, const float (&w)[3][3], const float (&fd)[3], float (&vel)[3], float (&A)[9], float4* pnode0, const P2GPayload& pp, float mass) {
+	float wp[3][3];// w * (node - particle) per axis
+#pragma unroll
+	for(int d = 0; d < 3; ++d) {
+#pragma unroll
+		for(int t = 0; t < 3; ++t) wp[d][t] = w[d][t] * ((float) t - fd[d]);
+	}
+	float pw[3][3];
+	v2f c12 = {0.f, 0.f};
+	if constexpr(FUSED) {
+#pragma unroll
+		for(int d = 0; d < 3; ++d) bspline_weight_cells(pp.fd[d], pw[d]);
+		c12 = (v2f) {pp.contrib[7], pp.contrib[8]};
+	}
+	if constexpr(FUSED) {
+		// A compiler barrier after every step pins the LDS operations in program order: {gather read k, scatter read k}
+		// -> ~14 VALU of gather + scatter arithmetic that need only the gather read -> add, scatter write k.  The
+		// arithmetic therefore sits in the shadow of the scatter's LDS round trip instead of in front of it.
+		// (volatile accesses would do the same but defeat address-space inference: they become flat_load/flat_store.)
+		float4* pn		 = pnode0;
+		const float4* gv = gbase;
+#pragma unroll
+		for(int i = 0; i < 3; ++i) {
+			float u0[3] = {0.f, 0.f, 0.f}, uy[3] = {0.f, 0.f, 0.f}, uz[3] = {0.f, 0.f, 0.f};
+			const float ppx = (float) i - pp.fd[0];
+#pragma unroll
+			for(int j = 0; j < 3; ++j) {
+				const float ppy	 = (float) j - pp.fd[1];
+				const float pwij = pw[0][i] * pw[1][j];
+				const float b0	 = pp.mv[0] + pp.contrib[0] * ppx + pp.contrib[3] * ppy;
+				const v2f b12	 = {pp.mv[1] + pp.contrib[1] * ppx + pp.contrib[4] * ppy, pp.mv[2] + pp.contrib[2] * ppx + pp.contrib[5] * ppy};
+				float t0[3] = {0.f, 0.f, 0.f}, t1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+				for(int k = 0; k < 3; ++k) {
+					const float4 v	 = gv[i * kG2PStrideX + j * 8 + k];
+					const int o		 = i * kArenaStrideX + j * 8 + k;
+					const float4 acc = pn[o];
+					t0[0] += w[2][k] * v.x;
+					t0[1] += w[2][k] * v.y;
+					t0[2] += w[2][k] * v.z;
+					t1[0] += wp[2][k] * v.x;
+					t1[1] += wp[2][k] * v.y;
+					t1[2] += wp[2][k] * v.z;
+					const float ppz = (float) k - pp.fd[2];
+					const float W	= pwij * pw[2][k];
+					const v2f m0	= {mass, b0 + pp.contrib[6] * ppz};
+					const v2f t12	= c12 * ppz + b12;
+					v2f a01			= {acc.x, acc.y};
+					v2f a23			= {acc.z, acc.w};
+					a01				= m0 * W + a01;
+					a23				= t12 * W + a23;
+					pn[o]			= make_float4(a01.x, a01.y, a23.x, a23.y);
+					__asm__ volatile("" ::: "memory");
+				}
+#pragma unroll
+				for(int d = 0; d < 3; ++d) {
+					u0[d] += w[1][j] * t0[d];
+					uy[d] += wp[1][j] * t0[d];
+					uz[d] += w[1][j] * t1[d];
+				}
+			}
+#pragma unroll
+			for(int d = 0; d < 3; ++d) {
+				vel[d] += w[0][i] * u0[d];
+				A[d] += wp[0][i] * u0[d];
+				A[3 + d] += w[0][i] * uy[d];
+				A[6 + d] += w[0][i] * uz[d];
+			}
+		}
+	} else {
+#pragma unroll
+		for(int i = 0; i < 3; ++i) {
+			float u0[3] = {0.f, 0.f, 0.f}, uy[3] = {0.f, 0.f, 0.f}, uz[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+			for(int j = 0; j < 3; ++j) {
+				const float4 v0 = gbase[i * kG2PStrideX + j * 8 + 0];
+				const float4 v1 = gbase[i * kG2PStrideX + j * 8 + 1];
+				const float4 v2 = gbase[i * kG2PStrideX + j * 8 + 2];
+				const float t0x = w[2][0] * v0.x + w[2][1] * v1.x + w[2][2] * v2.x;
+				const float t0y = w[2][0] * v0.y + w[2][1] * v1.y + w[2][2] * v2.y;
+				const float t0z = w[2][0] * v0.z + w[2][1] * v1.z + w[2][2] * v2.z;
+				const float t1x = wp[2][0] * v0.x + wp[2][1] * v1.x + wp[2][2] * v2.x;
+				const float t1y = wp[2][0] * v0.y + wp[2][1] * v1.y + wp[2][2] * v2.y;
+				const float t1z = wp[2][0] * v0.z + wp[2][1] * v1.z + wp[2][2] * v2.z;
+				u0[0] += w[1][j] * t0x;
+				u0[1] += w[1][j] * t0y;
+				u0[2] += w[1][j] * t0z;
+				uy[0] += wp[1][j] * t0x;
+				uy[1] += wp[1][j] * t0y;
+				uy[2] += wp[1][j] * t0z;
+				uz[0] += w[1][j] * t1x;
+				uz[1] += w[1][j] * t1y;
+				uz[2] += w[1][j] * t1z;
+			}
+#pragma unroll
+			for(int d = 0; d < 3; ++d) {
+				vel[d] += w[0][i] * u0[d];
+				A[d] += wp[0][i] * u0[d];
+				A[3 + d] += w[0][i] * uy[d];
+				A[6 + d] += w[0][i] * uz[d];
+			}
+		}
+	}
+}
+
 // Resolve intra-wave conflicts for one batch of payloads: lanes whose stencil base (key) is unique in the wave
 // scatter immediately; the others retry.  key < 216 (6^3 possible new cells around a block).
 __device__ __forceinline__ void p2g_resolve(float4* __restrict__ arena, unsigned char* __restrict__ owner, bool pending, int key, int nodeoff, const P2GPayload& pl, float mass, int lane) {
@@ -386,6 +499,10 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 		float nx_pos[3], nx_st[10];
 		int nx_tag = 0;
 		auto fetch = [&](int idx0) {
+#pragma unroll
+			for(int d = 0; d < 3; ++d) nx_pos[d] = ((float) (4 * (d == 0 ? kx : (d == 1 ? ky : kz))) + 4.5f) * cfg.dx;// idle lanes: a point inside the block
+#pragma unroll
+			for(int d = 0; d < 10; ++d) nx_st[d] = (d == 0 || d == 4 || d == 8) ? 1.f : 0.f;
 			if(idx0 + lane < nrec) {
 				const int rec	 = s_sorted[idx0 + lane];
 				nx_tag			 = rec >> tag_shift;
@@ -405,80 +522,61 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 			}
 		};
 		fetch(0);
+		// Software pipeline: the scatter of iteration i-1 (an ordered chain of 27 LDS round trips) is issued inside
+		// the gather of iteration i; `pv` is the payload in flight.
+		P2GPayload pv;
+		int pv_key = 0, pv_off = 0;
+		bool pv_in = false, have_prev = false;
 		for(int idx0 = 0; idx0 < nrec; idx0 += 64) {
 			const bool active = idx0 + lane < nrec;
 			const int pidib	  = chunk0 + idx0 + lane;// slot in the destination bins == position in the sorted order
-			P2GPayload pl;
-			int key = 0, nodeoff = 0;
-			bool in_arena = false;
 			// ---- advection record -> source bin (:747-768): data was requested one iteration ago
 			float pos[3] = {nx_pos[0], nx_pos[1], nx_pos[2]};
 			float st[10];// J, or F[9] (+ logJp)
 #pragma unroll
 			for(int d = 0; d < 10; ++d) st[d] = nx_st[d];
 			fetch(idx0 + 64);
+			// ---- stencil base + weights (:774-797) for ALL lanes (idle lanes of a last partial iteration carry a dummy
+			//      position inside the block); offsets in cell units (exact: dx is a power of two)
+			int base[3], arena[3];
+			float fd[3], w[3][3];
+#pragma unroll
+			for(int d = 0; d < 3; ++d) {
+				const float p = pos[d] * dx_inv;
+				base[d]		  = (int) __builtin_roundf(p) - 1;
+				fd[d]		  = p - (float) base[d];
+				bspline_weight_cells(fd[d], w[d]);
+				arena[d] = ((base[d] - 1) & 3) + 1;
+			}
+			float vel[3] = {0.f, 0.f, 0.f};
+			float A[9]	 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+			const float4* gbase = g2p + (arena[0] - 1) * kG2PStrideX + (arena[1] - 1) * 8 + (arena[2] - 1);
+			// ---- claim the stencil bases of the payload in flight; fuse its scatter into this gather if nobody collides
+			bool fused = false;
+			if constexpr(!(ABL & 1)) {
+				if(have_prev) {
+					if(pv_in) s_owner[pv_key] = (unsigned char) lane;
+					__syncthreads();
+					const bool win = pv_in && (int) s_owner[pv_key] == lane;
+					__syncthreads();
+					fused = __all(win);
+					if(!fused) p2g_resolve(p2g, s_owner, pv_in, pv_key, pv_off, pv, mass, lane);
+				}
+			}
+			if constexpr(ABL & 4) {
+				const float4 v = gbase[0];
+				vel[0] = v.x * w[0][0]; vel[1] = v.y * w[1][1]; vel[2] = v.z * w[2][2];
+				A[0] = v.x * fd[0]; A[4] = v.y * fd[1]; A[8] = v.z * fd[2];
+				if(fused) p2g_scatter_rmw(p2g + pv_off, pv, mass);
+			} else if(fused) {
+				gather_and_scatter<true>(gbase, w, fd, vel, A, p2g + pv_off, pv, mass);
+			} else {
+				gather_and_scatter<false>(gbase, w, fd, vel, A, p2g, pv, mass);
+			}
+			P2GPayload pl;
+			int key = 0, nodeoff = 0;
+			bool in_arena = false;
 			if(active) {
-				// ---- stencil base + weights (:774-797); offsets in cell units (exact: dx is a power of two)
-				int base[3], arena[3];
-				float fd[3], w[3][3];
-#pragma unroll
-				for(int d = 0; d < 3; ++d) {
-					const float p = pos[d] * dx_inv;
-					base[d]		  = (int) __builtin_roundf(p) - 1;
-					fd[d]		  = p - (float) base[d];
-					bspline_weight_cells(fd[d], w[d]);
-					arena[d] = ((base[d] - 1) & 3) + 1;
-				}
-				// ---- G2P gather (:801-835): vel = sum W v, A = sum W v (x_i - x_p)^T   [A in cell units]
-				float vel[3] = {0.f, 0.f, 0.f};
-				float A[9]	 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-				const float4* gbase = g2p + (arena[0] - 1) * kG2PStrideX + (arena[1] - 1) * 8 + (arena[2] - 1);
-				if constexpr(ABL & 4) {
-					const float4 v = gbase[0];
-					vel[0] = v.x * w[0][0]; vel[1] = v.y * w[1][1]; vel[2] = v.z * w[2][2];
-					A[0] = v.x * fd[0]; A[4] = v.y * fd[1]; A[8] = v.z * fd[2];
-				} else {
-					// tensor-product evaluation: reduce along z, then y, then x (fewer multiplies than 27 x 16; the
-					// summation order differs from the reference's node loop by rounding only)
-					float wp[3][3];// w * (node - particle) per axis
-#pragma unroll
-					for(int d = 0; d < 3; ++d) {
-#pragma unroll
-						for(int t = 0; t < 3; ++t) wp[d][t] = w[d][t] * ((float) t - fd[d]);
-					}
-#pragma unroll
-					for(int i = 0; i < 3; ++i) {
-						float u0[3] = {0.f, 0.f, 0.f}, uy[3] = {0.f, 0.f, 0.f}, uz[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-						for(int j = 0; j < 3; ++j) {
-							const float4 v0 = gbase[i * kG2PStrideX + j * 8 + 0];
-							const float4 v1 = gbase[i * kG2PStrideX + j * 8 + 1];
-							const float4 v2 = gbase[i * kG2PStrideX + j * 8 + 2];
-							const float t0x = w[2][0] * v0.x + w[2][1] * v1.x + w[2][2] * v2.x;
-							const float t0y = w[2][0] * v0.y + w[2][1] * v1.y + w[2][2] * v2.y;
-							const float t0z = w[2][0] * v0.z + w[2][1] * v1.z + w[2][2] * v2.z;
-							const float t1x = wp[2][0] * v0.x + wp[2][1] * v1.x + wp[2][2] * v2.x;
-							const float t1y = wp[2][0] * v0.y + wp[2][1] * v1.y + wp[2][2] * v2.y;
-							const float t1z = wp[2][0] * v0.z + wp[2][1] * v1.z + wp[2][2] * v2.z;
-							u0[0] += w[1][j] * t0x;
-							u0[1] += w[1][j] * t0y;
-							u0[2] += w[1][j] * t0z;
-							uy[0] += wp[1][j] * t0x;
-							uy[1] += wp[1][j] * t0y;
-							uy[2] += wp[1][j] * t0z;
-							uz[0] += w[1][j] * t1x;
-							uz[1] += w[1][j] * t1y;
-							uz[2] += w[1][j] * t1z;
-						}
-#pragma unroll
-						for(int d = 0; d < 3; ++d) {
-							vel[d] += w[0][i] * u0[d];
-							A[d] += wp[0][i] * u0[d];
-							A[3 + d] += w[0][i] * uy[d];
-							A[6 + d] += w[0][i] * uz[d];
-						}
-					}
-				}
 				// ---- advect (:838)
 #pragma unroll
 				for(int d = 0; d < 3; ++d) pos[d] += vel[d] * dt;
@@ -575,15 +673,23 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 				}
 				if(!in_arena) atomicAdd(&status[ST_ARENA], 1);// (:877-885) contribution discarded
 			}
-			// ---- P2G scatter into the LDS arena (:887-905), conflict-free read-modify-write
+			// ---- hand the payload to the next iteration's fused gather/scatter (:887-905)
 			if constexpr(ABL & 1) {
 #pragma unroll
 				for(int d = 0; d < 9; ++d) __asm__ volatile("" ::"v"(pl.contrib[d]));
 #pragma unroll
 				for(int d = 0; d < 3; ++d) __asm__ volatile("" ::"v"(pl.fd[d]), "v"(pl.mv[d]));
 				__asm__ volatile("" ::"v"(key), "v"(nodeoff));
-			} else
-				p2g_resolve(p2g, s_owner, in_arena, in_arena ? key : 0, in_arena ? nodeoff : 0, pl, mass, lane);
+			}
+			pv		  = pl;
+			pv_key	  = in_arena ? key : 0;
+			pv_off	  = in_arena ? nodeoff : 0;
+			pv_in	  = in_arena;
+			have_prev = true;
+		}
+		// drain the pipeline: scatter of the chunk's last iteration
+		if constexpr(!(ABL & 1)) {
+			if(have_prev) p2g_resolve(p2g, s_owner, pv_in, pv_key, pv_off, pv, mass, lane);
 		}
 		__syncthreads();
 	}
