@@ -411,7 +411,7 @@ int mpm_initial_setup(mpm_ctx* ctx) {
 static int launch_grid_update(mpm_ctx* ctx, float dt) {
 	hipStream_t s = ctx->s_compute;
 	HIP_TRY(hipMemsetAsync(ctx->d_maxvel, 0, sizeof(unsigned), s));
-	if(ctx->nbc) grid_update_kernel<<<cdiv(ctx->nbc, 4), 256, 0, s>>>(ctx->g, ctx->nbc, ctx->grid[0], ctx->part[ctx->rollid].keys, dt, ctx->d_maxvel);
+	if(ctx->nbc) grid_update_kernel<<<cdiv(ctx->nbc, 16), 256, 0, s>>>(ctx->g, ctx->nbc, ctx->grid[0], ctx->part[ctx->rollid].keys, dt, ctx->d_maxvel);
 	return MPM_OK;
 }
 

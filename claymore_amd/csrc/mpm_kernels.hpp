@@ -105,35 +105,46 @@ __device__ __forceinline__ int wave_append(int* counter, bool pred) {
 // (update_grid_velocity_query_max, mgmpm_kernels.cuh:325-420)
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void grid_update_kernel(GridCfg cfg, int nblocks, float* __restrict__ grid, const int* __restrict__ keys, float dt, unsigned* __restrict__ max_vel_bits) {
-	const int lane	  = threadIdx.x & 63;
-	const int blockno = blockIdx.x * 4 + (threadIdx.x >> 6);
+	// 16 lanes per grid block, 4 cells (one float4) per lane and channel: 16-B accesses, 4 blocks per wave
+	const int sub	  = threadIdx.x & 15;
+	const int blockno = (blockIdx.x * 256 + threadIdx.x) >> 4;
 	float vel_sqr	  = 0.f;
 	if(blockno < nblocks) {
 		const int kx = keys[3 * blockno], ky = keys[3 * blockno + 1], kz = keys[3 * blockno + 2];
 		const bool wx = kx < cfg.boundary || kx >= cfg.G - cfg.boundary;
 		const bool wy = ky < cfg.boundary || ky >= cfg.G - cfg.boundary;
 		const bool wz = kz < cfg.boundary || kz >= cfg.G - cfg.boundary;
-		float* g		 = grid + (size_t) blockno * 256;
-		const float mass = g[lane];
-		if(mass > 0.0f) {
-			const float mass_inv = 1.f / mass;
-			float v0 = g[64 + lane], v1 = g[128 + lane], v2 = g[192 + lane];
-			v0 = wx ? 0.0f : v0 * mass_inv;
-			v1 = wy ? 0.0f : v1 * mass_inv;
-			v1 += cfg.gravity * dt;
-			v2			  = wz ? 0.0f : v2 * mass_inv;
-			g[64 + lane]  = v0;
-			g[128 + lane] = v1;
-			g[192 + lane] = v2;
-			vel_sqr		  = v0 * v0 + v1 * v1 + v2 * v2;
-		}
-		if(vel_sqr != vel_sqr) vel_sqr = __builtin_inff();// NaN -> inf signals failure (:385-388)
+		float4* g	   = reinterpret_cast<float4*>(grid + (size_t) blockno * 256) + sub;
+		const float4 m = g[0];
+		float4 p0 = g[16], p1 = g[32], p2 = g[48];
+		const float gdt = cfg.gravity * dt;
+#define MPM_CELL(c)                                                                 \
+	if(m.c > 0.0f) {                                                                \
+		const float mass_inv = 1.f / m.c;                                           \
+		const float v0		 = wx ? 0.0f : p0.c * mass_inv;                         \
+		const float v1		 = (wy ? 0.0f : p1.c * mass_inv) + gdt;                 \
+		const float v2		 = wz ? 0.0f : p2.c * mass_inv;                         \
+		p0.c				 = v0;                                                  \
+		p1.c				 = v1;                                                  \
+		p2.c				 = v2;                                                  \
+		float q				 = v0 * v0 + v1 * v1 + v2 * v2;                         \
+		if(q != q) q = __builtin_inff(); /* NaN -> inf signals failure (:385-388) */ \
+		vel_sqr = fmaxf(vel_sqr, q);                                                \
+	}
+		MPM_CELL(x)
+		MPM_CELL(y)
+		MPM_CELL(z)
+		MPM_CELL(w)
+#undef MPM_CELL
+		g[16] = p0;
+		g[32] = p1;
+		g[48] = p2;
 	}
 #pragma unroll
 	for(int off = 32; off > 0; off >>= 1) vel_sqr = fmaxf(vel_sqr, __shfl_xor(vel_sqr, off));
 	// non-negative floats order as uints.  One same-address atomic per wave would serialise in L2 (90 k waves = 1 ms):
 	// the running maximum only grows, so a plain (possibly stale) read filters almost all of them out.
-	if(lane == 0 && vel_sqr > 0.f) {
+	if((threadIdx.x & 63) == 0 && vel_sqr > 0.f) {
 		const unsigned bits = __float_as_uint(vel_sqr);
 		if(bits > __hip_atomic_load(max_vel_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_vel_bits, bits);
 	}
