@@ -99,7 +99,11 @@ def fluid_dam(bits=10, size_cells=(256, 192, 256), min_corner=(12, 12, 12)):
 
 def split_slabs(xyz, parts, axis=0):
     """Static particle partition of MGSP: equal-count slabs of the initial lattice along `axis`."""
-    order = np.argsort(xyz[:, axis], kind="stable")
+    col = xyz[:, axis]
+    if col.size < 2 or bool(np.all(col[1:] >= col[:-1])):  # the lattice samplers emit particles sorted along x
+        bounds = np.linspace(0, xyz.shape[0], parts + 1).astype(np.int64)
+        return [np.ascontiguousarray(xyz[bounds[i]:bounds[i + 1]]) for i in range(parts)]
+    order = np.argsort(col, kind="stable")
     return [np.ascontiguousarray(xyz[idx]) for idx in np.array_split(order, parts)]
 
 

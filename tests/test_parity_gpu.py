@@ -206,3 +206,62 @@ def test_capacity_overflow_reports_error():
     with pytest.raises(Exception):
         eng.initial_setup()
     eng.close()
+
+
+def _dense_cube_scene(ppc_axis=3, cells=8, bits=6, material=_ffi.FIXED_COROTATED):
+    """A cube with ppc_axis^3 particles per cell: 27 per cell -> 1728 per block, i.e. more than one 1024-record sort
+    chunk and more than kSortRounds (24) particles per sort key - the ragged / overflow paths of the in-LDS sort."""
+    dx = 1.0 / (1 << bits)
+    lo = (1 << bits) // 2 - cells // 2
+    sub = (np.arange(ppc_axis) + 0.5) / ppc_axis - 0.5
+    ax = (np.arange(lo, lo + cells)[:, None] + sub[None, :]).reshape(-1) * dx
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    xyz = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1).astype(np.float32)
+    vol = float(np.float32(dx ** 3 / ppc_axis ** 3))
+    return {"name": "dense_cube", "bits": bits, "dt": 1e-4, "config": {"max_ppc": 32},
+            "models": [{"material": material, "xyz": xyz, "v0": (0.3, -0.2, 0.1), "params": {"volume": vol, "youngs_modulus": 5e3, "poisson_ratio": 0.4, "rho": 1e3}}]}
+
+
+def test_dense_blocks_multichunk_parity():
+    sc = _dense_cube_scene()
+    res = run_pair(sc, 25, 1e-4)
+    err = match_and_compare(res)
+    assert err["n"] == 8 ** 3 * 27
+    assert err["pos_rel"] < POS_TOL, err
+
+
+def test_reference_capacity_max_ppc_128_parity():
+    """The reference's own capacity (128 particles per cell -> 8192 per block, 13-bit slots in the advection record)."""
+    sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=1.0, speed=1.5)
+    sc["config"]["max_ppc"] = 128
+    res = run_pair(sc, 30, 1e-4)
+    err = match_and_compare(res)
+    assert err["pos_rel"] < POS_TOL, err
+
+
+def test_fast_flow_many_cell_changes_parity():
+    """~25 % of the particles change their stencil base every substep (|v| dt = 0.25 dx): exercises the predicted sort
+    key, the conflict/retry path of the scatter and cross-block advection in every step."""
+    sc = scenes.two_spheres(bits=6, radius_cells=4.0, gap_cells=24.0, speed=4.0)
+    dx = 1.0 / 64
+    res = run_pair(sc, 40, 0.25 * dx / 4.0)
+    err = match_and_compare(res)
+    assert err["pos_rel"] < POS_TOL, err
+
+
+def test_particle_outside_domain_is_rejected():
+    sc = scenes.two_spheres(bits=6, radius_cells=4.0, gap_cells=3.0)
+    sc["models"][0]["xyz"] = sc["models"][0]["xyz"].copy()
+    sc["models"][0]["xyz"][0] = (1.5, 0.5, 0.5)
+    eng = build_engine(sc)
+    with pytest.raises(Exception):
+        eng.initial_setup()
+    eng.close()
+
+
+def test_empty_context_is_rejected():
+    from claymore_amd.engine import Engine
+    eng = Engine(domain_bits=6)
+    with pytest.raises(Exception):
+        eng.initial_setup()
+    eng.close()
