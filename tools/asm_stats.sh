@@ -4,7 +4,7 @@ set -e
 MAT=${1:-2}; shift || true
 D=$(mktemp -d); trap 'rm -rf $D' EXIT
 cd "$(dirname "$0")/../claymore_amd/csrc"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -Wno-unused-value "$@" -save-temps=obj -o $D/x.so claymore_hip.hip 2>/dev/null
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -fno-slp-vectorize -Wno-unused-value "$@" -save-temps=obj -o $D/x.so claymore_hip.hip 2>/dev/null
 S=$D/claymore_hip-hip-amdgcn-amd-amdhsa-gfx950.s
 awk "/^_ZN3mpm12g2p2g_kernelILi${MAT}ELi0E/,/\.end_amdhsa_kernel/" $S > $D/k.s
 [ -n "$KEEP" ] && cp $D/k.s $KEEP
