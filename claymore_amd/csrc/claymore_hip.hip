@@ -224,6 +224,18 @@ void mpm_destroy(mpm_ctx* ctx) {
 	if(!ctx) return;
 	hipSetDevice(ctx->device);
 	hipDeviceSynchronize();
+	if(ctx->ablate & 32) {// phase timing of the profiling build (see g_prof in mpm_kernels.hpp)
+		std::vector<unsigned long long> rows(1024 * 16);
+		unsigned long long h[16] = {};
+		if(hipMemcpyFromSymbol(rows.data(), HIP_SYMBOL(mpm::g_prof), rows.size() * sizeof(unsigned long long)) == hipSuccess) {
+			for(int r = 0; r < 1024; ++r)
+				for(int i = 0; i < 16; ++i) h[i] += rows[r * 16 + i];
+			static const char* nm[9] = {"sort", "wait_prefetch", "claim", "gather+scatter", "stress+stores", "rebucket", "prologue", "epilogue", "iterations"};
+			unsigned long long tot = 0;
+			for(int i = 0; i < 8; ++i) tot += h[i];
+			for(int i = 0; i < 9; ++i) fprintf(stderr, "[g2p2g prof] %-16s %14llu  %5.1f %%  %8.0f cycles/iteration\n", nm[i], h[i], i < 8 ? 100.0 * h[i] / (double) tot : 0.0, h[8] ? (double) h[i] / (double) h[8] : 0.0);
+		}
+	}
 	for(int i = 0; i < 2; ++i) {
 		hipFree(ctx->part[i].table);
 		hipFree(ctx->part[i].keys);
@@ -473,6 +485,7 @@ static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, in
 				MPM_ABL(3)
 				MPM_ABL(7)
 				MPM_ABL(15)
+				MPM_ABL(32)
 #undef MPM_ABL
 				default: g2p2g_kernel<2><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_table, cur_keys, prev_table, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
 			}

@@ -365,6 +365,18 @@ __device__ __forceinline__ void p2g_resolve(float4* __restrict__ arena, unsigned
 	}
 }
 
+// Phase timing (ABL & 32, profiling builds only): wall cycles (s_memtime) that wave 0..n spend in each part of the
+// iteration, summed over all waves.  [0] sort, [1] wait for prefetched particle data, [2] claim, [3] gather+scatter,
+// [4] F update + stress + particle stores, [5] re-bucket / list append, [6] prologue, [7] epilogue, [8] iterations.
+__device__ unsigned long long g_prof[1024][16];// spread over 1024 rows: same-address atomics serialise
+#define MPM_TICK(slot) \
+	if constexpr(ABL & 32) { \
+		__asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+		const unsigned long long t_now = __builtin_readcyclecounter(); \
+		t_acc[slot] += t_now - t_last; \
+		t_last = t_now; \
+	}
+
 // ABL: ablation mask for profiling builds (0 in production): 1 skip the P2G scatter, 2 skip the stress (SVD),
 // 4 skip the G2P gather, 8 skip the interleave sort, 16 skip the particle stores.  Values are kept live with
 // empty asm statements so that the compiler cannot delete upstream work.
@@ -385,6 +397,9 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 	const int b	   = block_list ? block_list[blockIdx.x] : (int) blockIdx.x;
 	const int size = mv.size[b];
 	if(size == 0) return;// (:692-697)
+	unsigned long long t_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long t_last	= 0;
+	if constexpr(ABL & 32) t_last = __builtin_readcyclecounter();
 	const int kx = cur_keys[3 * b], ky = cur_keys[3 * b + 1], kz = cur_keys[3 * b + 2];
 
 	if(lane < 27) {
@@ -429,6 +444,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 	const int tag_shift = cfg.pid_bits + kKeyBits;
 	const unsigned rec_mask = (1u << (tag_shift + 5)) - 1u;
 
+	MPM_TICK(6)
 	for(int chunk0 = 0; chunk0 < size; chunk0 += kSortChunk) {
 		const int nrec = min(kSortChunk, size - chunk0);
 		// ---- counting sort of the chunk's records into "k-th particle of every cell" order, so that the 64 lanes
@@ -505,34 +521,43 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 		__syncthreads();
 		}
 
-		// particle data of the NEXT iteration is requested before the current one is computed (software prefetch:
-		// the gather loads have ~2 us of HBM latency and only two waves share a SIMD)
-		float nx_pos[3], nx_st[10];
-		int nx_tag = 0;
-		auto fetch = [&](int idx0) {
+		// Software prefetch: the particle data of iteration i+1 is requested at the top of iteration i (HBM latency under
+		// load is 2-4 us and only two waves share a SIMD).  Two details keep the compiler's s_waitcnt insertion from
+		// turning this into a wait for everything (it only counts memory operations that are issued unconditionally):
+		// the loads are unconditional - lanes past the end of the chunk re-read its last record - and the wait for the
+		// data is forced at the END of iteration i (`touch`), in the same straight-line code as the 13 particle stores,
+		// where it is an exact `vmcnt(13)`; at the loop header it would be `vmcnt(0)`, i.e. include the stores'
+		// acknowledgements and the list-append atomics.
+		struct Prefetch {
+			float pos[3], st[10];
+		};
+		auto fetch = [&](int idx0, Prefetch& f) {
+			const int rec	 = s_sorted[min(idx0 + lane, nrec - 1)];
+			const int tag	 = rec >> tag_shift;
+			const int sp	 = rec & (cfg.ppb - 1);
+			const int sbin	 = s_src_binoff[tag] + (sp >> 6);
+			const float* src = mv.bins_src + (size_t) sbin * (NCH * kBin) + (sp & 63);
+			f.pos[0]		 = src[0];
+			f.pos[1]		 = src[kBin];
+			f.pos[2]		 = src[2 * kBin];
+			if constexpr(MAT == 0) {
+				f.st[0] = src[3 * kBin];
+			} else {
 #pragma unroll
-			for(int d = 0; d < 3; ++d) nx_pos[d] = ((float) (4 * (d == 0 ? kx : (d == 1 ? ky : kz))) + 4.5f) * cfg.dx;// idle lanes: a point inside the block
-#pragma unroll
-			for(int d = 0; d < 10; ++d) nx_st[d] = (d == 0 || d == 4 || d == 8) ? 1.f : 0.f;
-			if(idx0 + lane < nrec) {
-				const int rec	 = s_sorted[idx0 + lane];
-				nx_tag			 = rec >> tag_shift;
-				const int sp	 = rec & (cfg.ppb - 1);
-				const int sbin	 = s_src_binoff[nx_tag] + (sp >> 6);
-				const float* src = mv.bins_src + (size_t) sbin * (NCH * kBin) + (sp & 63);
-				nx_pos[0]		 = src[0];
-				nx_pos[1]		 = src[kBin];
-				nx_pos[2]		 = src[2 * kBin];
-				if constexpr(MAT == 0) {
-					nx_st[0] = src[3 * kBin];
-				} else {
-#pragma unroll
-					for(int d = 0; d < 9; ++d) nx_st[d] = src[(3 + d) * kBin];
-					if constexpr(NCH == 13) nx_st[9] = src[12 * kBin];
-				}
+				for(int d = 0; d < 9; ++d) f.st[d] = src[(3 + d) * kBin];
+				if constexpr(NCH == 13) f.st[9] = src[12 * kBin];
 			}
 		};
-		fetch(0);
+		auto touch = [&](Prefetch& f) {
+#pragma unroll
+			for(int d = 0; d < 3; ++d) __asm__ volatile("" : "+v"(f.pos[d]));
+#pragma unroll
+			for(int d = 0; d < (MAT == 0 ? 1 : (NCH == 13 ? 10 : 9)); ++d) __asm__ volatile("" : "+v"(f.st[d]));
+		};
+		Prefetch pf;
+		fetch(0, pf);
+		touch(pf);
+		MPM_TICK(0)
 		// Software pipeline: the scatter of iteration i-1 (an ordered chain of 27 LDS round trips) is issued inside
 		// the gather of iteration i; `pv` is the payload in flight.
 		P2GPayload pv;
@@ -542,11 +567,19 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 			const bool active = idx0 + lane < nrec;
 			const int pidib	  = chunk0 + idx0 + lane;// slot in the destination bins == position in the sorted order
 			// ---- advection record -> source bin (:747-768): data was requested one iteration ago
-			float pos[3] = {nx_pos[0], nx_pos[1], nx_pos[2]};
+			float pos[3] = {pf.pos[0], pf.pos[1], pf.pos[2]};
 			float st[10];// J, or F[9] (+ logJp)
 #pragma unroll
-			for(int d = 0; d < 10; ++d) st[d] = nx_st[d];
-			fetch(idx0 + 64);
+			for(int d = 0; d < 10; ++d) st[d] = pf.st[d];
+			if constexpr(ABL & 32) {
+#pragma unroll
+				for(int d = 0; d < 10; ++d) __asm__ volatile("" ::"v"(st[d]));
+#pragma unroll
+				for(int d = 0; d < 3; ++d) __asm__ volatile("" ::"v"(pos[d]));
+				t_acc[8] += 1;
+			}
+			MPM_TICK(1)
+			fetch(idx0 + 64, pf);
 			// ---- stencil base + weights (:774-797) for ALL lanes (idle lanes of a last partial iteration carry a dummy
 			//      position inside the block); offsets in cell units (exact: dx is a power of two)
 			int base[3], arena[3];
@@ -574,6 +607,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 					if(!fused) p2g_resolve(p2g, s_owner, pv_in, pv_key, pv_off, pv, mass, lane);
 				}
 			}
+			MPM_TICK(2)
 			if constexpr(ABL & 4) {
 				const float4 v = gbase[0];
 				vel[0] = v.x * w[0][0]; vel[1] = v.y * w[1][1]; vel[2] = v.z * w[2][2];
@@ -584,106 +618,126 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 			} else {
 				gather_and_scatter<false>(gbase, w, fd, vel, A, p2g, pv, mass);
 			}
+			if constexpr(ABL & 32) {
+#pragma unroll
+				for(int d = 0; d < 9; ++d) __asm__ volatile("" ::"v"(A[d]));
+			}
+			MPM_TICK(3)
 			P2GPayload pl;
-			int key = 0, nodeoff = 0;
-			bool in_arena = false;
+			// Every lane runs the whole body: the idle lanes of a last partial iteration carry a dummy particle and write
+			// it into the padding slots of the block's last bin (slot == pidib < 64 * ceil(size / 64), allocated but never
+			// read).  Keeping the 13 stores out of divergent control flow matters: the wait for the NEXT iteration's
+			// prefetched data at the loop back-edge is then `vmcnt(13)` instead of `vmcnt(0)` (the compiler can only count
+			// unconditional operations), i.e. it no longer includes the store acknowledgements.
+			// ---- advect (:838)
+#pragma unroll
+			for(int d = 0; d < 3; ++d) pos[d] += vel[d] * dt;
+			// ---- new base, re-bucket (:852-866, add_advection particle_buffer.cuh:100-135).  The list-append atomics are
+			//      issued BEFORE the stress computation, which hides their round trip to L2 (~3 k cycles).
+			int nbase[3], narena[3], dirv[3];
+			bool in_arena = active;
+#pragma unroll
+			for(int d = 0; d < 3; ++d) {
+				const float p = pos[d] * dx_inv;
+				nbase[d]	  = (int) __builtin_roundf(p) - 1;
+				pl.fd[d]	  = p - (float) nbase[d];
+				pl.mv[d]	  = mass * vel[d];
+				dirv[d]		  = ((base[d] - 1) >> 2) - ((nbase[d] - 1) >> 2);
+				narena[d]	  = arena[d] + (nbase[d] - base[d]);
+				in_arena &= (narena[d] >= 0) & (narena[d] + 2 < 8);
+			}
+			const int key	  = narena[0] * 36 + narena[1] * 6 + narena[2];
+			const int nodeoff = narena[0] * kArenaStrideX + narena[1] * 8 + narena[2];
+			const bool dir_ok = ((unsigned) (dirv[0] + 1) < 3u) & ((unsigned) (dirv[1] + 1) < 3u) & ((unsigned) (dirv[2] + 1) < 3u);
+			const int ntag	  = dir_ok ? (dirv[0] + 1) * 9 + (dirv[1] + 1) * 3 + dirv[2] + 1 : kStay;
+			const int dno	  = (active && dir_ok) ? s_dst_no[ntag] : -1;
+			// sort key for the NEXT step: predicted stencil base after one more advection with the current velocity,
+			// expressed in the arena of the block the particle is in after THIS step (clamped to the 6^3 range)
+			int pkey = 0;
+#pragma unroll
+			for(int d = 0; d < 3; ++d) {
+				const int pb = (int) __builtin_roundf((pos[d] + vel[d] * new_dt) * dx_inv) - 1;
+				const int nk = min(max(((nbase[d] - 1) & 3) + 1 + (pb - nbase[d]), 0), 5);
+				pkey		 = pkey * 6 + nk;
+			}
+			const int rec	= (ntag << tag_shift) | (pkey << key_shift) | pidib;
+			const bool stay = dno >= 0 && ntag == kStay;
+			// particles that stay in this block share one wave-aggregated atomic
+			const unsigned long long stay_m = __ballot(stay);
+			const int stay_leader			= stay_m ? __ffsll((long long) stay_m) - 1 : 0;
+			const int stay_rank				= __popcll(stay_m & ((1ull << lane) - 1ull));
+			int raw_stay = 0, raw_move = 0;
+			int b_opaque = b;
+			__asm__("" : "+v"(b_opaque));// hide the uniform address: the compiler's atomic optimiser would broadcast the
+										 // result with v_readfirstlane right here, i.e. wait for the round trip
+			if(stay_m != 0ull && lane == stay_leader) raw_stay = atomicAdd(&mv.out_count[b_opaque], __popcll(stay_m));
+			if(dno >= 0 && !stay) raw_move = atomicAdd(&mv.out_count[dno], 1);
 			if(active) {
-				// ---- advect (:838)
-#pragma unroll
-				for(int d = 0; d < 3; ++d) pos[d] += vel[d] * dt;
-				// ---- material update, store to the destination bin (coalesced: slot == pidib) (:470-663)
-				float* dst = mv.bins_dst + (size_t) (binoff_dst + (pidib >> 6)) * (NCH * kBin) + (pidib & 63);
-				dst[0]		  = pos[0];
-				dst[kBin]	  = pos[1];
-				dst[2 * kBin] = pos[2];
-				if constexpr(MAT == 0) {
-					float Aw[9];
-#pragma unroll
-					for(int d = 0; d < 9; ++d) Aw[d] = A[d] * cfg.dx;
-					const float J = stress_jfluid(mv.mc, st[0], Aw, dt, cfg.d_inv, pl.contrib);
-					dst[3 * kBin] = J;
-				} else {
-					float dws[9], Fold[9], F[9];
-#pragma unroll
-					for(int d = 0; d < 9; ++d) {
-						dws[d]	= (A[d] * dt) * scale + ((d & 0x3) != 0 ? 0.f : 1.f);
-						Fold[d] = st[d];
-					}
-					matmul3(dws, Fold, F);
-					if constexpr(ABL & 2) {
-#pragma unroll
-						for(int d = 0; d < 9; ++d) pl.contrib[d] = F[d] * mv.mc.mu;
-						if constexpr(NCH == 13) dst[12 * kBin] = st[9];
-					} else if constexpr(MAT == 1) {
-						stress_fixed_corotated(mv.mc, F, pl.contrib);
-					} else if constexpr(MAT == 2) {
-						float lj = st[9];
-						stress_sand(mv.mc, F, lj, pl.contrib);
-						dst[12 * kBin] = lj;
-					} else {
-						float lj = st[9];
-						stress_nacc(mv.mc, F, lj, pl.contrib);
-						dst[12 * kBin] = lj;
-					}
-#pragma unroll
-					for(int d = 0; d < 9; ++d) dst[(3 + d) * kBin] = F[d];
-				}
-				// (:850) contrib = (A m - contrib new_dt) D^-1, pre-multiplied by dx so that P2G can stay in cell units
-				{
-					const float am = mass * cfg.dx * cfg.dx * cfg.d_inv;
-					const float cs = new_dt * cfg.d_inv * cfg.dx;
-#pragma unroll
-					for(int d = 0; d < 9; ++d) pl.contrib[d] = A[d] * am - pl.contrib[d] * cs;
-				}
-				// ---- new base, re-bucket (:852-866, add_advection particle_buffer.cuh:100-135)
-				int nbase[3], narena[3], dirv[3];
-				in_arena = true;
-#pragma unroll
-				for(int d = 0; d < 3; ++d) {
-					const float p = pos[d] * dx_inv;
-					nbase[d]	  = (int) __builtin_roundf(p) - 1;
-					pl.fd[d]	  = p - (float) nbase[d];
-					pl.mv[d]	  = mass * vel[d];
-					dirv[d]		  = ((base[d] - 1) >> 2) - ((nbase[d] - 1) >> 2);
-					narena[d]	  = arena[d] + (nbase[d] - base[d]);
-					in_arena &= (narena[d] >= 0) & (narena[d] + 2 < 8);
-				}
-				key		= narena[0] * 36 + narena[1] * 6 + narena[2];
-				nodeoff = narena[0] * kArenaStrideX + narena[1] * 8 + narena[2];
-				const bool dir_ok = ((unsigned) (dirv[0] + 1) < 3u) & ((unsigned) (dirv[1] + 1) < 3u) & ((unsigned) (dirv[2] + 1) < 3u);
-				const int ntag	  = dir_ok ? (dirv[0] + 1) * 9 + (dirv[1] + 1) * 3 + dirv[2] + 1 : kStay;
-				const int dno	  = dir_ok ? s_dst_no[ntag] : -1;
-				// sort key for the NEXT step: predicted stencil base after one more advection with the current velocity,
-				// expressed in the arena of the block the particle is in after THIS step (clamped to the 6^3 range)
-				int pkey = 0;
-#pragma unroll
-				for(int d = 0; d < 3; ++d) {
-					const int pb = (int) __builtin_roundf((pos[d] + vel[d] * new_dt) * dx_inv) - 1;
-					const int nk = min(max(((nbase[d] - 1) & 3) + 1 + (pb - nbase[d]), 0), 5);
-					pkey		 = pkey * 6 + nk;
-				}
-				const bool stay	  = dir_ok && ntag == kStay;
-				int slot		  = -1;
-				// wave-aggregated append for the particles that stay in this block (one atomic per wave)
-				const unsigned long long m = __ballot(stay);
-				if(stay) {
-					const int leader = __ffsll((long long) m) - 1;
-					int basev		 = 0;
-					if(lane == leader) basev = atomicAdd(&mv.out_count[b], __popcll(m));
-					basev = __shfl(basev, leader);
-					slot  = basev + __popcll(m & ((1ull << lane) - 1ull));
-				} else if(dno >= 0) {
-					slot = atomicAdd(&mv.out_count[dno], 1);
-				}
-				if(dno < 0) {
-					atomicAdd(&status[ST_LOST], 1);// reference: particle silently lost (particle_buffer.cuh:105-113)
-				} else if(slot >= cfg.ppb) {
-					atomicOr(&status[ST_OVERFLOW], 2);// reference drops beyond 128 per cell (:122-130)
-				} else {
-					mv.list_out[(size_t) dno * cfg.ppb + slot] = (ntag << tag_shift) | (pkey << key_shift) | pidib;
-				}
+				if(dno < 0) atomicAdd(&status[ST_LOST], 1);// reference: particle silently lost (particle_buffer.cuh:105-113)
 				if(!in_arena) atomicAdd(&status[ST_ARENA], 1);// (:877-885) contribution discarded
 			}
+			// ---- material update, store to the destination bin (coalesced: slot == pidib) (:470-663)
+			float* dst = mv.bins_dst + (size_t) (binoff_dst + (pidib >> 6)) * (NCH * kBin) + (pidib & 63);
+			dst[0]		  = pos[0];
+			dst[kBin]	  = pos[1];
+			dst[2 * kBin] = pos[2];
+			if constexpr(MAT == 0) {
+				float Aw[9];
+#pragma unroll
+				for(int d = 0; d < 9; ++d) Aw[d] = A[d] * cfg.dx;
+				const float J = stress_jfluid(mv.mc, st[0], Aw, dt, cfg.d_inv, pl.contrib);
+				dst[3 * kBin] = J;
+			} else {
+				float dws[9], Fold[9], F[9];
+#pragma unroll
+				for(int d = 0; d < 9; ++d) {
+					dws[d]	= (A[d] * dt) * scale + ((d & 0x3) != 0 ? 0.f : 1.f);
+					Fold[d] = st[d];
+				}
+				matmul3(dws, Fold, F);
+				if constexpr(ABL & 2) {
+#pragma unroll
+					for(int d = 0; d < 9; ++d) pl.contrib[d] = F[d] * mv.mc.mu;
+					if constexpr(NCH == 13) dst[12 * kBin] = st[9];
+				} else if constexpr(MAT == 1) {
+					stress_fixed_corotated(mv.mc, F, pl.contrib);
+				} else if constexpr(MAT == 2) {
+					float lj = st[9];
+					stress_sand(mv.mc, F, lj, pl.contrib);
+					dst[12 * kBin] = lj;
+				} else {
+					float lj = st[9];
+					stress_nacc(mv.mc, F, lj, pl.contrib);
+					dst[12 * kBin] = lj;
+				}
+#pragma unroll
+				for(int d = 0; d < 9; ++d) dst[(3 + d) * kBin] = F[d];
+			}
+			// (:850) contrib = (A m - contrib new_dt) D^-1, pre-multiplied by dx so that P2G can stay in cell units
+			{
+				const float am = mass * cfg.dx * cfg.dx * cfg.d_inv;
+				const float cs = new_dt * cfg.d_inv * cfg.dx;
+#pragma unroll
+				for(int d = 0; d < 9; ++d) pl.contrib[d] = A[d] * am - pl.contrib[d] * cs;
+			}
+			if constexpr(ABL & 32) {
+#pragma unroll
+				for(int d = 0; d < 9; ++d) __asm__ volatile("" ::"v"(pl.contrib[d]));
+			}
+			MPM_TICK(4)
+			// ---- list append: the atomics' results are in by now
+			{
+				const int basev = __shfl(raw_stay, stay_leader);
+				if(dno >= 0) {
+					const int slot = stay ? basev + stay_rank : raw_move;
+					if(slot >= cfg.ppb)
+						atomicOr(&status[ST_OVERFLOW], 2);// reference drops beyond 128 per cell (:122-130)
+					else
+						mv.list_out[(size_t) dno * cfg.ppb + slot] = rec;
+				}
+			}
+			touch(pf);// the next iteration's particle data must have arrived by now
+			MPM_TICK(5)
 			// ---- hand the payload to the next iteration's fused gather/scatter (:887-905)
 			if constexpr(ABL & 1) {
 #pragma unroll
@@ -703,6 +757,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 			if(have_prev) p2g_resolve(p2g, s_owner, pv_in, pv_key, pv_off, pv, mass, lane);
 		}
 		__syncthreads();
+		MPM_TICK(3)
 	}
 	// ---- arena -> next grid: one hardware f32 atomic per touched node, 256-B rows (:907-936)
 #pragma unroll
@@ -715,6 +770,14 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 			if(v.y != 0.f) unsafeAtomicAdd(g + 64, v.y);
 			if(v.z != 0.f) unsafeAtomicAdd(g + 128, v.z);
 			if(v.w != 0.f) unsafeAtomicAdd(g + 192, v.w);
+		}
+	}
+	if constexpr(ABL & 32) {
+		__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		MPM_TICK(7)
+		if(lane == 0) {
+#pragma unroll
+			for(int i = 0; i < 9; ++i) atomicAdd(&g_prof[blockIdx.x & 1023][i], t_acc[i]);
 		}
 	}
 }
