@@ -230,10 +230,10 @@ void mpm_destroy(mpm_ctx* ctx) {
 		if(hipMemcpyFromSymbol(rows.data(), HIP_SYMBOL(mpm::g_prof), rows.size() * sizeof(unsigned long long)) == hipSuccess) {
 			for(int r = 0; r < 1024; ++r)
 				for(int i = 0; i < 16; ++i) h[i] += rows[r * 16 + i];
-			static const char* nm[9] = {"sort", "wait_prefetch", "claim", "gather+scatter", "stress+stores", "rebucket", "prologue", "epilogue", "iterations"};
+			static const char* nm[12] = {"sort", "wait_prefetch", "claim", "gather+scatter", "stress+stores", "rebucket", "prologue", "epilogue", "iterations", "fused", "not_fused", "mispredicted"};
 			unsigned long long tot = 0;
 			for(int i = 0; i < 8; ++i) tot += h[i];
-			for(int i = 0; i < 9; ++i) fprintf(stderr, "[g2p2g prof] %-16s %14llu  %5.1f %%  %8.0f cycles/iteration\n", nm[i], h[i], i < 8 ? 100.0 * h[i] / (double) tot : 0.0, h[8] ? (double) h[i] / (double) h[8] : 0.0);
+			for(int i = 0; i < 12; ++i) fprintf(stderr, "[g2p2g prof] %-16s %14llu  %5.1f %%  %8.0f cycles/iteration\n", nm[i], h[i], i < 8 ? 100.0 * h[i] / (double) tot : 0.0, h[8] ? (double) h[i] / (double) h[8] : 0.0);
 		}
 	}
 	for(int i = 0; i < 2; ++i) {

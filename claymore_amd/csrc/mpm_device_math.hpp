@@ -11,6 +11,13 @@
 namespace mpm {
 
 #define MPM_DEV __device__ __forceinline__
+#ifndef MPM_MARK
+#ifdef MPM_ASM_MARKS
+#define MPM_MARK(name) __asm__ volatile("; MPM_MARK " name)
+#else
+#define MPM_MARK(name)
+#endif
+#endif
 
 // Projects/GMPM/utility_funcs.hpp:10-19 — quadratic B-spline weights; d = offset from the base node in cells
 MPM_DEV void bspline_weight_cells(float d, float (&w)[3]) {
@@ -22,9 +29,14 @@ MPM_DEV void bspline_weight_cells(float d, float (&w)[3]) {
 	w[2]		  = 0.5f * c * c;
 }
 
-// utility_funcs.hpp:21-23: lround(x * dx_inv) for x >= 0 (round half away from zero)
+// lround for p >= 0 (round half away from zero, utility_funcs.hpp:21-23) in 4 instructions: v_rndne_f32 rounds ties to
+// even, i.e. differs only for p = k + 0.5 with k even, where p - rndne(p) is exactly +0.5.
+MPM_DEV int lround_pos(float p) {
+	const float r = __builtin_rintf(p);
+	return (int) r + ((p - r) == 0.5f ? 1 : 0);
+}
 MPM_DEV int node_index(float x, float dx_inv) {
-	return (int) __builtin_roundf(x * dx_inv);
+	return lround_pos(x * dx_inv);
 }
 
 // Library/MnBase/Math/Matrix/MatrixUtils.h:147-157 (column-major)
@@ -56,6 +68,16 @@ MPM_DEV void P_Ft_vol(const float (&P)[9], const float (&F)[9], float volume, fl
 // approximate division itself; IEEE division costs ~10 VALU instructions on gfx950 and G2P2G is VALU-bound.
 MPM_DEV float rcp_fast(float x) {
 	return __builtin_amdgcn_rcpf(x);
+}
+// Natural log / exp through the 1-ulp hardware base-2 instructions (v_log_f32, v_exp_f32): 2 VALU instructions instead of
+// ~20 / ~15 for the IEEE-careful library versions.  The reference binary uses the same kind of approximation
+// (--use_fast_math turns logf / expf into lg2.approx / ex2.approx, CMake-Utils/setup_cuda.cmake:50).  Arguments on this
+// path are singular values in [1e-4, ~10] and log-strains of order 1: no denormals, no overflow.
+MPM_DEV float log_fast(float x) {
+	return __builtin_amdgcn_logf(x) * 0.693147180559945f;
+}
+MPM_DEV float exp_fast(float x) {
+	return __builtin_amdgcn_exp2f(x * 1.442695040888963f);
 }
 MPM_DEV float rsqrt_approx(float x) {
 	return __builtin_amdgcn_rsqf(x);// v_rsq_f32, ~1 ulp; the algorithm re-normalises (svd.cuh:210-215)
@@ -165,7 +187,17 @@ MPM_DEV void qr_givens(float apiv, float aqpiv, float& ap1, float& ap2, float& a
 // QR (:771-1122) is kept as the path for ill-conditioned B (sigma_3 < 1e-3 sigma_1), where normalising would divide
 // by ~0.  Deviation from the reference's QR result is of the order of the Jacobi residual of the reference itself
 // (tests/test_parity_gpu.py, tools note in DESIGN.md section 6).
-MPM_DEV void svd3(const float (&F)[9], float (&U)[9], float (&S)[3], float (&V)[9]) {
+//
+// Hook: the G2P2G kernel threads an unrelated, latency-bound chain of LDS read-modify-write steps (the P2G scatter of
+// the previous particle) through this arithmetic; `hk.at<SITE>()` is called at kSvdSites evenly spaced points that
+// every lane reaches (never inside divergent control flow).  NoHook compiles to nothing.
+struct NoHook {
+	template<int SITE>
+	MPM_DEV void at() {}
+};
+constexpr int kSvdSites = 16;
+template<int BASE, class Hook>
+MPM_DEV void svd3(const float (&F)[9], float (&U)[9], float (&S)[3], float (&V)[9], Hook& hk) {
 	float s11 = F[0] * F[0] + F[1] * F[1] + F[2] * F[2];
 	float s21 = F[3] * F[0] + F[4] * F[1] + F[5] * F[2];
 	float s31 = F[6] * F[0] + F[7] * F[1] + F[8] * F[2];
@@ -173,18 +205,31 @@ MPM_DEV void svd3(const float (&F)[9], float (&U)[9], float (&S)[3], float (&V)[
 	float s32 = F[6] * F[3] + F[7] * F[4] + F[8] * F[5];
 	float s33 = F[6] * F[6] + F[7] * F[7] + F[8] * F[8];
 	float v1[3] = {1.f, 0.f, 0.f}, v2[3] = {0.f, 1.f, 0.f}, v3[3] = {0.f, 0.f, 1.f};
+	MPM_MARK("svd_jacobi");
+	hk.template at<BASE + 0>();
 	// The reference always runs 4 sweeps (svd.cuh:167).  Cyclic Jacobi converges quadratically, so once every
 	// off-diagonal entry of every lane is below 1e-7 of the diagonal a further sweep only rotates by angles whose
-	// effect on U Sigma V^T is below fp32 resolution; the remaining sweeps are skipped for the whole wave then.
-#pragma unroll 1
-	for(int it = 0; it < 4; ++it) {
-		jacobi_conj(s11, s21, s22, s31, s32, s33, v1, v2);
-		jacobi_conj(s22, s32, s33, s21, s31, s11, v2, v3);
-		jacobi_conj(s33, s31, s11, s32, s21, s22, v3, v1);
-		const float off = fmaxf(fmaxf(fabsf(s21), fabsf(s31)), fabsf(s32));
-		const float dia = fminf(fminf(fabsf(s11), fabsf(s22)), fabsf(s33));
-		if(__all(off <= 1e-7f * dia)) break;
-	}
+	// effect on U Sigma V^T is below fp32 resolution; the remaining sweeps are skipped for the whole wave then
+	// (`done` is wave-uniform: scalar branches).
+	bool done = false;
+#define MPM_SWEEP(IT)                                                                  \
+	if(!done) jacobi_conj(s11, s21, s22, s31, s32, s33, v1, v2);                      \
+	hk.template at<BASE + 1 + 3 * IT>();                                              \
+	if(!done) jacobi_conj(s22, s32, s33, s21, s31, s11, v2, v3);                      \
+	hk.template at<BASE + 2 + 3 * IT>();                                              \
+	if(!done) {                                                                       \
+		jacobi_conj(s33, s31, s11, s32, s21, s22, v3, v1);                            \
+		const float off = fmaxf(fmaxf(fabsf(s21), fabsf(s31)), fabsf(s32));           \
+		const float dia = fminf(fminf(fabsf(s11), fabsf(s22)), fabsf(s33));           \
+		done			= __all(off <= 1e-7f * dia);                                  \
+	}                                                                                 \
+	hk.template at<BASE + 3 + 3 * IT>();
+	MPM_SWEEP(0)
+	MPM_SWEEP(1)
+	MPM_SWEEP(2)
+	MPM_SWEEP(3)
+#undef MPM_SWEEP
+	MPM_MARK("svd_post");
 	// B = F V (svd.cuh:532-588), columns b1 b2 b3
 	float b1[3], b2[3], b3[3];
 #pragma unroll
@@ -196,6 +241,7 @@ MPM_DEV void svd3(const float (&F)[9], float (&U)[9], float (&S)[3], float (&V)[
 	float n1 = b1[0] * b1[0] + b1[1] * b1[1] + b1[2] * b1[2];
 	float n2 = b2[0] * b2[0] + b2[1] * b2[1] + b2[2] * b2[2];
 	float n3 = b3[0] * b3[0] + b3[1] * b3[1] + b3[2] * b3[2];
+	hk.template at<BASE + 13>();
 	// sort columns by squared norm, descending; a swap negates one column so that V stays a rotation (svd.cuh:590-770)
 #define MPM_SWAPCOL(c, x, y, nx, ny, neg)                         \
 	{                                                             \
@@ -218,11 +264,12 @@ MPM_DEV void svd3(const float (&F)[9], float (&U)[9], float (&S)[3], float (&V)[
 		V[3 + r] = v2[r];
 		V[6 + r] = v3[r];
 	}
+	hk.template at<BASE + 14>();
 	if(n3 > 1e-6f * n1) {
 		// well conditioned: u_i = b_i / sigma_i
 		const float det = b1[0] * (b2[1] * b3[2] - b2[2] * b3[1]) - b2[0] * (b1[1] * b3[2] - b1[2] * b3[1]) + b3[0] * (b1[1] * b2[2] - b1[2] * b2[1]);
-		const float i1 = rsqrt_newton(n1), i2 = rsqrt_newton(n2);
-		float i3	   = rsqrt_newton(n3);
+		const float i1 = rsqrt_approx(n1), i2 = rsqrt_approx(n2);// v_rsq_f32 is 1 ulp: no Newton step needed (svd.cuh:487-498 refines a 12-bit estimate)
+		float i3	   = rsqrt_approx(n3);
 		S[0]		   = n1 * i1;
 		S[1]		   = n2 * i2;
 		S[2]		   = n3 * i3;
@@ -256,6 +303,12 @@ MPM_DEV void svd3(const float (&F)[9], float (&U)[9], float (&S)[3], float (&V)[
 		S[1] = a22;
 		S[2] = a33;
 	}
+	hk.template at<BASE + 15>();
+	MPM_MARK("svd_end");
+}
+MPM_DEV void svd3(const float (&F)[9], float (&U)[9], float (&S)[3], float (&V)[9]) {
+	NoHook nh;
+	svd3<0>(F, U, S, V, nh);
 }
 
 // Material constants passed by value to the kernels (Projects/GMPM/particle_buffer.cuh:141-264)
@@ -269,9 +322,11 @@ struct MaterialConst {
 };
 
 // compute_stress<FIXED_COROTATED>, Projects/GMPM/constitutive_models.cuh:36-73
-MPM_DEV void stress_fixed_corotated(const MaterialConst& mc, const float (&F)[9], float (&PF)[9]) {
+constexpr int kFcSites = kSvdSites + 2;
+template<int BASE, class Hook>
+MPM_DEV void stress_fixed_corotated(const MaterialConst& mc, const float (&F)[9], float (&PF)[9], Hook& hk) {
 	float U[9], S[3], V[9];
-	svd3(F, U, S, V);
+	svd3<BASE>(F, U, S, V, hk);
 	const float J			  = S[0] * S[1] * S[2];
 	const float scaled_mu	  = 2.0f * mc.mu;
 	const float scaled_lambda = mc.lambda * (J - 1.0f);
@@ -281,19 +336,27 @@ MPM_DEV void stress_fixed_corotated(const MaterialConst& mc, const float (&F)[9]
 	Ph[2] = scaled_mu * (S[2] - 1.f) + scaled_lambda * (S[0] * S[1]);
 	float P[9];
 	mat_diag_matT(P, U, Ph, V);
+	hk.template at<BASE + kSvdSites>();
 	P_Ft_vol(P, F, mc.volume, PF);
+	hk.template at<BASE + kSvdSites + 1>();
+}
+MPM_DEV void stress_fixed_corotated(const MaterialConst& mc, const float (&F)[9], float (&PF)[9]) {
+	NoHook nh;
+	stress_fixed_corotated<0>(mc, F, PF, nh);
 }
 
 // compute_stress<SAND>, constitutive_models.cuh:238-335 (Drucker-Prager return mapping, StVK-Hencky)
-MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9]) {
+constexpr int kSandSites = kSvdSites + 4;
+template<int BASE, class Hook>
+MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9], Hook& hk, float* __restrict__ Fdst = nullptr, int Fstride = 0) {
 	float U[9], S[3], V[9];
-	svd3(F, U, S, V);
+	svd3<BASE>(F, U, S, V, hk);
 	const float scaled_mu = 2.0f * mc.mu;
 	float epsilon[3], New_S[3] = {0.f, 0.f, 0.f};
 #pragma unroll
 	for(int i = 0; i < 3; i++) {
 		const float abs_S = fmaxf(fabsf(S[i]), 1e-4f);
-		epsilon[i]		  = logf(abs_S) - mc.cohesion;
+		epsilon[i]		  = log_fast(abs_S) - mc.cohesion;
 	}
 	const float sum_epsilon	  = epsilon[0] + epsilon[1] + epsilon[2];
 	const float trace_epsilon = sum_epsilon + log_jp;
@@ -301,12 +364,13 @@ MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, 
 #pragma unroll
 	for(int i = 0; i < 3; i++) epsilon_hat[i] = epsilon[i] - (trace_epsilon * (1.0f / 3.0f));
 	const float epsilon_hat_norm = __builtin_amdgcn_sqrtf(epsilon_hat[0] * epsilon_hat[0] + epsilon_hat[1] * epsilon_hat[1] + epsilon_hat[2] * epsilon_hat[2]);
+	hk.template at<BASE + kSvdSites>();
 	// log(New_S) is needed below; New_S = exp(H), so H itself is used instead of logf(expf(H)) (the reference's
 	// round trip, constitutive_models.cuh:311, differs from H by one rounding of expf: ~6e-8 absolute)
 	float lnS[3];
 	bool rebuild = false;
 	if(trace_epsilon >= 0.0f) {// case II: cone tip
-		New_S[0] = New_S[1] = New_S[2] = expf(mc.cohesion);
+		New_S[0] = New_S[1] = New_S[2] = exp_fast(mc.cohesion);
 		lnS[0] = lnS[1] = lnS[2] = mc.cohesion;
 		rebuild					 = true;
 		if(mc.volume_correction) log_jp = mc.beta * sum_epsilon + log_jp;
@@ -322,26 +386,56 @@ MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, 
 			for(int i = 0; i < 3; i++) lnS[i] = epsilon[i] - r * epsilon_hat[i] + mc.cohesion;
 		}
 #pragma unroll
-		for(int i = 0; i < 3; i++) New_S[i] = expf(lnS[i]);
+		for(int i = 0; i < 3; i++) New_S[i] = exp_fast(lnS[i]);
 		rebuild = true;
 	} else {
 		lnS[0] = lnS[1] = lnS[2] = -__builtin_inff();// reference: logf(0) when mu == 0 (:298-300)
 	}
+	hk.template at<BASE + kSvdSites + 1>();
 	if(rebuild) mat_diag_matT(F, U, New_S, V);
+	if(Fdst) {// the kernel has the projected F written out here: nine registers less while P F^T is formed
+#pragma unroll
+		for(int d = 0; d < 9; ++d) Fdst[d * Fstride] = F[d];
+	}
+	hk.template at<BASE + kSvdSites + 2>();
 	const float trace_log_S = lnS[0] + lnS[1] + lnS[2];
-	float P_hat[3];
-	P_hat[0] = (scaled_mu * lnS[0] + mc.lambda * trace_log_S) * rcp_fast(New_S[0]);
-	P_hat[1] = (scaled_mu * lnS[1] + mc.lambda * trace_log_S) * rcp_fast(New_S[1]);
-	P_hat[2] = (scaled_mu * lnS[2] + mc.lambda * trace_log_S) * rcp_fast(New_S[2]);
-	float P[9];
-	mat_diag_matT(P, U, P_hat, V);
-	P_Ft_vol(P, F, mc.volume, PF);
+	// P F^T vol (:318-334).  With F = U New_S V^T as rebuilt above, P F^T = U P_hat V^T V New_S U^T = U diag(P_hat_k New_S_k) U^T
+	// with P_hat_k New_S_k = 2 mu ln S_k + lambda tr(ln S): 27 FMAs instead of two 3x3x3 products and three reciprocals
+	// (V^T V = I to ~1e-7, the same order as the reference's own SVD residual).
+	// (mu == 0 leaves F as it is and ln S = -inf: the reference's P is NaN then, and so is this.)  No branch here on
+	// purpose: stores to PF in two arms get merged into one store with a variable offset, which keeps PF in scratch.
+	{
+		float d[3], UD[9];
+#pragma unroll
+		for(int k = 0; k < 3; ++k) d[k] = (scaled_mu * lnS[k] + mc.lambda * trace_log_S) * mc.volume;
+#pragma unroll
+		for(int k = 0; k < 3; ++k) {
+#pragma unroll
+			for(int i = 0; i < 3; ++i) UD[3 * k + i] = U[3 * k + i] * d[k];
+		}
+		PF[0] = UD[0] * U[0] + UD[3] * U[3] + UD[6] * U[6];
+		PF[1] = UD[1] * U[0] + UD[4] * U[3] + UD[7] * U[6];
+		PF[2] = UD[2] * U[0] + UD[5] * U[3] + UD[8] * U[6];
+		PF[4] = UD[1] * U[1] + UD[4] * U[4] + UD[7] * U[7];
+		PF[5] = UD[2] * U[1] + UD[5] * U[4] + UD[8] * U[7];
+		PF[8] = UD[2] * U[2] + UD[5] * U[5] + UD[8] * U[8];
+		PF[3] = PF[1];
+		PF[6] = PF[2];
+		PF[7] = PF[5];
+	}
+	hk.template at<BASE + kSvdSites + 3>();
+}
+MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9]) {
+	NoHook nh;
+	stress_sand<0>(mc, F, log_jp, PF, nh);
 }
 
 // compute_stress<NACC>, constitutive_models.cuh:77-234 (USE_JOSH_FRACTURE_PAPER branch)
-MPM_DEV void stress_nacc(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9]) {
+constexpr int kNaccSites = kSvdSites + 2;
+template<int BASE, class Hook>
+MPM_DEV void stress_nacc(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9], Hook& hk) {
 	float U[9], S[3], V[9];
-	svd3(F, U, S, V);
+	svd3<BASE>(F, U, S, V, hk);
 	const float bm	  = mc.bm;
 	const float p0	  = bm * (0.00001f + sinhf(mc.xi * (-log_jp > 0 ? -log_jp : 0)));
 	const float p_min = -mc.beta * p0;
@@ -393,6 +487,7 @@ MPM_DEV void stress_nacc(const MaterialConst& mc, float (&F)[9], float& log_jp, 
 			if(Je_new_fake > 1e-4f) log_jp += logf(Je_trial / Je_new_fake);
 		}
 	}
+	hk.template at<BASE + kSvdSites>();
 	const float J = S[0] * S[1] * S[2];
 	float b[9];
 #pragma unroll
@@ -415,6 +510,11 @@ MPM_DEV void stress_nacc(const MaterialConst& mc, float (&F)[9], float& log_jp, 
 	PF[6]					= (dev_b_coeff * b[6]) * mc.volume;
 	PF[7]					= (dev_b_coeff * b[7]) * mc.volume;
 	PF[8]					= (dev_b_coeff * bd8 + i_coeff) * mc.volume;
+	hk.template at<BASE + kSvdSites + 1>();
+}
+MPM_DEV void stress_nacc(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9]) {
+	NoHook nh;
+	stress_nacc<0>(mc, F, log_jp, PF, nh);
 }
 
 // J-fluid (weakly compressible, Tait EOS + Newtonian viscosity), Projects/GMPM/mgmpm_kernels.cuh:476-505

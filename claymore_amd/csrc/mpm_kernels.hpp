@@ -234,6 +234,7 @@ __device__ __forceinline__ void p2g_scatter_rmw(float4* __restrict__ node0, cons
 				a23			   = t12 * W + a23;
 				*node		   = make_float4(a01.x, a01.y, a23.x, a23.y);
 				__asm__ volatile("" ::: "memory");
+				__builtin_amdgcn_sched_barrier(0);// rare path: keep the 27 steps' arithmetic from being hoisted (registers)
 			}
 		}
 	}
@@ -352,6 +353,81 @@ __device__ __forceinline__ void gather_and_scatter(const float4* __restrict__ gb
 	}
 }
 
+// The P2G scatter of one particle per lane as a chain of 27 ordered LDS read-modify-write steps that is threaded
+// through unrelated register-only arithmetic (the NEXT particle's re-bucketing, F update, SVD and stress).  Each step
+// is an LDS round trip (~130-200 cycles under load) and the steps cannot overlap each other - step o+1 may hit the node
+// another lane wrote in step o (see p2g_scatter_rmw) - so issued back to back they leave the wave idle; spread over
+// NSITES call sites `at<SITE>()` of the host computation (~30 VALU instructions apart) the round trips disappear
+// behind it.  Site s completes steps [27 s / NSITES, 27 (s+1) / NSITES): the accumulator of the following step is
+// requested right after a step's write and consumed at the next site.  Only lanes with `win` (pairwise distinct
+// stencil bases) take part; the others are scattered afterwards by p2g_resolve.
+template<int NSITES>
+struct ScatterChain {
+	float4* node0;
+	P2GPayload pp;// element-wise copy: a reference member or a struct copy keeps the payload in scratch memory
+	float mass;
+	int win;// (int, not bool: a 1-byte member makes the compiler slice its neighbours into bytes)
+	float pw[3][3];
+	float b0, wij;
+	v2f b12, c12;
+	float4 acc;
+	MPM_DEV ScatterChain(float4* n0, const P2GPayload& p, float m, bool w)
+		: node0(n0)
+		, mass(m)
+		, win(w) {
+#pragma unroll
+		for(int d = 0; d < 3; ++d) {
+			pp.fd[d] = p.fd[d];
+			pp.mv[d] = p.mv[d];
+		}
+#pragma unroll
+		for(int d = 0; d < 9; ++d) pp.contrib[d] = p.contrib[d];
+#pragma unroll
+		for(int d = 0; d < 3; ++d) bspline_weight_cells(pp.fd[d], pw[d]);
+		c12 = (v2f) {pp.contrib[7], pp.contrib[8]};
+		if(win) acc = node0[0];
+	}
+	MPM_DEV void step(int o) {// o is a compile-time constant after unrolling
+		const int i = o / 9, j = (o / 3) % 3, k = o % 3;
+		if(k == 0) {
+			const float px = (float) i - pp.fd[0], py = (float) j - pp.fd[1];
+			b0	= pp.mv[0] + pp.contrib[0] * px + pp.contrib[3] * py;
+			b12 = (v2f) {pp.mv[1] + pp.contrib[1] * px + pp.contrib[4] * py, pp.mv[2] + pp.contrib[2] * px + pp.contrib[5] * py};
+			wij = pw[0][i] * pw[1][j];
+		}
+		const float pz = (float) k - pp.fd[2];
+		const float W  = wij * pw[2][k];
+		const v2f m0   = {mass, b0 + pp.contrib[6] * pz};
+		const v2f t12  = c12 * pz + b12;
+		if(win) {
+			v2f a01			 = {acc.x, acc.y};
+			v2f a23			 = {acc.z, acc.w};
+			a01				 = m0 * W + a01;
+			a23				 = t12 * W + a23;
+			const int off	 = i * kArenaStrideX + j * 8 + k;
+			node0[off]		 = make_float4(a01.x, a01.y, a23.x, a23.y);
+			__asm__ volatile("" ::: "memory");
+			if(o + 1 < 27) {
+				const int i1 = (o + 1) / 9, j1 = ((o + 1) / 3) % 3, k1 = (o + 1) % 3;
+				acc			 = node0[i1 * kArenaStrideX + j1 * 8 + k1];
+			}
+		}
+	}
+	template<int SITE>
+	MPM_DEV void at() {
+		static_assert(SITE >= 0 && SITE < NSITES, "site out of range");
+#pragma unroll
+		for(int o = SITE * 27 / NSITES; o < (SITE + 1) * 27 / NSITES; ++o) step(o);
+	}
+	template<int LO, int HI>
+	MPM_DEV void range() {
+		if constexpr(LO < HI) {
+			at<LO>();
+			range<LO + 1, HI>();
+		}
+	}
+};
+
 // Resolve intra-wave conflicts for one batch of payloads: lanes whose stencil base (key) is unique in the wave
 // scatter immediately; the others retry.  key < 216 (6^3 possible new cells around a block).
 __device__ __forceinline__ void p2g_resolve(float4* __restrict__ arena, unsigned char* __restrict__ owner, bool pending, int key, int nodeoff, const P2GPayload& pl, float mass, int lane) {
@@ -377,6 +453,13 @@ __device__ unsigned long long g_prof[1024][16];// spread over 1024 rows: same-ad
 		t_last = t_now; \
 	}
 
+// tools/asm_stats.sh -DMPM_ASM_MARKS: comment markers in the assembly for per-phase instruction counts
+#ifdef MPM_ASM_MARKS
+#define MPM_MARK(name) __asm__ volatile("; MPM_MARK " name)
+#else
+#define MPM_MARK(name)
+#endif
+
 // ABL: ablation mask for profiling builds (0 in production): 1 skip the P2G scatter, 2 skip the stress (SVD),
 // 4 skip the G2P gather, 8 skip the interleave sort, 16 skip the particle stores.  Values are kept live with
 // empty asm statements so that the compiler cannot delete upstream work.
@@ -397,7 +480,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 	const int b	   = block_list ? block_list[blockIdx.x] : (int) blockIdx.x;
 	const int size = mv.size[b];
 	if(size == 0) return;// (:692-697)
-	unsigned long long t_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};// [9] fused iterations, [10] conflict-retry passes, [11] mispredicted keys
 	unsigned long long t_last	= 0;
 	if constexpr(ABL & 32) t_last = __builtin_readcyclecounter();
 	const int kx = cur_keys[3 * b], ky = cur_keys[3 * b + 1], kz = cur_keys[3 * b + 2];
@@ -530,6 +613,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 		// acknowledgements and the list-append atomics.
 		struct Prefetch {
 			float pos[3], st[10];
+			int key;// the stencil base this particle was predicted to have after this step (its sort key)
 		};
 		auto fetch = [&](int idx0, Prefetch& f) {
 			const int rec	 = s_sorted[min(idx0 + lane, nrec - 1)];
@@ -537,6 +621,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 			const int sp	 = rec & (cfg.ppb - 1);
 			const int sbin	 = s_src_binoff[tag] + (sp >> 6);
 			const float* src = mv.bins_src + (size_t) sbin * (NCH * kBin) + (sp & 63);
+			f.key			 = (rec >> key_shift) & 255;
 			f.pos[0]		 = src[0];
 			f.pos[1]		 = src[kBin];
 			f.pos[2]		 = src[2 * kBin];
@@ -564,6 +649,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 		int pv_key = 0, pv_off = 0;
 		bool pv_in = false, have_prev = false;
 		for(int idx0 = 0; idx0 < nrec; idx0 += 64) {
+			MPM_MARK("loop_top");
 			const bool active = idx0 + lane < nrec;
 			const int pidib	  = chunk0 + idx0 + lane;// slot in the destination bins == position in the sorted order
 			// ---- advection record -> source bin (:747-768): data was requested one iteration ago
@@ -571,6 +657,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 			float st[10];// J, or F[9] (+ logJp)
 #pragma unroll
 			for(int d = 0; d < 10; ++d) st[d] = pf.st[d];
+			const int predicted_key = pf.key;
 			if constexpr(ABL & 32) {
 #pragma unroll
 				for(int d = 0; d < 10; ++d) __asm__ volatile("" ::"v"(st[d]));
@@ -587,7 +674,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 #pragma unroll
 			for(int d = 0; d < 3; ++d) {
 				const float p = pos[d] * dx_inv;
-				base[d]		  = (int) __builtin_roundf(p) - 1;
+				base[d]		  = lround_pos(p) - 1;
 				fd[d]		  = p - (float) base[d];
 				bspline_weight_cells(fd[d], w[d]);
 				arena[d] = ((base[d] - 1) & 3) + 1;
@@ -595,26 +682,28 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 			float vel[3] = {0.f, 0.f, 0.f};
 			float A[9]	 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 			const float4* gbase = g2p + (arena[0] - 1) * kG2PStrideX + (arena[1] - 1) * 8 + (arena[2] - 1);
-			// ---- claim the stencil bases of the payload in flight; fuse its scatter into this gather if nobody collides
-			bool fused = false;
+			MPM_MARK("claim");
+			// ---- claim the stencil bases of the payload in flight: lanes whose base is unique in the wave (`win`) scatter
+			//      in the chain threaded through this iteration's arithmetic, the others afterwards
+			bool win = false;
 			if constexpr(!(ABL & 1)) {
 				if(have_prev) {
 					if(pv_in) s_owner[pv_key] = (unsigned char) lane;
 					__syncthreads();
-					const bool win = pv_in && (int) s_owner[pv_key] == lane;
+					win = pv_in && (int) s_owner[pv_key] == lane;
 					__syncthreads();
-					fused = __all(win);
-					if(!fused) p2g_resolve(p2g, s_owner, pv_in, pv_key, pv_off, pv, mass, lane);
+					if constexpr(ABL & 32) {
+						if(__all(win || !pv_in)) t_acc[9] += 1;
+						else t_acc[10] += 1;
+					}
 				}
 			}
+			MPM_MARK("gather");
 			MPM_TICK(2)
 			if constexpr(ABL & 4) {
 				const float4 v = gbase[0];
 				vel[0] = v.x * w[0][0]; vel[1] = v.y * w[1][1]; vel[2] = v.z * w[2][2];
 				A[0] = v.x * fd[0]; A[4] = v.y * fd[1]; A[8] = v.z * fd[2];
-				if(fused) p2g_scatter_rmw(p2g + pv_off, pv, mass);
-			} else if(fused) {
-				gather_and_scatter<true>(gbase, w, fd, vel, A, p2g + pv_off, pv, mass);
 			} else {
 				gather_and_scatter<false>(gbase, w, fd, vel, A, p2g, pv, mass);
 			}
@@ -623,6 +712,10 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 				for(int d = 0; d < 9; ++d) __asm__ volatile("" ::"v"(A[d]));
 			}
 			MPM_TICK(3)
+			MPM_MARK("rebucket");
+			constexpr int kPreSites = 3, kStressSites = MAT == 0 ? 1 : (MAT == 1 ? kFcSites : (MAT == 2 ? kSandSites : kNaccSites));
+			constexpr int kSites	= kPreSites + kStressSites + 1;
+			ScatterChain<kSites> chain(p2g + pv_off, pv, mass, win);
 			P2GPayload pl;
 			// Every lane runs the whole body: the idle lanes of a last partial iteration carry a dummy particle and write
 			// it into the padding slots of the block's last bin (slot == pidib < 64 * ceil(size / 64), allocated but never
@@ -639,15 +732,17 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 #pragma unroll
 			for(int d = 0; d < 3; ++d) {
 				const float p = pos[d] * dx_inv;
-				nbase[d]	  = (int) __builtin_roundf(p) - 1;
+				nbase[d]	  = lround_pos(p) - 1;
 				pl.fd[d]	  = p - (float) nbase[d];
 				pl.mv[d]	  = mass * vel[d];
 				dirv[d]		  = ((base[d] - 1) >> 2) - ((nbase[d] - 1) >> 2);
 				narena[d]	  = arena[d] + (nbase[d] - base[d]);
 				in_arena &= (narena[d] >= 0) & (narena[d] + 2 < 8);
 			}
+			chain.template at<0>();
 			const int key	  = narena[0] * 36 + narena[1] * 6 + narena[2];
 			const int nodeoff = narena[0] * kArenaStrideX + narena[1] * 8 + narena[2];
+			if constexpr(ABL & 32) t_acc[11] += __popcll(__ballot(in_arena && key != predicted_key));
 			const bool dir_ok = ((unsigned) (dirv[0] + 1) < 3u) & ((unsigned) (dirv[1] + 1) < 3u) & ((unsigned) (dirv[2] + 1) < 3u);
 			const int ntag	  = dir_ok ? (dirv[0] + 1) * 9 + (dirv[1] + 1) * 3 + dirv[2] + 1 : kStay;
 			const int dno	  = (active && dir_ok) ? s_dst_no[ntag] : -1;
@@ -656,10 +751,11 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 			int pkey = 0;
 #pragma unroll
 			for(int d = 0; d < 3; ++d) {
-				const int pb = (int) __builtin_roundf((pos[d] + vel[d] * new_dt) * dx_inv) - 1;
+				const int pb = (int) __builtin_rintf((pos[d] + vel[d] * new_dt) * dx_inv) - 1;// a prediction: ties do not matter
 				const int nk = min(max(((nbase[d] - 1) & 3) + 1 + (pb - nbase[d]), 0), 5);
 				pkey		 = pkey * 6 + nk;
 			}
+			chain.template at<1>();
 			const int rec	= (ntag << tag_shift) | (pkey << key_shift) | pidib;
 			const bool stay = dno >= 0 && ntag == kStay;
 			// particles that stay in this block share one wave-aggregated atomic
@@ -676,6 +772,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 				if(dno < 0) atomicAdd(&status[ST_LOST], 1);// reference: particle silently lost (particle_buffer.cuh:105-113)
 				if(!in_arena) atomicAdd(&status[ST_ARENA], 1);// (:877-885) contribution discarded
 			}
+			MPM_MARK("stress");
 			// ---- material update, store to the destination bin (coalesced: slot == pidib) (:470-663)
 			float* dst = mv.bins_dst + (size_t) (binoff_dst + (pidib >> 6)) * (NCH * kBin) + (pidib & 63);
 			dst[0]		  = pos[0];
@@ -685,7 +782,9 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 				float Aw[9];
 #pragma unroll
 				for(int d = 0; d < 9; ++d) Aw[d] = A[d] * cfg.dx;
+				chain.template at<2>();
 				const float J = stress_jfluid(mv.mc, st[0], Aw, dt, cfg.d_inv, pl.contrib);
+				chain.template at<3>();
 				dst[3 * kBin] = J;
 			} else {
 				float dws[9], Fold[9], F[9];
@@ -695,30 +794,43 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 					Fold[d] = st[d];
 				}
 				matmul3(dws, Fold, F);
+				chain.template at<2>();
 				if constexpr(ABL & 2) {
 #pragma unroll
 					for(int d = 0; d < 9; ++d) pl.contrib[d] = F[d] * mv.mc.mu;
 					if constexpr(NCH == 13) dst[12 * kBin] = st[9];
+					chain.template range<kPreSites, kPreSites + kStressSites>();
 				} else if constexpr(MAT == 1) {
-					stress_fixed_corotated(mv.mc, F, pl.contrib);
+					stress_fixed_corotated<kPreSites>(mv.mc, F, pl.contrib, chain);
 				} else if constexpr(MAT == 2) {
 					float lj = st[9];
-					stress_sand(mv.mc, F, lj, pl.contrib);
+					stress_sand<kPreSites>(mv.mc, F, lj, pl.contrib, chain, dst + 3 * kBin, kBin);
 					dst[12 * kBin] = lj;
 				} else {
 					float lj = st[9];
-					stress_nacc(mv.mc, F, lj, pl.contrib);
+					stress_nacc<kPreSites>(mv.mc, F, lj, pl.contrib, chain);
 					dst[12 * kBin] = lj;
 				}
+				if constexpr(MAT != 2 || (ABL & 2)) {
 #pragma unroll
-				for(int d = 0; d < 9; ++d) dst[(3 + d) * kBin] = F[d];
+					for(int d = 0; d < 9; ++d) dst[(3 + d) * kBin] = F[d];
+				}
 			}
+			MPM_MARK("tail");
 			// (:850) contrib = (A m - contrib new_dt) D^-1, pre-multiplied by dx so that P2G can stay in cell units
 			{
 				const float am = mass * cfg.dx * cfg.dx * cfg.d_inv;
 				const float cs = new_dt * cfg.d_inv * cfg.dx;
 #pragma unroll
 				for(int d = 0; d < 9; ++d) pl.contrib[d] = A[d] * am - pl.contrib[d] * cs;
+			}
+			chain.template at<kSites - 1>();
+			// ---- the lanes that lost the claim scatter now (rare: a partial or overflowing sort round)
+			if constexpr(!(ABL & 1)) {
+				if(have_prev) {
+					const bool lost = pv_in && !win;
+					if(__any(lost)) p2g_resolve(p2g, s_owner, lost, pv_key, pv_off, pv, mass, lane);
+				}
 			}
 			if constexpr(ABL & 32) {
 #pragma unroll
@@ -736,6 +848,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 						mv.list_out[(size_t) dno * cfg.ppb + slot] = rec;
 				}
 			}
+			MPM_MARK("loop_end");
 			touch(pf);// the next iteration's particle data must have arrived by now
 			MPM_TICK(5)
 			// ---- hand the payload to the next iteration's fused gather/scatter (:887-905)
@@ -777,7 +890,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 		MPM_TICK(7)
 		if(lane == 0) {
 #pragma unroll
-			for(int i = 0; i < 9; ++i) atomicAdd(&g_prof[blockIdx.x & 1023][i], t_acc[i]);
+			for(int i = 0; i < 12; ++i) atomicAdd(&g_prof[blockIdx.x & 1023][i], t_acc[i]);
 		}
 	}
 }
@@ -938,7 +1051,7 @@ __global__ void rasterize_kernel(GridCfg cfg, size_t n, const float* __restrict_
 	float w[3][3];
 	for(int d = 0; d < 3; ++d) {
 		const float p = xyz[3 * pi + d] * cfg.dx_inv;
-		base[d]		  = (int) __builtin_roundf(p) - 1;
+		base[d]		  = lround_pos(p) - 1;
 		bspline_weight_cells(p - (float) base[d], w[d]);
 	}
 	for(int i = 0; i < 3; ++i)
