@@ -478,62 +478,80 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 
 	const int lane = threadIdx.x;
 	const int b	   = block_list ? block_list[blockIdx.x] : (int) blockIdx.x;
-	const int size = mv.size[b];
+	// The per-block set-up is a chain of dependent global round trips (~2-4 us each under load, ~8 per block would be a
+	// third of the kernel): they are arranged in three waves of independent loads, and the LDS-only sort runs in the
+	// shadow of the last one.
+	// ---- round trip 1: everything addressed by the block number alone
+	const int size		 = mv.size[b];
+	const int kx = cur_keys[3 * b], ky = cur_keys[3 * b + 1], kz = cur_keys[3 * b + 2];
+	const int row		 = mv.row_of[b];
+	const int binoff_dst = mv.binoff_dst[b];
 	if(size == 0) return;// (:692-697)
 	unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};// [9] fused iterations, [10] conflict-retry passes, [11] mispredicted keys
 	unsigned long long t_last	= 0;
 	if constexpr(ABL & 32) t_last = __builtin_readcyclecounter();
-	const int kx = cur_keys[3 * b], ky = cur_keys[3 * b + 1], kz = cur_keys[3 * b + 2];
-
+	const int* list		 = mv.list_in + (size_t) row * cfg.ppb;
+	const float dx_inv	 = cfg.dx_inv;
+	const float scale	 = 4.f * cfg.dx_inv;// dx * D^-1 (settings.h:66): A is accumulated in cell units
+	const float mass	 = mv.mc.mass;
+	const int key_shift = cfg.pid_bits;
+	const int tag_shift = cfg.pid_bits + kKeyBits;
+	const unsigned rec_mask = (1u << (tag_shift + 5)) - 1u;
+	// ---- round trip 2: the first chunk's advection records (unconditional, clamped) and the 27 + 27 + 8 table look-ups
+	unsigned recs[kSortChunk / 64];
+	auto load_records = [&](int chunk0) {
+		const int last = min(kSortChunk, size - chunk0) - 1;
+#pragma unroll
+		for(int it = 0; it < kSortChunk / 64; ++it) recs[it] = (unsigned) list[chunk0 + min(it * 64 + lane, last)];
+	};
+	load_records(0);
+	int srcno = -1;
 	if(lane < 27) {
 		int ox, oy, oz;
 		dir_components(lane, ox, oy, oz);
-		const int srcno	   = table_query(cfg, prev_table, kx + ox, ky + oy, kz + oz);
-		s_src_binoff[lane] = srcno >= 0 ? mv.binoff_src[srcno] : -1;
-		s_dst_no[lane]	   = table_query(cfg, cur_table, kx - ox, ky - oy, kz - oz);
+		srcno		   = table_query(cfg, prev_table, kx + ox, ky + oy, kz + oz);
+		s_dst_no[lane] = table_query(cfg, cur_table, kx - ox, ky - oy, kz - oz);
 	} else if(lane >= 32 && lane < 40) {
 		const int lb = lane - 32;
 		s_nb[lb]	 = table_query(cfg, cur_table, kx + ((lb >> 2) & 1), ky + ((lb >> 1) & 1), kz + (lb & 1));
 	}
 	for(int i = lane; i < kArenaNodes; i += 64) p2g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 	__syncthreads();
+	// ---- round trip 3: source bin offsets and the 8 grid blocks (lane = cell -> 256-B rows per channel, :699-727); both
+	//      are consumed after the first chunk's sort
+	const int src_binoff = srcno >= 0 ? mv.binoff_src[srcno] : -1;
 	const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;// lane == cell of a 4x4x4 block
-	{// stage the 8 grid blocks: lane = cell -> 256-B rows per channel (:699-727)
-		float4 v[8];
+	float4 gv[8];
 #pragma unroll
-		for(int lb = 0; lb < 8; ++lb) {
-			const int nb	= s_nb[lb];
-			const float* gb = grid + (size_t) (nb < 0 ? 0 : nb) * 256;
-			v[lb].x			= gb[64 + lane];
-			v[lb].y			= gb[128 + lane];
-			v[lb].z			= gb[192 + lane];
-			v[lb].w			= 0.f;
-			if(nb < 0) v[lb].x = v[lb].y = v[lb].z = 0.f;
-		}
+	for(int lb = 0; lb < 8; ++lb) {
+		const int nb	= s_nb[lb];
+		const float* gb = grid + (size_t) (nb < 0 ? 0 : nb) * 256;
+		gv[lb].x		= gb[64 + lane];
+		gv[lb].y		= gb[128 + lane];
+		gv[lb].z		= gb[192 + lane];
+		gv[lb].w		= 0.f;
+		if(nb < 0) gv[lb].x = gv[lb].y = gv[lb].z = 0.f;
+	}
+	auto stage_grid = [&]() {
+		if(lane < 27) s_src_binoff[lane] = src_binoff;
 #pragma unroll
 		for(int lb = 0; lb < 8; ++lb) {
 			const int ax = cx + ((lb & 4) ? 4 : 0) - 1, ay = cy + ((lb & 2) ? 4 : 0) - 1, az = cz + ((lb & 1) ? 4 : 0) - 1;
-			if(((unsigned) ax < 6u) & ((unsigned) ay < 6u) & ((unsigned) az < 6u)) g2p[ax * kG2PStrideX + ay * 8 + az] = v[lb];
+			if(((unsigned) ax < 6u) & ((unsigned) ay < 6u) & ((unsigned) az < 6u)) g2p[ax * kG2PStrideX + ay * 8 + az] = gv[lb];
 		}
-	}
-
-	const int row		 = mv.row_of[b];
-	const int* list		 = mv.list_in + (size_t) row * cfg.ppb;
-	const float dx_inv	 = cfg.dx_inv;
-	const float scale	 = 4.f * cfg.dx_inv;// dx * D^-1 (settings.h:66): A is accumulated in cell units
-	const float mass	 = mv.mc.mass;
-	const int binoff_dst = mv.binoff_dst[b];
-	const int key_shift = cfg.pid_bits;
-	const int tag_shift = cfg.pid_bits + kKeyBits;
-	const unsigned rec_mask = (1u << (tag_shift + 5)) - 1u;
+	};
 
 	MPM_TICK(6)
-	for(int chunk0 = 0; chunk0 < size; chunk0 += kSortChunk) {
-		const int nrec = min(kSortChunk, size - chunk0);
+	// The first chunk is sorted here, while round trip 3 is in flight; further chunks (blocks with more than 1024
+	// particles) at the bottom of the chunk loop.  (A lambda inlined twice rather than a loop-carried `recs`: the
+	// records would otherwise occupy 16 registers throughout the main loop.)
+	auto sort_chunk = [&](int nrec) {
 		// ---- counting sort of the chunk's records into "k-th particle of every cell" order, so that the 64 lanes
 		//      of one iteration hold particles of 64 distinct cells (replaces cell_bucket_to_block, :70-84)
 		if constexpr(ABL & 8) {
-			for(int idx = lane; idx < nrec; idx += 64) s_sorted[idx] = list[chunk0 + idx];
+#pragma unroll
+			for(int it = 0; it < kSortChunk / 64; ++it)
+				if(it * 64 + lane < nrec) s_sorted[it * 64 + lane] = (int) recs[it];
 			__syncthreads();
 		} else {
 		// The sort key is the stencil base the particle is PREDICTED to have after this step's advection (computed one
@@ -549,7 +567,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 			const int idx = it * 64 + lane;
 			packed[it]	  = 0u;
 			if(idx < nrec) {
-				const unsigned rec = (unsigned) list[chunk0 + idx] & rec_mask;
+				const unsigned rec = recs[it] & rec_mask;
 				const int c		   = (rec >> key_shift) & 255;
 				const int k		   = atomicAdd(&s_cnt[c], 1);// ds_add_rtn_u32: integer LDS atomics run at full rate
 				packed[it]		   = rec | ((unsigned) min(k, kSortRounds) << 26);
@@ -603,6 +621,13 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 		}
 		__syncthreads();
 		}
+	};
+	sort_chunk(min(kSortChunk, size));
+	stage_grid();// the grid blocks and bin offsets requested before the sort have arrived by now
+	__syncthreads();
+	MPM_TICK(0)
+	for(int chunk0 = 0;;) {
+		const int nrec = min(kSortChunk, size - chunk0);
 
 		// Software prefetch: the particle data of iteration i+1 is requested at the top of iteration i (HBM latency under
 		// load is 2-4 us and only two waves share a SIMD).  Two details keep the compiler's s_waitcnt insertion from
@@ -642,7 +667,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 		Prefetch pf;
 		fetch(0, pf);
 		touch(pf);
-		MPM_TICK(0)
+		MPM_TICK(1)
 		// Software pipeline: the scatter of iteration i-1 (an ordered chain of 27 LDS round trips) is issued inside
 		// the gather of iteration i; `pv` is the payload in flight.
 		P2GPayload pv;
@@ -871,6 +896,11 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 		}
 		__syncthreads();
 		MPM_TICK(3)
+		chunk0 += kSortChunk;
+		if(chunk0 >= size) break;
+		load_records(chunk0);
+		sort_chunk(min(kSortChunk, size - chunk0));
+		MPM_TICK(0)
 	}
 	// ---- arena -> next grid: one hardware f32 atomic per touched node, 256-B rows (:907-936)
 #pragma unroll
