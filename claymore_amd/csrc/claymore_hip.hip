@@ -225,15 +225,15 @@ void mpm_destroy(mpm_ctx* ctx) {
 	hipSetDevice(ctx->device);
 	hipDeviceSynchronize();
 	if(ctx->ablate & 32) {// phase timing of the profiling build (see g_prof in mpm_kernels.hpp)
-		std::vector<unsigned long long> rows(1024 * 16);
-		unsigned long long h[16] = {};
+		std::vector<unsigned long long> rows(1024 * 20);
+		unsigned long long h[20] = {};
 		if(hipMemcpyFromSymbol(rows.data(), HIP_SYMBOL(mpm::g_prof), rows.size() * sizeof(unsigned long long)) == hipSuccess) {
 			for(int r = 0; r < 1024; ++r)
-				for(int i = 0; i < 16; ++i) h[i] += rows[r * 16 + i];
-			static const char* nm[12] = {"sort", "wait_prefetch", "claim", "gather+scatter", "stress+stores", "rebucket", "prologue", "epilogue", "iterations", "fused", "not_fused", "mispredicted"};
+				for(int i = 0; i < 20; ++i) h[i] += rows[r * 20 + i];
+			static const char* nm[20] = {"sort(later chunks)", "wait_prefetch", "claim", "gather+chain", "stress+chain", "tail", "tables+zero", "epilogue", "iterations", "fused", "not_fused", "mispredicted", "round trip 1", "rt2 issue+zero", "sort pass 1", "sort masks", "sort placement", "stage grid (rt3)", "", ""};
 			unsigned long long tot = 0;
-			for(int i = 0; i < 8; ++i) tot += h[i];
-			for(int i = 0; i < 12; ++i) fprintf(stderr, "[g2p2g prof] %-16s %14llu  %5.1f %%  %8.0f cycles/iteration\n", nm[i], h[i], i < 8 ? 100.0 * h[i] / (double) tot : 0.0, h[8] ? (double) h[i] / (double) h[8] : 0.0);
+			for(int i = 0; i < 20; ++i) tot += (i >= 8 && i < 12) ? 0 : h[i];
+			for(int i = 0; i < 18; ++i) fprintf(stderr, "[g2p2g prof] %-18s %14llu  %5.1f %%  %8.0f cycles/iteration\n", nm[i], h[i], (i < 8 || i >= 12) ? 100.0 * h[i] / (double) tot : 0.0, h[8] ? (double) h[i] / (double) h[8] : 0.0);
 		}
 	}
 	for(int i = 0; i < 2; ++i) {

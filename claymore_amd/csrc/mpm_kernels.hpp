@@ -240,117 +240,77 @@ __device__ __forceinline__ void p2g_scatter_rmw(float4* __restrict__ node0, cons
 	}
 }
 
-typedef float v4f __attribute__((ext_vector_type(4)));
-
 // Tensor-product B-spline gather of one particle per lane (:801-835): vel = sum W v, A = sum W v (x_i - x_p)^T in cell
-// units.  With FUSED the 27 read-modify-write steps of the PREVIOUS iteration's scatter are issued in between (3 per
-// (i,j) group): each step is an LDS round trip whose latency is otherwise exposed (the steps are ordered - see
-// p2g_scatter_rmw - so they cannot overlap each other), while the gather is pure VALU work plus independent LDS reads.
-// The arena accesses are volatile vector accesses: the compiler keeps their order, everything else floats around them.
-template<bool FUSED>
-__device__ __forceinline__ void gather_and_scatter(const float4* __restrict__ gbase, const float (&w)[3][3], const float (&fd)[3], float (&vel)[3], float (&A)[9], float4* pnode0, const P2GPayload& pp, float mass) {
-	float wp[3][3];// w * (node - particle) per axis
+// units, separable over the three axes (27 x 6 + 9 x 9 + 3 x 12 multiply-adds instead of 27 x 12).  Written on float2
+// so that the x and y components, and the (w, w (x_i - x_p)) weight pairs, go through packed fp32 FMAs (v_pk_fma_f32 with
+// op_sel broadcasts): 3 packed instructions per node instead of 6 scalar ones.
+constexpr int kGatherSites = 9;
+template<int BASE, class Hook>
+__device__ __forceinline__ void gather_apic(const float4* __restrict__ gbase, const float (&w)[3][3], const float (&fd)[3], float (&vel)[3], float (&A)[9], Hook& hk) {
+	v2f wz[3], wy[3], wx[3];// {w, w * (node - particle)} per axis and stencil offset
 #pragma unroll
-	for(int d = 0; d < 3; ++d) {
-#pragma unroll
-		for(int t = 0; t < 3; ++t) wp[d][t] = w[d][t] * ((float) t - fd[d]);
+	for(int t = 0; t < 3; ++t) {
+		wx[t] = (v2f) {w[0][t], w[0][t] * ((float) t - fd[0])};
+		wy[t] = (v2f) {w[1][t], w[1][t] * ((float) t - fd[1])};
+		wz[t] = (v2f) {w[2][t], w[2][t] * ((float) t - fd[2])};
 	}
-	float pw[3][3];
-	v2f c12 = {0.f, 0.f};
-	if constexpr(FUSED) {
-#pragma unroll
-		for(int d = 0; d < 3; ++d) bspline_weight_cells(pp.fd[d], pw[d]);
-		c12 = (v2f) {pp.contrib[7], pp.contrib[8]};
+	v2f vel_xy = {0.f, 0.f}, A0_xy = {0.f, 0.f}, A3_xy = {0.f, 0.f}, A6_xy = {0.f, 0.f};
+	v2f velz_A2 = {0.f, 0.f};
+	float A5 = 0.f, A8 = 0.f;
+	v2f u0_xy, uy_xy, uz_xy, u0z_uyz;
+	float uzz;
+#define MPM_GATHER_ROW(i, j)                                                     \
+	{                                                                            \
+		v2f t0_xy = {0.f, 0.f}, t1_xy = {0.f, 0.f}, t0z_t1z = {0.f, 0.f};        \
+		_Pragma("unroll") for(int k = 0; k < 3; ++k) {                           \
+			const float4 v = gbase[i * kG2PStrideX + j * 8 + k];                 \
+			const v2f vxy  = {v.x, v.y};                                         \
+			t0_xy		   = vxy * wz[k].x + t0_xy;                              \
+			t1_xy		   = vxy * wz[k].y + t1_xy;                              \
+			t0z_t1z		   = wz[k] * v.z + t0z_t1z;                              \
+		}                                                                        \
+		if(j == 0) {                                                             \
+			u0_xy = uy_xy = uz_xy = u0z_uyz = (v2f) {0.f, 0.f};                  \
+			uzz											= 0.f;                   \
+		}                                                                        \
+		u0_xy	= t0_xy * wy[j].x + u0_xy;                                       \
+		uy_xy	= t0_xy * wy[j].y + uy_xy;                                       \
+		uz_xy	= t1_xy * wy[j].x + uz_xy;                                       \
+		u0z_uyz = wy[j] * t0z_t1z.x + u0z_uyz;                                   \
+		uzz += wy[j].x * t0z_t1z.y;                                              \
+		if(j == 2) {                                                             \
+			vel_xy	= u0_xy * wx[i].x + vel_xy;                                  \
+			A0_xy	= u0_xy * wx[i].y + A0_xy;                                   \
+			A3_xy	= uy_xy * wx[i].x + A3_xy;                                   \
+			A6_xy	= uz_xy * wx[i].x + A6_xy;                                   \
+			velz_A2 = wx[i] * u0z_uyz.x + velz_A2;                               \
+			A5 += wx[i].x * u0z_uyz.y;                                           \
+			A8 += wx[i].x * uzz;                                                 \
+		}                                                                        \
+		hk.template at<BASE + 3 * i + j>();                                      \
 	}
-	if constexpr(FUSED) {
-		// A compiler barrier after every step pins the LDS operations in program order: {gather read k, scatter read k}
-		// -> ~14 VALU of gather + scatter arithmetic that need only the gather read -> add, scatter write k.  The
-		// arithmetic therefore sits in the shadow of the scatter's LDS round trip instead of in front of it.
-		// (volatile accesses would do the same but defeat address-space inference: they become flat_load/flat_store.)
-		float4* pn		 = pnode0;
-		const float4* gv = gbase;
-#pragma unroll
-		for(int i = 0; i < 3; ++i) {
-			float u0[3] = {0.f, 0.f, 0.f}, uy[3] = {0.f, 0.f, 0.f}, uz[3] = {0.f, 0.f, 0.f};
-			const float ppx = (float) i - pp.fd[0];
-#pragma unroll
-			for(int j = 0; j < 3; ++j) {
-				const float ppy	 = (float) j - pp.fd[1];
-				const float pwij = pw[0][i] * pw[1][j];
-				const float b0	 = pp.mv[0] + pp.contrib[0] * ppx + pp.contrib[3] * ppy;
-				const v2f b12	 = {pp.mv[1] + pp.contrib[1] * ppx + pp.contrib[4] * ppy, pp.mv[2] + pp.contrib[2] * ppx + pp.contrib[5] * ppy};
-				float t0[3] = {0.f, 0.f, 0.f}, t1[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-				for(int k = 0; k < 3; ++k) {
-					const float4 v	 = gv[i * kG2PStrideX + j * 8 + k];
-					const int o		 = i * kArenaStrideX + j * 8 + k;
-					const float4 acc = pn[o];
-					t0[0] += w[2][k] * v.x;
-					t0[1] += w[2][k] * v.y;
-					t0[2] += w[2][k] * v.z;
-					t1[0] += wp[2][k] * v.x;
-					t1[1] += wp[2][k] * v.y;
-					t1[2] += wp[2][k] * v.z;
-					const float ppz = (float) k - pp.fd[2];
-					const float W	= pwij * pw[2][k];
-					const v2f m0	= {mass, b0 + pp.contrib[6] * ppz};
-					const v2f t12	= c12 * ppz + b12;
-					v2f a01			= {acc.x, acc.y};
-					v2f a23			= {acc.z, acc.w};
-					a01				= m0 * W + a01;
-					a23				= t12 * W + a23;
-					pn[o]			= make_float4(a01.x, a01.y, a23.x, a23.y);
-					__asm__ volatile("" ::: "memory");
-				}
-#pragma unroll
-				for(int d = 0; d < 3; ++d) {
-					u0[d] += w[1][j] * t0[d];
-					uy[d] += wp[1][j] * t0[d];
-					uz[d] += w[1][j] * t1[d];
-				}
-			}
-#pragma unroll
-			for(int d = 0; d < 3; ++d) {
-				vel[d] += w[0][i] * u0[d];
-				A[d] += wp[0][i] * u0[d];
-				A[3 + d] += w[0][i] * uy[d];
-				A[6 + d] += w[0][i] * uz[d];
-			}
-		}
-	} else {
-#pragma unroll
-		for(int i = 0; i < 3; ++i) {
-			float u0[3] = {0.f, 0.f, 0.f}, uy[3] = {0.f, 0.f, 0.f}, uz[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-			for(int j = 0; j < 3; ++j) {
-				const float4 v0 = gbase[i * kG2PStrideX + j * 8 + 0];
-				const float4 v1 = gbase[i * kG2PStrideX + j * 8 + 1];
-				const float4 v2 = gbase[i * kG2PStrideX + j * 8 + 2];
-				const float t0x = w[2][0] * v0.x + w[2][1] * v1.x + w[2][2] * v2.x;
-				const float t0y = w[2][0] * v0.y + w[2][1] * v1.y + w[2][2] * v2.y;
-				const float t0z = w[2][0] * v0.z + w[2][1] * v1.z + w[2][2] * v2.z;
-				const float t1x = wp[2][0] * v0.x + wp[2][1] * v1.x + wp[2][2] * v2.x;
-				const float t1y = wp[2][0] * v0.y + wp[2][1] * v1.y + wp[2][2] * v2.y;
-				const float t1z = wp[2][0] * v0.z + wp[2][1] * v1.z + wp[2][2] * v2.z;
-				u0[0] += w[1][j] * t0x;
-				u0[1] += w[1][j] * t0y;
-				u0[2] += w[1][j] * t0z;
-				uy[0] += wp[1][j] * t0x;
-				uy[1] += wp[1][j] * t0y;
-				uy[2] += wp[1][j] * t0z;
-				uz[0] += w[1][j] * t1x;
-				uz[1] += w[1][j] * t1y;
-				uz[2] += w[1][j] * t1z;
-			}
-#pragma unroll
-			for(int d = 0; d < 3; ++d) {
-				vel[d] += w[0][i] * u0[d];
-				A[d] += wp[0][i] * u0[d];
-				A[3 + d] += w[0][i] * uy[d];
-				A[6 + d] += w[0][i] * uz[d];
-			}
-		}
-	}
+	MPM_GATHER_ROW(0, 0)
+	MPM_GATHER_ROW(0, 1)
+	MPM_GATHER_ROW(0, 2)
+	MPM_GATHER_ROW(1, 0)
+	MPM_GATHER_ROW(1, 1)
+	MPM_GATHER_ROW(1, 2)
+	MPM_GATHER_ROW(2, 0)
+	MPM_GATHER_ROW(2, 1)
+	MPM_GATHER_ROW(2, 2)
+#undef MPM_GATHER_ROW
+	vel[0] = vel_xy.x;
+	vel[1] = vel_xy.y;
+	vel[2] = velz_A2.x;
+	A[0]   = A0_xy.x;
+	A[1]   = A0_xy.y;
+	A[2]   = velz_A2.y;
+	A[3]   = A3_xy.x;
+	A[4]   = A3_xy.y;
+	A[5]   = A5;
+	A[6]   = A6_xy.x;
+	A[7]   = A6_xy.y;
+	A[8]   = A8;
 }
 
 // The P2G scatter of one particle per lane as a chain of 27 ordered LDS read-modify-write steps that is threaded
@@ -444,7 +404,7 @@ __device__ __forceinline__ void p2g_resolve(float4* __restrict__ arena, unsigned
 // Phase timing (ABL & 32, profiling builds only): wall cycles (s_memtime) that wave 0..n spend in each part of the
 // iteration, summed over all waves.  [0] sort, [1] wait for prefetched particle data, [2] claim, [3] gather+scatter,
 // [4] F update + stress + particle stores, [5] re-bucket / list append, [6] prologue, [7] epilogue, [8] iterations.
-__device__ unsigned long long g_prof[1024][16];// spread over 1024 rows: same-address atomics serialise
+__device__ unsigned long long g_prof[1024][20];// spread over 1024 rows: same-address atomics serialise
 #define MPM_TICK(slot) \
 	if constexpr(ABL & 32) { \
 		__asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
@@ -487,9 +447,11 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 	const int row		 = mv.row_of[b];
 	const int binoff_dst = mv.binoff_dst[b];
 	if(size == 0) return;// (:692-697)
-	unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};// [9] fused iterations, [10] conflict-retry passes, [11] mispredicted keys
+	unsigned long long t_acc[20] = {};// [9] fused iterations, [10] conflict-retry passes, [11] mispredicted keys
 	unsigned long long t_last	= 0;
 	if constexpr(ABL & 32) t_last = __builtin_readcyclecounter();
+	__asm__ volatile("" ::"s"(row), "s"(binoff_dst), "s"(kz));
+	MPM_TICK(12)
 	const int* list		 = mv.list_in + (size_t) row * cfg.ppb;
 	const float dx_inv	 = cfg.dx_inv;
 	const float scale	 = 4.f * cfg.dx_inv;// dx * D^-1 (settings.h:66): A is accumulated in cell units
@@ -517,6 +479,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 	}
 	for(int i = lane; i < kArenaNodes; i += 64) p2g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 	__syncthreads();
+	MPM_TICK(13)
 	// ---- round trip 3: source bin offsets and the 8 grid blocks (lane = cell -> 256-B rows per channel, :699-727); both
 	//      are consumed after the first chunk's sort
 	const int src_binoff = srcno >= 0 ? mv.binoff_src[srcno] : -1;
@@ -574,6 +537,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 			}
 		}
 		__syncthreads();
+		MPM_TICK(14)
 		{
 			int my[4];
 			int maxc = 0;
@@ -603,6 +567,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 			s_cnt[lane] = 0;
 		}
 		__syncthreads();
+		MPM_TICK(15)
 #pragma unroll
 		for(int it = 0; it < kSortChunk / 64; ++it) {
 			if(it * 64 + lane < nrec) {
@@ -623,9 +588,10 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 		}
 	};
 	sort_chunk(min(kSortChunk, size));
+	MPM_TICK(16)
 	stage_grid();// the grid blocks and bin offsets requested before the sort have arrived by now
 	__syncthreads();
-	MPM_TICK(0)
+	MPM_TICK(17)
 	for(int chunk0 = 0;;) {
 		const int nrec = min(kSortChunk, size - chunk0);
 
@@ -725,12 +691,16 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 			}
 			MPM_MARK("gather");
 			MPM_TICK(2)
+			constexpr int kPreSites = kGatherSites + 3, kStressSites = MAT == 0 ? 1 : (MAT == 1 ? kFcSites : (MAT == 2 ? kSandSites : kNaccSites));
+			constexpr int kSites	= kPreSites + kStressSites + 1;
+			ScatterChain<kSites> chain(p2g + pv_off, pv, mass, win);
 			if constexpr(ABL & 4) {
+				chain.template range<0, kGatherSites>();
 				const float4 v = gbase[0];
 				vel[0] = v.x * w[0][0]; vel[1] = v.y * w[1][1]; vel[2] = v.z * w[2][2];
 				A[0] = v.x * fd[0]; A[4] = v.y * fd[1]; A[8] = v.z * fd[2];
 			} else {
-				gather_and_scatter<false>(gbase, w, fd, vel, A, p2g, pv, mass);
+				gather_apic<0>(gbase, w, fd, vel, A, chain);
 			}
 			if constexpr(ABL & 32) {
 #pragma unroll
@@ -738,9 +708,6 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 			}
 			MPM_TICK(3)
 			MPM_MARK("rebucket");
-			constexpr int kPreSites = 3, kStressSites = MAT == 0 ? 1 : (MAT == 1 ? kFcSites : (MAT == 2 ? kSandSites : kNaccSites));
-			constexpr int kSites	= kPreSites + kStressSites + 1;
-			ScatterChain<kSites> chain(p2g + pv_off, pv, mass, win);
 			P2GPayload pl;
 			// Every lane runs the whole body: the idle lanes of a last partial iteration carry a dummy particle and write
 			// it into the padding slots of the block's last bin (slot == pidib < 64 * ceil(size / 64), allocated but never
@@ -764,7 +731,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 				narena[d]	  = arena[d] + (nbase[d] - base[d]);
 				in_arena &= (narena[d] >= 0) & (narena[d] + 2 < 8);
 			}
-			chain.template at<0>();
+			chain.template at<kGatherSites + 0>();
 			const int key	  = narena[0] * 36 + narena[1] * 6 + narena[2];
 			const int nodeoff = narena[0] * kArenaStrideX + narena[1] * 8 + narena[2];
 			if constexpr(ABL & 32) t_acc[11] += __popcll(__ballot(in_arena && key != predicted_key));
@@ -780,7 +747,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 				const int nk = min(max(((nbase[d] - 1) & 3) + 1 + (pb - nbase[d]), 0), 5);
 				pkey		 = pkey * 6 + nk;
 			}
-			chain.template at<1>();
+			chain.template at<kGatherSites + 1>();
 			const int rec	= (ntag << tag_shift) | (pkey << key_shift) | pidib;
 			const bool stay = dno >= 0 && ntag == kStay;
 			// particles that stay in this block share one wave-aggregated atomic
@@ -807,9 +774,9 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 				float Aw[9];
 #pragma unroll
 				for(int d = 0; d < 9; ++d) Aw[d] = A[d] * cfg.dx;
-				chain.template at<2>();
+				chain.template at<kGatherSites + 2>();
 				const float J = stress_jfluid(mv.mc, st[0], Aw, dt, cfg.d_inv, pl.contrib);
-				chain.template at<3>();
+				chain.template at<kPreSites>();
 				dst[3 * kBin] = J;
 			} else {
 				float dws[9], Fold[9], F[9];
@@ -819,7 +786,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 					Fold[d] = st[d];
 				}
 				matmul3(dws, Fold, F);
-				chain.template at<2>();
+				chain.template at<kGatherSites + 2>();
 				if constexpr(ABL & 2) {
 #pragma unroll
 					for(int d = 0; d < 9; ++d) pl.contrib[d] = F[d] * mv.mc.mu;
@@ -920,7 +887,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 		MPM_TICK(7)
 		if(lane == 0) {
 #pragma unroll
-			for(int i = 0; i < 12; ++i) atomicAdd(&g_prof[blockIdx.x & 1023][i], t_acc[i]);
+			for(int i = 0; i < 20; ++i) atomicAdd(&g_prof[blockIdx.x & 1023][i], t_acc[i]);
 		}
 	}
 }
