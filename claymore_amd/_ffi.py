@@ -15,7 +15,7 @@ MATERIAL_NAMES = {"jfluid": J_FLUID, "fixed_corotated": FIXED_COROTATED, "sand":
 class Config(C.Structure):
     _fields_ = [("domain_bits", C.c_int), ("max_ppc", C.c_int), ("boundary_blocks", C.c_int),
                 ("gravity", C.c_float), ("cfl", C.c_float), ("max_blocks", C.c_int64),
-                ("reserved", C.c_int * 6)]
+                ("grow", C.c_int), ("reserved", C.c_int * 5)]
 
 
 class MaterialParams(C.Structure):
@@ -85,6 +85,7 @@ HIP_ONLY = {
     "last_g2p2g_ms": (_i, [_vp, _fp]),
     "streams": (_i, [_vp, _P(_vp), _P(_vp)]),
     "sync": (_i, [_vp]),
+    "get_capacity": (_i, [_vp, _P(C.c_int64), _P(C.c_int64), _ip]),
 }
 
 

@@ -66,6 +66,7 @@ struct mpm_ctx {
 	unsigned long long* d_counter = nullptr;
 	bool ready = false;
 	int ablate = 0;// MPM_G2P2G_ABLATE (profiling only)
+	int capacity_events = 0;// number of capacity growths so far (check_capacity)
 	mpm_timers timers {};
 	float last_g2p2g_ms = 0.f;
 	// halo state (MGSP)
@@ -103,6 +104,20 @@ static hipError_t dalloc(T** p, size_t n) {
 	return hipMalloc((void**) p, sizeof(T) * (n ? n : 1));
 }
 
+// Replace *p (old_n elements) by a zero-initialised array of new_n elements holding the old contents.
+template<typename T>
+static hipError_t regrow(T** p, size_t old_n, size_t new_n, hipStream_t s) {
+	T* q		 = nullptr;
+	hipError_t e = hipMalloc((void**) &q, sizeof(T) * new_n);
+	if(e != hipSuccess) return e;
+	if((e = hipMemsetAsync(q, 0, sizeof(T) * new_n, s)) != hipSuccess) return e;
+	if(*p && old_n && (e = hipMemcpyAsync(q, *p, sizeof(T) * old_n, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
+	if((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+	if(*p) hipFree(*p);
+	*p = q;
+	return hipSuccess;
+}
+
 static inline unsigned cdiv(size_t a, size_t b) {
 	return (unsigned) ((a + b - 1) / b);
 }
@@ -118,6 +133,7 @@ int mpm_default_config(int domain_bits, mpm_config* cfg) {
 	cfg->gravity		 = -9.8f; // settings.h:85
 	cfg->cfl			 = 0.5f;  // settings.h:53
 	cfg->max_blocks		 = 0;
+	cfg->grow			 = 1;
 	return MPM_OK;
 }
 
@@ -556,6 +572,55 @@ static int launch_rebuild(mpm_ctx* ctx) {
 	return MPM_OK;
 }
 
+// check_capacity() (gmpm_simulator.cuh:283-300): once the exterior block count / a model's bin count passes 3/4 of its
+// capacity the capacity grows by 3/2.  Runs at the one host synchronisation of a substep, after the rebuild; every
+// array indexed by block number (keys, grids, lists, sizes, bin offsets, halo lists) or by bin is reallocated and
+// copied.  The dense table is sized by the domain, not by the capacity.
+static int grow_capacity(mpm_ctx* ctx) {
+	if(!ctx->cfg.grow) return MPM_OK;
+	hipStream_t s	   = ctx->s_compute;
+	const size_t table = (size_t) ctx->g.G * ctx->g.G * ctx->g.G;
+	const size_t cap   = (size_t) ctx->g.cap;
+	if((size_t) ctx->ebc * 4 > cap * 3 && cap < table) {
+		const size_t ncap = std::min(table, cap * 3 / 2 + 1);
+		HIP_TRY(hipDeviceSynchronize());// both streams idle: buffers are about to be replaced
+		for(int i = 0; i < 2; ++i) {
+			HIP_TRY(regrow(&ctx->part[i].keys, 3 * cap, 3 * ncap, s));
+			HIP_TRY(regrow(&ctx->grid[i], cap * 256, ncap * 256, s));
+		}
+		for(auto& m: ctx->models) {
+			for(int i = 0; i < 2; ++i) {
+				HIP_TRY(regrow(&m.binoff[i], cap + 1, ncap + 1, s));
+				HIP_TRY(regrow(&m.list[i], cap * (size_t) ctx->g.ppb, ncap * (size_t) ctx->g.ppb, s));
+			}
+			HIP_TRY(regrow(&m.size, cap + 1, ncap + 1, s));
+			HIP_TRY(regrow(&m.row_of, cap + 1, ncap + 1, s));
+			HIP_TRY(regrow(&m.out_count, cap + 1, ncap + 1, s));
+		}
+		if(ctx->d_overlap) {
+			HIP_TRY(regrow(&ctx->d_overlap, cap + 1, ncap + 1, s));
+			HIP_TRY(regrow(&ctx->d_halo_list, cap + 1, ncap + 1, s));
+			HIP_TRY(regrow(&ctx->d_inner_list, cap + 1, ncap + 1, s));
+		}
+		for(int p = 0; p < 32; ++p)
+			if(ctx->d_send_ids[p]) HIP_TRY(regrow(&ctx->d_send_ids[p], cap + 1, ncap + 1, s));
+		ctx->g.cap = (int) ncap;
+		ctx->capacity_events++;
+	}
+	for(auto& m: ctx->models) {
+		// worst case: every block ends with one partially filled bin
+		const size_t need = m.n / kBin + (size_t) ctx->g.cap + 1;
+		if((size_t) m.bincount * 4 > m.bin_cap * 3 || need > m.bin_cap) {
+			const size_t nb = std::max(need, (size_t) m.bincount * 4 > m.bin_cap * 3 ? m.bin_cap * 3 / 2 + 1 : m.bin_cap);
+			HIP_TRY(hipDeviceSynchronize());
+			for(int i = 0; i < 2; ++i) HIP_TRY(regrow(&m.bins[i], m.bin_cap * m.nch * kBin, nb * m.nch * kBin, s));
+			m.bin_cap = nb;
+			ctx->capacity_events++;
+		}
+	}
+	return MPM_OK;
+}
+
 static int finish_rebuild(mpm_ctx* ctx, mpm_counts* counts) {
 	int rc = read_status(ctx);
 	if(rc) return rc;
@@ -573,6 +638,8 @@ static int finish_rebuild(mpm_ctx* ctx, mpm_counts* counts) {
 		m.list_in ^= 1;
 	}
 	ctx->rollid ^= 1;// gmpm_simulator.cuh:578
+	rc = grow_capacity(ctx);
+	if(rc) return rc;
 	if(counts) return mpm_get_counts(ctx, counts);
 	return MPM_OK;
 }
@@ -674,6 +741,15 @@ int mpm_get_counts(mpm_ctx* ctx, mpm_counts* counts) {
 		counts->bins[mi]	  = ctx->models[mi].bincount;
 		counts->particles[mi] = ctx->models[mi].bucketed;
 	}
+	return MPM_OK;
+}
+
+int mpm_get_capacity(mpm_ctx* ctx, int64_t* block_capacity, int64_t* bin_capacity, int* growth_events) {
+	if(!ctx || !ctx->ready) return MPM_ERR_NOT_READY;
+	if(block_capacity) *block_capacity = ctx->g.cap;
+	if(bin_capacity)
+		for(size_t i = 0; i < ctx->models.size() && i < 8; ++i) bin_capacity[i] = (int64_t) ctx->models[i].bin_cap;
+	if(growth_events) *growth_events = ctx->capacity_events;
 	return MPM_OK;
 }
 

@@ -143,6 +143,12 @@ class Engine:
         self._check(self.api.get_counts(self.ctx, C.byref(c)))
         return c
 
+    def capacity(self):
+        """(block capacity, per-model bin capacities, number of growth events) - HIP engine only."""
+        blocks, bins, events = C.c_int64(0), (C.c_int64 * 8)(), C.c_int(0)
+        self._check(self.api.get_capacity(self.ctx, C.byref(blocks), bins, C.byref(events)))
+        return blocks.value, list(bins), events.value
+
     def timers(self):
         t = _ffi.Timers()
         self._check(self.api.get_timers(self.ctx, C.byref(t)))

@@ -56,8 +56,10 @@ typedef struct mpm_config {
 	int boundary_blocks; /* slip-wall zone in blocks; settings.h:63 G_BOUNDARY_CONDITION = 2 */
 	float gravity;		 /* settings.h:85 (-9.8; MGSP settings.h:108 uses -4.9) */
 	float cfl;			 /* utility_funcs.hpp:41 uses 0.5 (MGSP utility_funcs.hpp:39: 0.3) */
-	int64_t max_blocks;	 /* capacity in (exterior) blocks; settings.h:89 G_MAX_ACTIVE_BLOCK; 0 = size from the models */
-	int reserved[6];
+	int64_t max_blocks;	 /* (initial) capacity in (exterior) blocks; settings.h:89 G_MAX_ACTIVE_BLOCK; 0 = size from the models */
+	int grow;			 /* 1 (default): block / bin capacities grow by 3/2 once 3/4 full, like check_capacity()
+							(gmpm_simulator.cuh:283-300); 0: fixed capacities, MPM_ERR_CAPACITY when exceeded */
+	int reserved[5];
 } mpm_config;
 
 /* Material parameter block (Projects/GMPM/particle_buffer.cuh:141-264).  Unused fields are ignored. */
@@ -146,6 +148,10 @@ int mpm_retrieve_positions(mpm_ctx* ctx, int model, float* xyz, size_t* n);
 int mpm_retrieve_state(mpm_ctx* ctx, int model, float* xyz, float* state9, float* logjp, size_t* n);
 
 int mpm_get_counts(mpm_ctx* ctx, mpm_counts* counts);
+
+/* Current capacities and the number of times check_capacity() (gmpm_simulator.cuh:283-300) has grown them: blocks
+ * (exterior count limit), bins per model (bin_capacity[8]).  HIP library only. */
+int mpm_get_capacity(mpm_ctx* ctx, int64_t* block_capacity, int64_t* bin_capacity, int* growth_events);
 int mpm_get_timers(mpm_ctx* ctx, mpm_timers* t);
 /* Sum over the current grid of {mass, momentum x, y, z} (the reference's sum_grid_mass debug kernel,
  * mgmpm_kernels.cuh:1034-1037, extended to momentum); valid between rebuild and the next grid update. */

@@ -98,6 +98,8 @@ int mpmo_default_config(int domain_bits, mpm_config* cfg) {
 	cfg->gravity		 = -9.8f; /* settings.h:85 */
 	cfg->cfl			 = 0.5f;  /* settings.h:53 */
 	cfg->max_blocks		 = 0;
+	cfg->grow			 = 1; /* the oracle does not re-allocate: with grow set, max_blocks is only the INITIAL capacity and the
+						   oracle sizes itself from the models (6 x particle blocks, as with max_blocks = 0) */
 	return MPM_OK;
 }
 
@@ -334,7 +336,7 @@ int mpmo_initial_setup(mpmo_ctx* c) {
 	const int r = c->rollid, n = r ^ 1;
 	/* capacity: count distinct particle blocks first (the reference uses the compile-time G_MAX_ACTIVE_BLOCK) */
 	size_t table = (size_t) c->G * c->G * c->G;
-	if(c->cfg.max_blocks > 0) {
+	if(c->cfg.max_blocks > 0 && !c->cfg.grow) {
 		c->cap = (size_t) c->cfg.max_blocks;
 	} else {
 		unsigned char* seen = (unsigned char*) calloc(table, 1);

@@ -87,6 +87,7 @@ def test_capacity_error_is_reported():
     api = oracle_api()
     sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=3.0)
     sc["config"]["max_blocks"] = 8
+    sc["config"]["grow"] = 0          # fixed capacity: exceeding it is an error (gmpm_simulator.cuh:473-476)
     eng = build_engine(sc, api=api)
     with pytest.raises(Exception):
         eng.initial_setup()

@@ -208,6 +208,50 @@ def test_capacity_overflow_reports_error():
     eng.close()
 
 
+def test_block_capacity_grows_like_check_capacity():
+    """gmpm_simulator.cuh:283-300: capacities grow by 3/2 once 3/4 full.  A run that starts with a block capacity just above
+    its exterior block count grows at the first rebuild and must then follow the same trajectory as a generously sized run."""
+    sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=4.0, speed=2.0)
+    ref = build_engine(sc)
+    ref.initial_setup()
+    ebc = ref.counts().exterior_blocks
+    ref.run_fixed(40, sc["dt"])
+    xyz_ref = ref.retrieve_positions(0)
+    ref.close()
+
+    sc["config"]["max_blocks"] = ebc + 8   # initial capacity, 3/4 rule trips immediately
+    eng = build_engine(sc)
+    eng.initial_setup()
+    cap0, bins0, ev0 = eng.capacity()
+    assert cap0 == ebc + 8 and ev0 == 0
+    eng.run_fixed(40, sc["dt"])
+    cap1, bins1, ev1 = eng.capacity()
+    assert ev1 >= 1 and cap1 >= (cap0 * 3) // 2 and bins1[0] >= bins0[0]
+    xyz = eng.retrieve_positions(0)
+    eng.close()
+    from parity_util import match
+    idx, _ = match(xyz_ref.astype(np.float64), xyz.astype(np.float64))
+    rel = np.abs(xyz[idx].astype(np.float64) - xyz_ref).max(axis=1) / np.abs(xyz_ref).max(axis=1)
+    assert xyz.shape == xyz_ref.shape and rel.max() < POS_TOL, rel.max()
+
+
+def test_fixed_capacity_reports_error_when_exceeded():
+    """grow = 0: the reference's abort path (gmpm_simulator.cuh:473-476) becomes MPM_ERR_CAPACITY."""
+    sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=4.0)
+    probe = build_engine(sc)
+    probe.initial_setup()
+    ebc = probe.counts().exterior_blocks
+    probe.close()
+    sc["config"]["max_blocks"] = ebc - 1
+    sc["config"]["grow"] = 0
+    eng = build_engine(sc)
+    with pytest.raises(Exception) as ei:
+        eng.initial_setup()
+        eng.run_fixed(5, sc["dt"])
+    assert "block" in str(ei.value).lower() or "capacity" in str(ei.value).lower()
+    eng.close()
+
+
 def _dense_cube_scene(ppc_axis=3, cells=8, bits=6, material=_ffi.FIXED_COROTATED):
     """A cube with ppc_axis^3 particles per cell: 27 per cell -> 1728 per block, i.e. more than one 1024-record sort
     chunk and more than kSortRounds (24) particles per sort key - the ragged / overflow paths of the in-LDS sort."""
