@@ -27,6 +27,12 @@ class MaterialParams(C.Structure):
                 ("reserved", C.c_int * 5)]
 
 
+class CollisionObject(C.Structure):
+    _fields_ = [("type", C.c_int), ("friction", C.c_float), ("scale", C.c_float), ("dsdt", C.c_float),
+                ("trans", C.c_float * 3), ("trans_vel", C.c_float * 3), ("omega", C.c_float * 3),
+                ("rot_mat", C.c_float * 9), ("time", C.c_float), ("reserved", C.c_int * 3)]
+
+
 class Counts(C.Structure):
     _fields_ = [("particle_blocks", C.c_int), ("neighbor_blocks", C.c_int), ("exterior_blocks", C.c_int),
                 ("model_count", C.c_int), ("bins", C.c_int64 * 8), ("particles", C.c_int64 * 8)]
@@ -62,6 +68,8 @@ SIGNATURES = {
     "get_timers": (_i, [_vp, _P(Timers)]),
     "grid_totals": (_i, [_vp, _P(C.c_double)]),
     "dump_grid": (_i, [_vp, _vp, _vp, _P(_sz)]),
+    "default_collision_object": (_i, [_P(CollisionObject)]),
+    "set_collision_object": (_i, [_vp, _P(CollisionObject), _vp, _vp, _vp, _vp]),
     "test_svd": (_i, [_vp, _sz, _vp, _i]),
     "test_stress": (_i, [_i, _P(MaterialParams), _vp, _vp, _sz, _vp, _i]),
 }

@@ -67,6 +67,9 @@ struct mpm_ctx {
 	bool ready = false;
 	int ablate = 0;// MPM_G2P2G_ABLATE (profiling only)
 	int capacity_events = 0;// number of capacity growths so far (check_capacity)
+	bool has_collision = false;// level-set collision object of the MGSP grid update
+	CollisionObject collision {};
+	float4* d_sdf = nullptr;
 	mpm_timers timers {};
 	float last_g2p2g_ms = 0.f;
 	// halo state (MGSP)
@@ -252,6 +255,7 @@ void mpm_destroy(mpm_ctx* ctx) {
 			for(int i = 0; i < 18; ++i) fprintf(stderr, "[g2p2g prof] %-18s %14llu  %5.1f %%  %8.0f cycles/iteration\n", nm[i], h[i], (i < 8 || i >= 12) ? 100.0 * h[i] / (double) tot : 0.0, h[8] ? (double) h[i] / (double) h[8] : 0.0);
 		}
 	}
+	hipFree(ctx->d_sdf);
 	for(int i = 0; i < 2; ++i) {
 		hipFree(ctx->part[i].table);
 		hipFree(ctx->part[i].keys);
@@ -439,7 +443,12 @@ int mpm_initial_setup(mpm_ctx* ctx) {
 static int launch_grid_update(mpm_ctx* ctx, float dt) {
 	hipStream_t s = ctx->s_compute;
 	HIP_TRY(hipMemsetAsync(ctx->d_maxvel, 0, sizeof(unsigned), s));
-	if(ctx->nbc) grid_update_kernel<<<cdiv(ctx->nbc, 16), 256, 0, s>>>(ctx->g, ctx->nbc, ctx->grid[0], ctx->part[ctx->rollid].keys, dt, ctx->d_maxvel);
+	if(ctx->nbc) {
+		if(ctx->has_collision)
+			grid_update_collision_kernel<<<cdiv(ctx->nbc, 4), 256, 0, s>>>(ctx->g, ctx->nbc, ctx->grid[0], ctx->part[ctx->rollid].keys, dt, ctx->collision, ctx->d_maxvel);
+		else
+			grid_update_kernel<<<cdiv(ctx->nbc, 16), 256, 0, s>>>(ctx->g, ctx->nbc, ctx->grid[0], ctx->part[ctx->rollid].keys, dt, ctx->d_maxvel);
+	}
 	return MPM_OK;
 }
 
@@ -741,6 +750,54 @@ int mpm_get_counts(mpm_ctx* ctx, mpm_counts* counts) {
 		counts->bins[mi]	  = ctx->models[mi].bincount;
 		counts->particles[mi] = ctx->models[mi].bucketed;
 	}
+	return MPM_OK;
+}
+
+int mpm_default_collision_object(mpm_collision_object* o) {
+	if(!o) return MPM_ERR_INVALID;
+	memset(o, 0, sizeof(*o));
+	o->type		  = MPM_BOUNDARY_STICKY;// boundary_condition.cuh:43-48
+	o->friction	  = 0.3f;
+	o->scale	  = 1.0f;
+	o->dsdt		  = 0.0f;
+	o->rot_mat[0] = o->rot_mat[4] = o->rot_mat[8] = 1.f;
+	return MPM_OK;
+}
+
+int mpm_set_collision_object(mpm_ctx* ctx, const mpm_collision_object* obj, const float* sdf, const float* gx, const float* gy, const float* gz) {
+	if(!ctx) return MPM_ERR_INVALID;
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipDeviceSynchronize());
+	if(ctx->d_sdf) HIP_TRY(hipFree(ctx->d_sdf));
+	ctx->d_sdf		   = nullptr;
+	ctx->has_collision = false;
+	if(!obj) return MPM_OK;
+	if(!sdf || !gx || !gy || !gz) return fail(ctx, MPM_ERR_INVALID, "collision object without a signed distance field");
+	if(obj->type < MPM_BOUNDARY_STICKY || obj->type > MPM_BOUNDARY_SEPARATE) return fail(ctx, MPM_ERR_INVALID, "[ERROR] Wrong Boundary Type!");// boundary_condition.cuh:244
+	const size_t N = (size_t) 1 << ctx->cfg.domain_bits, n = N * N * N;
+	float* stage = nullptr;
+	HIP_TRY(dalloc(&stage, 4 * n));
+	HIP_TRY(dalloc(&ctx->d_sdf, n));
+	const float* src[4] = {sdf, gx, gy, gz};
+	for(int c = 0; c < 4; ++c) HIP_TRY(hipMemcpy(stage + c * n, src[c], sizeof(float) * n, hipMemcpyHostToDevice));
+	pack_sdf_kernel<<<cdiv(n, 256), 256, 0, ctx->s_compute>>>(n, stage, stage + n, stage + 2 * n, stage + 3 * n, ctx->d_sdf);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(ctx->s_compute));
+	HIP_TRY(hipFree(stage));
+	CollisionObject& c = ctx->collision;
+	c.type	   = obj->type;
+	c.friction = obj->friction;
+	c.scale	   = obj->scale;
+	c.dsdt	   = obj->dsdt;
+	for(int d = 0; d < 3; ++d) {
+		c.trans[d]	   = obj->trans[d];
+		c.trans_vel[d] = obj->trans_vel[d];
+		c.omega[d]	   = obj->omega[d];
+	}
+	for(int i = 0; i < 9; ++i) c.rot[i] = obj->rot_mat[i];
+	c.time			   = obj->time;
+	c.field			   = ctx->d_sdf;
+	ctx->has_collision = true;
 	return MPM_OK;
 }
 

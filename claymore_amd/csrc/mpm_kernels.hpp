@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mpm_device_math.hpp"
+#include "mpm_collision.hpp"
 
 namespace mpm {
 
@@ -148,6 +149,53 @@ __global__ __launch_bounds__(256) void grid_update_kernel(GridCfg cfg, int nbloc
 		const unsigned bits = __float_as_uint(vel_sqr);
 		if(bits > __hip_atomic_load(max_vel_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_vel_bits, bits);
 	}
+}
+
+// Grid update with a level-set collision object (second update_grid_velocity_query_max overload,
+// Projects/MGSP/mgmpm_kernels.cuh:323-399): one wave per grid block, lane = cell.  Reports the reference's doubled
+// |v|^2 (vel.dot(vel) followed by the three += of the plain overload, :365-373).
+__global__ __launch_bounds__(256) void grid_update_collision_kernel(GridCfg cfg, int nblocks, float* __restrict__ grid, const int* __restrict__ keys, float dt, CollisionObject obj, unsigned* __restrict__ max_vel_bits) {
+	const int cell	  = threadIdx.x & 63;
+	const int blockno = (blockIdx.x * 256 + threadIdx.x) >> 6;
+	float vel_sqr	  = 0.f;
+	if(blockno < nblocks) {
+		const int kx = keys[3 * blockno], ky = keys[3 * blockno + 1], kz = keys[3 * blockno + 2];
+		const bool wx = kx < cfg.boundary || kx >= cfg.G - cfg.boundary;
+		const bool wy = ky < cfg.boundary || ky >= cfg.G - cfg.boundary;
+		const bool wz = kz < cfg.boundary || kz >= cfg.G - cfg.boundary;
+		float* g		 = grid + (size_t) blockno * 256 + cell;
+		const float mass = g[0];
+		if(mass > 0.0f) {
+			const float mass_inv = 1.f / mass;
+			float vel[3];
+			vel[0] = wx ? 0.0f : g[64] * mass_inv;
+			vel[1] = (wy ? 0.0f : g[128] * mass_inv) + cfg.gravity * dt;
+			vel[2] = wz ? 0.0f : g[192] * mass_inv;
+			const int node[3] = {kx * 4 + (cell >> 4), ky * 4 + ((cell >> 2) & 3), kz * 4 + (cell & 3)};
+			collision_resolve(obj, node, cfg.dx, cfg.G * 4, (float) cfg.boundary * cfg.dx * 4.f, (float) (cfg.G - cfg.boundary) * 4.f * cfg.dx, vel);
+			g[64]	= vel[0];
+			g[128]	= vel[1];
+			g[192]	= vel[2];
+			float q = vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2];
+			q += vel[0] * vel[0];
+			q += vel[1] * vel[1];
+			q += vel[2] * vel[2];
+			if(q != q) q = __builtin_inff();
+			vel_sqr = q;
+		}
+	}
+#pragma unroll
+	for(int off = 32; off > 0; off >>= 1) vel_sqr = fmaxf(vel_sqr, __shfl_xor(vel_sqr, off));
+	if((threadIdx.x & 63) == 0 && vel_sqr > 0.f) {
+		const unsigned bits = __float_as_uint(vel_sqr);
+		if(bits > __hip_atomic_load(max_vel_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_vel_bits, bits);
+	}
+}
+
+// node-major {sdis, gx, gy, gz} from the four per-node arrays the ABI receives
+__global__ __launch_bounds__(256) void pack_sdf_kernel(size_t n, const float* __restrict__ sd, const float* __restrict__ gx, const float* __restrict__ gy, const float* __restrict__ gz, float4* __restrict__ out) {
+	const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+	if(i < n) out[i] = make_float4(sd[i], gx[i], gy[i], gz[i]);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -143,6 +143,29 @@ class Engine:
         self._check(self.api.get_counts(self.ctx, C.byref(c)))
         return c
 
+    def set_collision_object(self, sdf=None, grad=None, **fields):
+        """Install the level-set collision object of the MGSP grid update (MgspBenchmark::init_boundary,
+        mgsp_benchmark.cuh:257-266).  sdf: (N, N, N) float32 node values, grad: (3, N, N, N); fields: type, friction, scale,
+        dsdt, trans, trans_vel, omega, rot_mat, time.  sdf=None removes the object."""
+        if sdf is None:
+            self._check(self.api.set_collision_object(self.ctx, None, None, None, None, None))
+            return
+        obj = _ffi.CollisionObject()
+        self._check(self.api.default_collision_object(C.byref(obj)))
+        for k, v in fields.items():
+            cur = getattr(obj, k)
+            if hasattr(cur, "__len__"):
+                for i, x in enumerate(np.asarray(v, dtype=np.float32).ravel()):
+                    cur[i] = float(x)
+            else:
+                setattr(obj, k, v)
+        n = 1 << self.cfg.domain_bits
+        sdf = np.ascontiguousarray(sdf, dtype=np.float32)
+        grad = np.ascontiguousarray(grad, dtype=np.float32)
+        assert sdf.shape == (n, n, n) and grad.shape == (3, n, n, n), (sdf.shape, grad.shape)
+        self._check(self.api.set_collision_object(self.ctx, C.byref(obj), sdf.ctypes.data, grad[0].ctypes.data,
+                                                  grad[1].ctypes.data, grad[2].ctypes.data))
+
     def capacity(self):
         """(block capacity, per-model bin capacities, number of growth events) - HIP engine only."""
         blocks, bins, events = C.c_int64(0), (C.c_int64 * 8)(), C.c_int(0)
@@ -185,4 +208,6 @@ def build_engine(scene, device=0, api=None):
     eng = Engine(cfg=cfg, device=device, api=a)
     for m in scene["models"]:
         eng.init_model(m["material"], m["xyz"], m.get("v0", (0, 0, 0)), **m.get("params", {}))
+    if scene.get("collision"):
+        eng.set_collision_object(**scene["collision"])
     return eng

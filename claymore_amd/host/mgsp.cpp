@@ -8,6 +8,9 @@
 // (halo_buffer.cuh:54-59).  The one-process-per-GPU RCCL variant is claymore_amd/mgsp.py.
 //
 //   mgsp [--devices N] [--scenario 2|3] [--bits B] [--frames F] [--fps R] [--same-device] [--out DIR]
+//        [--boundary PREFIX [--boundary-type sticky|slip|separate] [--friction MU]]
+// --boundary reads PREFIX_sdf.bin, PREFIX_grad_{0,1,2}.bin (N^3 floats each) like MgspBenchmark::init_boundary
+// (mgsp_benchmark.cuh:257-266, boundary_condition.cuh:292-321) and installs the collision object on every device.
 // --same-device puts every context on GPU 0 (functional testing on a single GPU).
 #include <hip/hip_runtime.h>
 
@@ -72,7 +75,8 @@ static float compute_dt_mgsp(float max_vel, float cur, float next, float dt_defa
 int main(int argc, char** argv) {
 	int ndev = 2, scenario = 2, bits = 8, frames = 2, fps = 48;
 	bool same = false;
-	std::string out = ".";
+	std::string out = ".", boundary, boundary_type = "sticky";
+	float friction = 0.3f;
 	for(int i = 1; i < argc; ++i) {
 		auto is = [&](const char* s) { return !std::strcmp(argv[i], s) && i + 1 < argc; };
 		if(is("--devices")) ndev = std::atoi(argv[++i]);
@@ -81,6 +85,9 @@ int main(int argc, char** argv) {
 		else if(is("--frames")) frames = std::atoi(argv[++i]);
 		else if(is("--fps")) fps = std::atoi(argv[++i]);
 		else if(is("--out")) out = argv[++i];
+		else if(is("--boundary")) boundary = argv[++i];
+		else if(is("--boundary-type")) boundary_type = argv[++i];
+		else if(is("--friction")) friction = (float) std::atof(argv[++i]);
 		else if(!std::strcmp(argv[i], "--same-device")) same = true;
 	}
 	int ngpu = 0;
@@ -128,6 +135,28 @@ int main(int argc, char** argv) {
 		D.n = pts.size();
 		std::printf("init model on device %d (gpu %d) with %zu particles\n", d, D.gpu, D.n);
 		pio::write_bgeo(out + "/model_dev[" + std::to_string(d) + "]_frame[0].bgeo", pts[0].data(), pts.size());
+	}
+	if(!boundary.empty()) {// init_boundary (mgsp_benchmark.cuh:257-266)
+		const size_t n = (size_t) N * N * N;
+		std::vector<float> field[4];
+		const char* suffix[4] = {"_sdf.bin", "_grad_0.bin", "_grad_1.bin", "_grad_2.bin"};
+		for(int c = 0; c < 4; ++c) {
+			field[c].resize(n);
+			const std::string fn = boundary + suffix[c];
+			FILE* f				 = std::fopen(fn.c_str(), "rb");
+			const size_t got	 = f ? std::fread(field[c].data(), sizeof(float), n, f) : 0;
+			if(f) std::fclose(f);
+			if(got != n) {
+				std::fprintf(stderr, "Error in loading file [%s]: read in %zu entries, should be %zu\n", fn.c_str(), got, n);// boundary_condition.cuh:304
+				return 1;
+			}
+		}
+		mpm_collision_object obj;
+		mpm_default_collision_object(&obj);
+		obj.type	 = boundary_type == "slip" ? MPM_BOUNDARY_SLIP : (boundary_type == "separate" ? MPM_BOUNDARY_SEPARATE : MPM_BOUNDARY_STICKY);
+		obj.friction = friction;
+		for(auto& D: devs) check(D, mpm_set_collision_object(D.ctx, &obj, field[0].data(), field[1].data(), field[2].data(), field[3].data()));
+		std::printf("[Collision Object] %s, %s\n", boundary.c_str(), boundary_type.c_str());
 	}
 	for(auto& D: devs) check(D, mpm_initial_setup(D.ctx));
 	// staging buffers sized by the block capacity implied by the initial counts

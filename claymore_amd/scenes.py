@@ -109,3 +109,27 @@ def split_slabs(xyz, parts, axis=0):
 
 def total_particles(scene):
     return int(sum(m["xyz"].shape[0] for m in scene["models"]))
+
+
+def sphere_level_set(bits, centre, radius):
+    """Node-sampled signed distance (negative inside) and gradient of a sphere, in the layout of the reference's
+    `<name>_sdf.bin` / `_grad_{0,1,2}.bin` files (Projects/MGSP/boundary_condition.cuh:252-321): (N, N, N) and (3, N, N, N)."""
+    n = 1 << bits
+    ax = np.arange(n, dtype=np.float64) / n
+    X, Y, Z = np.meshgrid(ax - centre[0], ax - centre[1], ax - centre[2], indexing="ij")
+    r = np.sqrt(X * X + Y * Y + Z * Z)
+    rs = np.maximum(r, 1e-12)
+    return (r - radius).astype(np.float32), np.stack([X / rs, Y / rs, Z / rs]).astype(np.float32)
+
+
+def sphere_on_obstacle(bits=6, radius_cells=5.0, obstacle_cells=6.0, boundary="slip", friction=0.3, speed=1.0, material=FIXED_COROTATED):
+    """An elastic sphere thrown onto a fixed spherical level-set obstacle (the MGSP collision-object path)."""
+    dx = 1.0 / (1 << bits)
+    c_obs = (0.5, 0.34, 0.5)
+    c_sph = (0.5 + 1.5 * dx, c_obs[1] + (obstacle_cells + radius_cells + 1.5) * dx, 0.5)
+    vol = float(np.float32(dx ** 3 / 8))
+    sdf, grad = sphere_level_set(bits, c_obs, obstacle_cells * dx)
+    return {"name": "sphere_on_obstacle", "bits": bits, "dt": 1e-4, "config": {},
+            "models": [{"material": material, "xyz": lattice_sphere(bits, c_sph, radius_cells), "v0": (0.0, -speed, 0.0),
+                        "params": {"volume": vol, "youngs_modulus": 5e3, "poisson_ratio": 0.4, "rho": 1e3}}],
+            "collision": {"sdf": sdf, "grad": grad, "type": {"sticky": 0, "slip": 1, "separate": 2}[boundary], "friction": friction}}

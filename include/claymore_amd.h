@@ -149,6 +149,30 @@ int mpm_retrieve_state(mpm_ctx* ctx, int model, float* xyz, float* state9, float
 
 int mpm_get_counts(mpm_ctx* ctx, mpm_counts* counts);
 
+/* Level-set collision object of the MGSP grid update (Projects/MGSP/boundary_condition.cuh:25-250, the second
+ * update_grid_velocity_query_max overload Projects/MGSP/mgmpm_kernels.cuh:323-399, set up by
+ * MgspBenchmark::init_boundary mgsp_benchmark.cuh:257-266).  Field values of SignedDistanceGrid. */
+enum { MPM_BOUNDARY_STICKY = 0, MPM_BOUNDARY_SLIP = 1, MPM_BOUNDARY_SEPARATE = 2 }; /* BoundaryT, boundary_condition.cuh:19-23 */
+typedef struct mpm_collision_object {
+	int type;			/* BoundaryT; default STICKY (:46) */
+	float friction;		/* 0.3 (:45) */
+	float scale;		/* 1 (:44) */
+	float dsdt;			/* 0 (:43) */
+	float trans[3];		/* 0 */
+	float trans_vel[3]; /* 0 */
+	float omega[3];		/* 0 */
+	float rot_mat[9];	/* identity; stored as the reference stores vec3x3: element (i, j) at [3 i + j] */
+	float time;			/* `current_time` handed to detect_and_resolve_collision; the reference passes 0.f (:364) */
+	int reserved[3];
+} mpm_collision_object;
+int mpm_default_collision_object(mpm_collision_object* obj);
+/* Install (obj != NULL) or remove (obj == NULL) the collision object.  sdf / grad_x / grad_y / grad_z: one float per grid
+ * NODE of the whole domain, N = 2^domain_bits per axis, node (i, j, k) at [(i N + j) N + k] - the layout of the
+ * reference's `<name>_sdf.bin` / `_grad_{0,1,2}.bin` files (boundary_condition.cuh:252-321).  Copied during the call.
+ * With an object installed, mpm_grid_update follows the reference's boundary overload, including its max-velocity
+ * quirk (|v|^2 is accumulated twice, mgmpm_kernels.cuh:365-373). */
+int mpm_set_collision_object(mpm_ctx* ctx, const mpm_collision_object* obj, const float* sdf, const float* grad_x, const float* grad_y, const float* grad_z);
+
 /* Current capacities and the number of times check_capacity() (gmpm_simulator.cuh:283-300) has grown them: blocks
  * (exterior count limit), bins per model (bin_capacity[8]).  HIP library only. */
 int mpm_get_capacity(mpm_ctx* ctx, int64_t* block_capacity, int64_t* bin_capacity, int* growth_events);

@@ -78,6 +78,10 @@ typedef struct mpmo_ctx {
 	int halo_tagged;
 	float last_max_vel_sqr;
 	int peer_rows_max;
+	/* collision object (Projects/MGSP/boundary_condition.cuh) */
+	int has_collision;
+	mpm_collision_object col;
+	float* sdf4; /* [node][4] = {sdis, gradx, grady, gradz} */
 	mpm_timers timers;
 	char err[256];
 } mpmo_ctx;
@@ -178,6 +182,7 @@ void mpmo_destroy(mpmo_ctx* c) {
 		free_pbuf(&c->models[m].buf[0]);
 		free_pbuf(&c->models[m].buf[1]);
 	}
+	free(c->sdf4);
 	free(c->marks);
 	free(c->sources);
 	free(c->destinations);
@@ -487,6 +492,173 @@ int mpmo_initial_setup(mpmo_ctx* c) {
 }
 
 /* ---- update_grid_velocity_query_max, Projects/GMPM/mgmpm_kernels.cuh:325-420 ---- */
+/* ---- SignedDistanceGrid, Projects/MGSP/boundary_condition.cuh:25-250 ---- */
+int mpmo_default_collision_object(mpm_collision_object* o) {
+	if(!o) return MPM_ERR_INVALID;
+	memset(o, 0, sizeof(*o));
+	o->type		= MPM_BOUNDARY_STICKY; /* :46 */
+	o->friction = 0.3f;				   /* :45 */
+	o->scale	= 1.0f;				   /* :44 */
+	o->dsdt		= 0.0f;				   /* :43 */
+	o->rot_mat[0] = o->rot_mat[4] = o->rot_mat[8] = 1.f; /* :47-48 */
+	return MPM_OK;
+}
+
+int mpmo_set_collision_object(mpmo_ctx* c, const mpm_collision_object* obj, const float* sdf, const float* gx, const float* gy, const float* gz) {
+	if(!c) return MPM_ERR_INVALID;
+	free(c->sdf4);
+	c->sdf4			 = NULL;
+	c->has_collision = 0;
+	if(!obj) return MPM_OK;
+	if(!sdf || !gx || !gy || !gz) return MPM_ERR_INVALID;
+	const size_t N = (size_t) c->G * 4, n = N * N * N;
+	c->sdf4 = (float*) malloc(sizeof(float) * 4 * n);
+	if(!c->sdf4) return MPM_ERR_DEVICE;
+	for(size_t i = 0; i < n; ++i) {
+		c->sdf4[4 * i]	   = sdf[i];
+		c->sdf4[4 * i + 1] = gx[i];
+		c->sdf4[4 * i + 2] = gy[i];
+		c->sdf4[4 * i + 3] = gz[i];
+	}
+	c->col			 = *obj;
+	c->has_collision = 1;
+	return MPM_OK;
+}
+
+/* rot_angle_to_matrix (:68-91): element (i, j) of the reference's vec3x3 lives at [3 i + j] */
+static void col_rot_angle_to_matrix(float omega, int dim, float* res) {
+	for(int i = 0; i < 9; ++i) res[i] = 0.f;
+	if(dim == 0) {
+		res[0] = 1;
+		res[4] = res[8] = cosf(omega);
+		res[7] = res[5] = sinf(omega);
+		res[5]			= -res[5];
+	} else if(dim == 1) {
+		res[4] = 1;
+		res[0] = res[8] = cosf(omega);
+		res[6] = res[2] = sinf(omega);
+		res[6]			= -res[6];
+	} else {
+		res[8] = 1;
+		res[0] = res[4] = cosf(omega);
+		res[3] = res[1] = sinf(omega);
+		res[1]			= -res[1];
+	}
+}
+/* vec_cross_mul_vec_3d, MatrixUtils.h:53-58 and vec3_cross_vec3, boundary_condition.cuh:93-96 (both with plus signs) */
+static void col_cross(float* out, const float* a, const float* b) {
+	out[0] = a[1] * b[2] + a[2] * b[1];
+	out[1] = a[2] * b[0] + a[0] * b[2];
+	out[2] = a[0] * b[1] + a[1] * b[0];
+}
+/* get_signed_distance_and_normal (:99-140) */
+static float col_signed_distance_and_normal(const mpmo_ctx* c, const float* x, float* normal) {
+	const float dx = c->dx;
+	const size_t N = (size_t) c->G * 4;
+	int g_cid[3];
+	for(int d = 0; d < 3; ++d) g_cid[d] = (int) (x[d] / dx);
+	float sdis = 0.f;
+	normal[0] = normal[1] = normal[2] = 0.f;
+	float w1[3][2];
+	for(int d = 0; d < 3; ++d) {
+		const float dis_lb = x[d] - ((float) g_cid[d] * dx);
+		w1[d][0]		   = 1 - dis_lb / dx;
+		w1[d][1]		   = dis_lb / dx;
+	}
+	for(int i = 0; i < 2; ++i)
+		for(int j = 0; j < 2; ++j)
+			for(int k = 0; k < 2; ++k) {
+				const float w  = w1[0][i] * w1[1][j] * w1[2][k];
+				const float* v = c->sdf4 + 4 * ((((size_t) (g_cid[0] + i)) * N + (size_t) (g_cid[1] + j)) * N + (size_t) (g_cid[2] + k));
+				sdis += w * v[0];
+				normal[0] += w * v[1];
+				normal[1] += w * v[2];
+				normal[2] += w * v[3];
+			}
+	const float nn = sqrtf(normal[0] * normal[0] + normal[1] * normal[1] + normal[2] * normal[2]);
+	for(int d = 0; d < 3; ++d) normal[d] /= nn;
+	return sdis;
+}
+/* query_sdf (:141-146) */
+static int col_query_sdf(const mpmo_ctx* c, float* normal, const float* x) {
+	const float lo = (float) c->cfg.boundary_blocks * c->dx * 4.f;
+	const float hi = (float) (c->G - c->cfg.boundary_blocks) * 4.f * c->dx;
+	if(x[0] < lo || x[0] >= hi || x[1] < lo || x[1] >= hi || x[2] < lo || x[2] >= hi) return 0;
+	return col_signed_distance_and_normal(c, x, normal) <= 0.f;
+}
+/* detect_and_resolve_collision (:164-248) */
+static void col_detect_and_resolve(const mpmo_ctx* c, const int* block_id, const int* cell_id, float t, float* vel) {
+	const mpm_collision_object* o = &c->col;
+	float xmt[3], x[3], x0[3];
+	for(int d = 0; d < 3; ++d) xmt[d] = (float) (block_id[d] * 4 + cell_id[d]) * c->dx - (o->trans[d] + o->trans_vel[d] * t);
+	float rot[9], tmp[9], prev[9];
+	memcpy(rot, o->rot_mat, sizeof(rot));
+	{
+		const float inv = 1.f / (1.f + o->dsdt * t);
+		for(int d = 0; d < 3; ++d) x0[d] = xmt[d] * inv;
+		for(int dim = 0; dim < 3; ++dim) {
+			col_rot_angle_to_matrix(o->omega[dim] * t, dim, tmp);
+			memcpy(prev, rot, sizeof(rot));
+			orc_matmul3(prev, tmp, rot); /* matrix_matrix_multiplication_3d on the raw arrays (:177-187) */
+		}
+		/* mat_t_mul_vec_3d, MatrixUtils.h:45-49 */
+		x[0] = rot[0] * x0[0] + rot[1] * x0[1] + rot[2] * x0[2];
+		x[1] = rot[3] * x0[0] + rot[4] * x0[1] + rot[5] * x0[2];
+		x[2] = rot[6] * x0[0] + rot[7] * x0[1] + rot[8] * x0[2];
+	}
+	for(int d = 0; d < 3; ++d) x[d] = x[d] * o->scale + o->trans[d];
+	float n[3];
+	if(!col_query_sdf(c, n, x)) return;
+	/* object velocity in deformation space (:197-204) */
+	float v_obj[3], radius[3], mat_vel[3], rot_v[3];
+	col_cross(v_obj, o->omega, xmt);
+	for(int d = 0; d < 3; ++d) v_obj[d] += xmt[d] * (o->dsdt / o->scale);
+	for(int d = 0; d < 3; ++d) radius[d] = x[d] - o->trans[d];
+	col_cross(mat_vel, o->omega, radius); /* get_material_velocity (:59-65) */
+	for(int d = 0; d < 3; ++d) mat_vel[d] += o->trans_vel[d];
+	/* matrix_vector_multiplication_3d, MatrixUtils.h:210-214 */
+	rot_v[0] = rot[0] * mat_vel[0] + rot[3] * mat_vel[1] + rot[6] * mat_vel[2];
+	rot_v[1] = rot[1] * mat_vel[0] + rot[4] * mat_vel[1] + rot[7] * mat_vel[2];
+	rot_v[2] = rot[2] * mat_vel[0] + rot[5] * mat_vel[1] + rot[8] * mat_vel[2];
+	for(int d = 0; d < 3; ++d) v_obj[d] += rot_v[d] * o->scale + o->trans_vel[d];
+	for(int d = 0; d < 3; ++d) vel[d] -= v_obj[d];
+	if(o->type == MPM_BOUNDARY_STICKY) {
+		vel[0] = vel[1] = vel[2] = 0.f;
+	} else {
+		if(o->type == MPM_BOUNDARY_SEPARATE && n[0] == 0.0f && n[1] == 0.0f && n[2] == 0.0f) {
+			vel[0] = vel[1] = vel[2] = 0.f;
+			return; /* (:227-230): returns WITHOUT adding the object velocity back */
+		}
+		float nr[3];
+		nr[0] = rot[0] * n[0] + rot[3] * n[1] + rot[6] * n[2];
+		nr[1] = rot[1] * n[0] + rot[4] * n[1] + rot[7] * n[2];
+		nr[2] = rot[2] * n[0] + rot[5] * n[1] + rot[8] * n[2];
+		const float v_dot_n = nr[0] * vel[0] + nr[1] * vel[1] + nr[2] * vel[2];
+		if(o->type == MPM_BOUNDARY_SLIP) {
+			for(int d = 0; d < 3; ++d) vel[d] -= nr[d] * v_dot_n;
+			if(o->friction > 0.0f && v_dot_n < 0) {
+				const float vel_norm = sqrtf(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]);
+				if(-v_dot_n * o->friction < vel_norm) {
+					for(int d = 0; d < 3; ++d) vel[d] += vel[d] / vel_norm * (v_dot_n * o->friction);
+				} else {
+					vel[0] = vel[1] = vel[2] = 0.f;
+				}
+			}
+		} else if(v_dot_n < 0) { /* SEPARATE (:236-247) */
+			for(int d = 0; d < 3; ++d) vel[d] -= nr[d] * v_dot_n;
+			if(o->friction != 0) {
+				const float vel_norm = sqrtf(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]);
+				if(-v_dot_n * o->friction < vel_norm) {
+					for(int d = 0; d < 3; ++d) vel[d] += vel[d] / vel_norm * (v_dot_n * o->friction);
+				} else {
+					vel[0] = vel[1] = vel[2] = 0.f;
+				}
+			}
+		}
+	}
+	for(int d = 0; d < 3; ++d) vel[d] += v_obj[d];
+}
+
 int mpmo_grid_update(mpmo_ctx* c, float dt, float* max_vel_sqr) {
 	if(!c || !c->ready) return MPM_ERR_NOT_READY;
 	double t0				= now_ms();
@@ -509,6 +681,15 @@ int mpmo_grid_update(mpmo_ctx* c, float dt, float* max_vel_sqr) {
 				v1 = wy ? 0.0f : v1 * mass_inv;
 				v1 += c->cfg.gravity * dt;
 				v2 = wz ? 0.0f : v2 * mass_inv;
+				if(c->has_collision) { /* boundary overload, Projects/MGSP/mgmpm_kernels.cuh:362-373 */
+					float vel[3]		 = {v0, v1, v2};
+					const int cellid[3] = {(cell & 0x30) >> 4, (cell & 0xc) >> 2, cell & 0x3};
+					col_detect_and_resolve(c, key, cellid, c->col.time, vel);
+					v0 = vel[0];
+					v1 = vel[1];
+					v2 = vel[2];
+					vel_sqr = v0 * v0 + v1 * v1 + v2 * v2; /* vel.dot(vel), then added again below: the reference's 2 |v|^2 */
+				}
 				g[64 + cell]  = v0;
 				g[128 + cell] = v1;
 				g[192 + cell] = v2;
