@@ -198,6 +198,7 @@ int main(int argc, char** argv) {
 	float cur_time = 0.f;
 	long steps	   = 0;
 	std::vector<float> buf;
+	pio::AsyncWriter io;
 	const auto wall0 = std::chrono::steady_clock::now();
 	for(int frame = 1; frame <= frames; ++frame) {
 		for(float t = 0.f; t < spf;) {
@@ -225,9 +226,11 @@ int main(int argc, char** argv) {
 			rc		 = mpm_retrieve_positions(ctx, (int) mi, buf.data(), &n);
 			if(rc) die(ctx, rc);
 			std::printf("total number of particles %zu\n", n);
-			pio::write_bgeo(out_dir + "/model_id[" + std::to_string(mi) + "]_frame[" + std::to_string(frame) + "].bgeo", buf.data(), n);
+			// IO::insert_job (gmpm_simulator.cuh:626-632): the frame is written by the IO thread while the next frame is computed
+			io.write_bgeo_async(out_dir + "/model_id[" + std::to_string(mi) + "]_frame[" + std::to_string(frame) + "].bgeo", buf, n);
 		}
 	}
+	io.flush();// IO::flush() at the end of main_loop (gmpm_simulator.cuh:591)
 	const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
 	std::printf("done: %ld substeps in %.3f s\n", steps, wall);
 	mpm_destroy(ctx);

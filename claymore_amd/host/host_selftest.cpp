@@ -31,6 +31,17 @@ int main(int argc, char** argv) {
 	if(argc > 1) {
 		const float xyz[6] = {0.25f, 0.5f, 0.75f, -1.5f, 2.0f, 3.25f};
 		std::cout << "bgeo " << (pio::write_bgeo(argv[1], xyz, 2) ? "written" : "failed") << "\n";
+		{// the IO worker: 8 frames queued, flush() returns only when all of them are on disk
+			pio::AsyncWriter io;
+			for(int f = 0; f < 8; ++f) io.write_bgeo_async(std::string(argv[1]) + ".async" + std::to_string(f), std::vector<float>(xyz, xyz + 6), 2);
+			io.flush();
+			int ok = 0;
+			for(int f = 0; f < 8; ++f) {
+				std::ifstream in(std::string(argv[1]) + ".async" + std::to_string(f), std::ios::binary | std::ios::ate);
+				ok += in && in.tellg() == std::ifstream::pos_type(41 + 2 * 16 + 2);
+			}
+			std::cout << "async " << ok << "\n";
+		}
 	}
 	return 0;
 }

@@ -263,6 +263,7 @@ int main(int argc, char** argv) {
 	float dt   = compute_dt_mgsp(0.f, 0.f, spf, dt_default, dx);
 	long steps = 0;
 	std::vector<float> buf;
+	pio::AsyncWriter io;
 	for(int frame = 1; frame <= frames; ++frame) {
 		for(float t = 0.f; t < spf;) {
 			float maxv2 = 0.f;
@@ -292,10 +293,11 @@ int main(int argc, char** argv) {
 			size_t n = D.n;
 			check(D, mpm_retrieve_positions(D.ctx, 0, buf.data(), &n));
 			std::printf("total number of particles %zu\n", n);
-			pio::write_bgeo(out + "/model_dev[" + std::to_string(d) + "]_frame[" + std::to_string(frame) + "].bgeo", buf.data(), n);
+			io.write_bgeo_async(out + "/model_dev[" + std::to_string(d) + "]_frame[" + std::to_string(frame) + "].bgeo", buf, n);// IO::insert_job, mgsp_benchmark.cuh:586-590
 		}
 		std::printf("frame %d done after %ld substeps\n", frame, steps);
 	}
+	io.flush();
 	for(auto& D: devs) mpm_destroy(D.ctx);
 	return 0;
 }

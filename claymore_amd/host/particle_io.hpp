@@ -5,6 +5,11 @@
 // nPrims 0, nPointGroups 0, nPrimGroups 0, nPointAttrib 0, nVertexAttrib 0, nPrimAttrib 0, nAttrib 0, then per point
 // x y z w(=1) as float32, then the two trailing bytes 0x00 0xff.
 #pragma once
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -97,6 +102,63 @@ struct Sdf {
 			for(int b = 0; b < 2; ++b)
 				for(int e = 0; e < 2; ++e) r += (a ? t[0] : 1 - t[0]) * (b ? t[1] : 1 - t[1]) * (e ? t[2] : 1 - t[2]) * at(c[0] + a, c[1] + b, c[2] + e);
 		return r;
+	}
+};
+
+// Asynchronous output: one worker thread drains a queue of jobs so that the simulation does not wait for the file system
+// (the reference's IO singleton, Library/MnSystem/IO/IO.h:10-67: insert_job / flush).  The caller hands over the
+// position array by value (moved into the job).
+class AsyncWriter {
+	std::mutex mut_;
+	std::condition_variable cv_, idle_;
+	std::deque<std::function<void()>> jobs_;
+	bool running_ = true;
+	int busy_	  = 0;
+	std::thread th_;
+	void worker() {
+		for(;;) {
+			std::function<void()> job;
+			{
+				std::unique_lock<std::mutex> lk(mut_);
+				cv_.wait(lk, [this] { return !running_ || !jobs_.empty(); });
+				if(jobs_.empty()) return;// !running_ and drained
+				job = std::move(jobs_.front());
+				jobs_.pop_front();
+				busy_ = 1;
+			}
+			job();
+			{
+				std::lock_guard<std::mutex> lk(mut_);
+				busy_ = 0;
+			}
+			idle_.notify_all();
+		}
+	}
+
+public:
+	AsyncWriter()
+		: th_([this] { worker(); }) {}
+	~AsyncWriter() {
+		{
+			std::lock_guard<std::mutex> lk(mut_);
+			running_ = false;
+		}
+		cv_.notify_all();
+		th_.join();// remaining jobs are written before the thread exits
+	}
+	void insert_job(std::function<void()> job) {
+		{
+			std::lock_guard<std::mutex> lk(mut_);
+			jobs_.push_back(std::move(job));
+		}
+		cv_.notify_one();
+	}
+	void write_bgeo_async(std::string fn, std::vector<float> xyz, size_t n) {
+		insert_job([fn = std::move(fn), xyz = std::move(xyz), n] { write_bgeo(fn, xyz.data(), n); });
+	}
+	void flush() {// IO::flush: wait until every queued job has been written
+		std::unique_lock<std::mutex> lk(mut_);
+		idle_.wait(lk, [this] { return jobs_.empty() && !busy_; });
 	}
 };
 }// namespace pio

@@ -29,7 +29,7 @@ def read_bgeo(path):
 
 def test_host_selftest(tmp_path):
     exe = tmp_path / "host_selftest"
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", str(exe), os.path.join(HOST, "host_selftest.cpp")])
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-o", str(exe), os.path.join(HOST, "host_selftest.cpp")])
     out = subprocess.check_output([str(exe), str(tmp_path / "t.bgeo")], text=True).splitlines()
     assert out[0] == 'json_ok 2 5e-06 s"q -1'
     assert out[1] == "json_bad rejected"
@@ -37,6 +37,9 @@ def test_host_selftest(tmp_path):
     assert n == scenes.lattice_sphere(6, (0.5, 0.5, 0.5), 5.0).shape[0]     # same lattice rule as the Python sampler
     pts = read_bgeo(tmp_path / "t.bgeo")
     assert np.array_equal(pts, np.array([[0.25, 0.5, 0.75], [-1.5, 2.0, 3.25]], dtype=np.float32))
+    # the asynchronous IO worker (reference IO.h:10-67): all queued frames are on disk after flush()
+    assert out[4] == "async 8"
+    assert np.array_equal(read_bgeo(str(tmp_path / "t.bgeo") + ".async7"), pts)
 
 
 @pytest.mark.gpu
