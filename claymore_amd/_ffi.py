@@ -94,6 +94,9 @@ HIP_ONLY = {
     "streams": (_i, [_vp, _P(_vp), _P(_vp)]),
     "sync": (_i, [_vp]),
     "get_capacity": (_i, [_vp, _P(C.c_int64), _P(C.c_int64), _ip]),
+    "checkpoint_size": (_i, [_vp, _P(_sz)]),
+    "checkpoint_save": (_i, [_vp, _vp, _sz, _P(_sz)]),
+    "checkpoint_load": (_i, [_vp, _vp, _sz]),
 }
 
 

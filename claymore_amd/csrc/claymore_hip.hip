@@ -41,6 +41,7 @@ struct Model {
 	int* row_of		 = nullptr;
 	int* out_count	 = nullptr;
 	int64_t bincount = 0;
+	int64_t bincount_src = 0;// bins in use in bins[rollid] (the source of the next g2p2g): the previous bincount
 	int64_t bucketed = 0;// particles currently in the advection lists (device-counted at each rebuild)
 	int list_in		 = 0;// which list buffer g2p2g reads next
 };
@@ -422,6 +423,7 @@ int mpm_initial_setup(mpm_ctx* ctx) {
 	ctx->ebc = ctx->h_status[ST_EBC];
 	for(size_t mi = 0; mi < ctx->models.size(); ++mi) {
 		ctx->models[mi].bincount = ctx->h_status[ST_BINS0 + mi];
+		ctx->models[mi].bincount_src = ctx->models[mi].bincount;
 		ctx->models[mi].bucketed = (int64_t) ctx->models[mi].n;
 		if((size_t) ctx->models[mi].bincount > ctx->models[mi].bin_cap) return fail(ctx, MPM_ERR_CAPACITY, "bin capacity");
 	}
@@ -641,6 +643,7 @@ static int finish_rebuild(mpm_ctx* ctx, mpm_counts* counts) {
 	if(ctx->ebc > ctx->g.cap) return fail(ctx, MPM_ERR_CAPACITY, "Too much exterior blocks: " + std::to_string(ctx->ebc));
 	for(size_t mi = 0; mi < ctx->models.size(); ++mi) {
 		Model& m   = ctx->models[mi];
+		m.bincount_src = m.bincount;
 		m.bincount = ctx->h_status[ST_BINS0 + mi];
 		m.bucketed = ctx->h_status[ST_PART0 + mi];
 		if((size_t) m.bincount > m.bin_cap) return fail(ctx, MPM_ERR_CAPACITY, "bin capacity exceeded");
@@ -925,3 +928,4 @@ int mpm_sync(mpm_ctx* ctx) {
 }// extern "C"
 
 #include "mpm_halo.inc"
+#include "mpm_checkpoint.inc"

@@ -192,6 +192,27 @@ __global__ __launch_bounds__(256) void grid_update_collision_kernel(GridCfg cfg,
 	}
 }
 
+// ---- checkpoint helpers (mpm_checkpoint.inc) ----
+// advection-list rows <-> one packed array: block b's size[b] records live at packed[offset[b] ...)
+__global__ __launch_bounds__(64) void pack_lists_kernel(int ppb, const int* __restrict__ size, const int* __restrict__ row_of, const long long* __restrict__ offset, const int* __restrict__ list, int* __restrict__ packed) {
+	const int b = blockIdx.x;
+	const int n = size[b];
+	const int* row = list + (size_t) row_of[b] * ppb;
+	for(int i = threadIdx.x; i < n; i += 64) packed[offset[b] + i] = row[i];
+}
+__global__ __launch_bounds__(64) void unpack_lists_kernel(int ppb, const int* __restrict__ size, int* __restrict__ row_of, const long long* __restrict__ offset, int* __restrict__ list, const int* __restrict__ packed) {
+	const int b = blockIdx.x;
+	const int n = size[b];
+	int* row	= list + (size_t) b * ppb;// rows are re-seated at their own block number
+	for(int i = threadIdx.x; i < n; i += 64) row[i] = packed[offset[b] + i];
+	if(threadIdx.x == 0) row_of[b] = b;
+}
+// dense table from a key list (the inverse of what compact / register build incrementally)
+__global__ __launch_bounds__(256) void table_from_keys_kernel(GridCfg cfg, int n, const int* __restrict__ keys, int* __restrict__ table) {
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if(i < n) table[key_index(cfg, keys[3 * i], keys[3 * i + 1], keys[3 * i + 2])] = i;
+}
+
 // node-major {sdis, gx, gy, gz} from the four per-node arrays the ABI receives
 __global__ __launch_bounds__(256) void pack_sdf_kernel(size_t n, const float* __restrict__ sd, const float* __restrict__ gx, const float* __restrict__ gy, const float* __restrict__ gz, float4* __restrict__ out) {
 	const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;

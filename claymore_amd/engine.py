@@ -166,6 +166,19 @@ class Engine:
         self._check(self.api.set_collision_object(self.ctx, C.byref(obj), sdf.ctypes.data, grad[0].ctypes.data,
                                                   grad[1].ctypes.data, grad[2].ctypes.data))
 
+    def save_checkpoint(self):
+        """Full state at the current substep boundary as a numpy byte array (HIP engine only)."""
+        n = C.c_size_t(0)
+        self._check(self.api.checkpoint_size(self.ctx, C.byref(n)))
+        buf = np.empty(n.value, dtype=np.uint8)
+        w = C.c_size_t(0)
+        self._check(self.api.checkpoint_save(self.ctx, buf.ctypes.data, buf.size, C.byref(w)))
+        return buf[: w.value]
+
+    def load_checkpoint(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        self._check(self.api.checkpoint_load(self.ctx, buf.ctypes.data, buf.size))
+
     def capacity(self):
         """(block capacity, per-model bin capacities, number of growth events) - HIP engine only."""
         blocks, bins, events = C.c_int64(0), (C.c_int64 * 8)(), C.c_int(0)

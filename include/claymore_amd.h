@@ -149,6 +149,15 @@ int mpm_retrieve_state(mpm_ctx* ctx, int model, float* xyz, float* state9, float
 
 int mpm_get_counts(mpm_ctx* ctx, mpm_counts* counts);
 
+/* Full-state checkpoint / restart at a substep boundary (the reference has no restart: its only
+ * output is output_model's position dump, gmpm_simulator.cuh:594-634).  The buffer holds both partitions' key lists, the
+ * grid, and per model the bins, bin offsets, block sizes and packed advection lists.  mpm_checkpoint_load needs a context
+ * with the same configuration and models that has been through mpm_initial_setup; capacities grow as needed.  After a
+ * load the MGSP halo tags must be recomputed.  HIP library only. */
+int mpm_checkpoint_size(mpm_ctx* ctx, size_t* bytes);
+int mpm_checkpoint_save(mpm_ctx* ctx, void* buf, size_t capacity, size_t* written);
+int mpm_checkpoint_load(mpm_ctx* ctx, const void* buf, size_t bytes);
+
 /* Level-set collision object of the MGSP grid update (Projects/MGSP/boundary_condition.cuh:25-250, the second
  * update_grid_velocity_query_max overload Projects/MGSP/mgmpm_kernels.cuh:323-399, set up by
  * MgspBenchmark::init_boundary mgsp_benchmark.cuh:257-266).  Field values of SignedDistanceGrid. */
