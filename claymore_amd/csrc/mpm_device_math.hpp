@@ -196,7 +196,11 @@ struct NoHook {
 	MPM_DEV void at() {}
 };
 constexpr int kSvdSites = 16;
-template<int BASE, class Hook>
+// SORTED = false (the stress functions): the columns are left in the order Jacobi produced them.  Every consumer on
+// this path is symmetric under a simultaneous permutation of (sigma_i, u_i, v_i), and the three conditional column
+// swaps cost ~60 VALU instructions per particle; only the sign convention (a negative determinant goes to the SMALLEST
+// singular value) is kept.  SORTED = true is math::svd's contract and is what mpm_test_svd exposes.
+template<int BASE, class Hook, bool SORTED = true>
 MPM_DEV void svd3(const float (&F)[9], float (&U)[9], float (&S)[3], float (&V)[9], Hook& hk) {
 	float s11 = F[0] * F[0] + F[1] * F[1] + F[2] * F[2];
 	float s21 = F[3] * F[0] + F[4] * F[1] + F[5] * F[2];
@@ -254,9 +258,20 @@ MPM_DEV void svd3(const float (&F)[9], float (&U)[9], float (&S)[3], float (&V)[
 		}                                                         \
 		cond_swap(c, nx, ny);                                     \
 	}
-	MPM_SWAPCOL(n1 < n2, 1, 2, n1, n2, 2)
-	MPM_SWAPCOL(n1 < n3, 1, 3, n1, n3, 1)
-	MPM_SWAPCOL(n2 < n3, 2, 3, n2, n3, 3)
+	if constexpr(SORTED) {
+		MPM_SWAPCOL(n1 < n2, 1, 2, n1, n2, 2)
+		MPM_SWAPCOL(n1 < n3, 1, 3, n1, n3, 1)
+		MPM_SWAPCOL(n2 < n3, 2, 3, n2, n3, 3)
+	}
+	const float nmin = fminf(fminf(n1, n2), n3), nmax = fmaxf(fmaxf(n1, n2), n3);
+	bool well = nmin > 1e-6f * nmax;
+	if constexpr(!SORTED) {
+		if(!well) {// ill conditioned (rare): sort after all, the Givens QR below wants descending columns
+			MPM_SWAPCOL(n1 < n2, 1, 2, n1, n2, 2)
+			MPM_SWAPCOL(n1 < n3, 1, 3, n1, n3, 1)
+			MPM_SWAPCOL(n2 < n3, 2, 3, n2, n3, 3)
+		}
+	}
 #undef MPM_SWAPCOL
 #pragma unroll
 	for(int r = 0; r < 3; ++r) {
@@ -265,18 +280,24 @@ MPM_DEV void svd3(const float (&F)[9], float (&U)[9], float (&S)[3], float (&V)[
 		V[6 + r] = v3[r];
 	}
 	hk.template at<BASE + 14>();
-	if(n3 > 1e-6f * n1) {
+	if(well) {
 		// well conditioned: u_i = b_i / sigma_i
 		const float det = b1[0] * (b2[1] * b3[2] - b2[2] * b3[1]) - b2[0] * (b1[1] * b3[2] - b1[2] * b3[1]) + b3[0] * (b1[1] * b2[2] - b1[2] * b2[1]);
-		const float i1 = rsqrt_approx(n1), i2 = rsqrt_approx(n2);// v_rsq_f32 is 1 ulp: no Newton step needed (svd.cuh:487-498 refines a 12-bit estimate)
-		float i3	   = rsqrt_approx(n3);
-		S[0]		   = n1 * i1;
-		S[1]		   = n2 * i2;
-		S[2]		   = n3 * i3;
-		if(det < 0.f) {
-			S[2] = -S[2];
-			i3	 = -i3;
+		float i1 = rsqrt_approx(n1), i2 = rsqrt_approx(n2);// v_rsq_f32 is 1 ulp: no Newton step needed (svd.cuh:487-498 refines a 12-bit estimate)
+		float i3 = rsqrt_approx(n3);
+		if(det < 0.f) {// the smallest singular value carries the sign of det F (svd.cuh:590-770 does this through the sort)
+			if constexpr(SORTED) {
+				i3 = -i3;
+			} else {
+				const bool m1 = n1 <= n2 && n1 <= n3, m2 = !m1 && n2 <= n3;
+				i1 = m1 ? -i1 : i1;
+				i2 = m2 ? -i2 : i2;
+				i3 = (!m1 && !m2) ? -i3 : i3;
+			}
 		}
+		S[0] = n1 * i1;
+		S[1] = n2 * i2;
+		S[2] = n3 * i3;
 #pragma unroll
 		for(int r = 0; r < 3; ++r) {
 			U[r]	 = b1[r] * i1;
@@ -326,7 +347,7 @@ constexpr int kFcSites = kSvdSites + 2;
 template<int BASE, class Hook>
 MPM_DEV void stress_fixed_corotated(const MaterialConst& mc, const float (&F)[9], float (&PF)[9], Hook& hk) {
 	float U[9], S[3], V[9];
-	svd3<BASE>(F, U, S, V, hk);
+	svd3<BASE, Hook, false>(F, U, S, V, hk);
 	const float J			  = S[0] * S[1] * S[2];
 	const float scaled_mu	  = 2.0f * mc.mu;
 	const float scaled_lambda = mc.lambda * (J - 1.0f);
@@ -350,7 +371,7 @@ constexpr int kSandSites = kSvdSites + 4;
 template<int BASE, class Hook>
 MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9], Hook& hk, float* __restrict__ Fdst = nullptr, int Fstride = 0) {
 	float U[9], S[3], V[9];
-	svd3<BASE>(F, U, S, V, hk);
+	svd3<BASE, Hook, false>(F, U, S, V, hk);
 	const float scaled_mu = 2.0f * mc.mu;
 	float epsilon[3], New_S[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -435,7 +456,7 @@ constexpr int kNaccSites = kSvdSites + 2;
 template<int BASE, class Hook>
 MPM_DEV void stress_nacc(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9], Hook& hk) {
 	float U[9], S[3], V[9];
-	svd3<BASE>(F, U, S, V, hk);
+	svd3<BASE, Hook, false>(F, U, S, V, hk);
 	const float bm	  = mc.bm;
 	const float p0	  = bm * (0.00001f + sinhf(mc.xi * (-log_jp > 0 ? -log_jp : 0)));
 	const float p_min = -mc.beta * p0;
