@@ -40,6 +40,7 @@ struct Model {
 	int* size		 = nullptr;
 	int* row_of		 = nullptr;
 	int* out_count	 = nullptr;
+	int* blockinfo	 = nullptr;// [block][kInfoRow], written by prepare_blocks_kernel
 	int64_t bincount = 0;
 	int64_t bincount_src = 0;// bins in use in bins[rollid] (the source of the next g2p2g): the previous bincount
 	int64_t bucketed = 0;// particles currently in the advection lists (device-counted at each rebuild)
@@ -104,6 +105,8 @@ static float host_maxvel(const mpm_ctx* ctx) {
 	for(int i = 0; i < kMaxVelSlots; ++i) m = std::max(m, ctx->h_maxvel[i]);
 	return m;
 }
+
+static int launch_prepare(mpm_ctx* ctx, int cur, int prev, bool list_is_out, int binoff_sel, const int* pbc_ptr, int nblocks_max, bool sort);
 
 static int fail(mpm_ctx* ctx, int code, const std::string& msg) {
 	ctx->err = msg;
@@ -272,6 +275,7 @@ void mpm_destroy(mpm_ctx* ctx) {
 	}
 	for(auto& m: ctx->models) {
 		hipFree(m.d_xyz);
+		hipFree(m.blockinfo);
 		for(int i = 0; i < 2; ++i) {
 			hipFree(m.bins[i]);
 			hipFree(m.binoff[i]);
@@ -406,6 +410,7 @@ int mpm_initial_setup(mpm_ctx* ctx) {
 		HIP_TRY(dalloc(&m.size, cap + 1));
 		HIP_TRY(dalloc(&m.row_of, cap + 1));
 		HIP_TRY(dalloc(&m.out_count, cap + 1));
+		HIP_TRY(dalloc(&m.blockinfo, cap * (size_t) kInfoRow));
 		HIP_TRY(hipMemsetAsync(m.out_count, 0, sizeof(int) * (cap + 1), s));
 		HIP_TRY(hipMemsetAsync(m.size, 0, sizeof(int) * (cap + 1), s));
 		if(m.n) bucket_particles_kernel<<<cdiv(m.n, 256), 256, 0, s>>>(g, m.n, m.d_xyz, P.table, m.out_count, m.list[1], ctx->d_status);
@@ -442,6 +447,9 @@ int mpm_initial_setup(mpm_ctx* ctx) {
 	HIP_TRY(hipMemsetAsync(ctx->grid[0], 0, sizeof(float) * 256 * (size_t) ctx->nbc, s));
 	for(auto& m: ctx->models)
 		if(m.n) rasterize_kernel<<<cdiv(m.n, 256), 256, 0, s>>>(g, m.n, m.d_xyz, ctx->part[r].table, ctx->grid[0], m.mc.mass, m.v0[0], m.v0[1], m.v0[2]);
+	// the first G2P2G: current == previous numbering (roll r), lists as filled above
+	rc = launch_prepare(ctx, r, n, false, r, &ctx->d_status[ST_PBC], ctx->pbc, true);
+	if(rc) return rc;
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(s));
 	ctx->ready = true;
@@ -495,6 +503,7 @@ static ModelView make_view(mpm_ctx* ctx, Model& m) {
 	v.size		 = m.size;
 	v.row_of	 = m.row_of;
 	v.out_count	 = m.out_count;
+	v.blockinfo	 = m.blockinfo;
 	v.mc		 = m.mc;
 	return v;
 }
@@ -502,29 +511,26 @@ static ModelView make_view(mpm_ctx* ctx, Model& m) {
 static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, int nblocks, float dt, float next_dt, hipStream_t s) {
 	const int r = ctx->rollid, n = r ^ 1;
 	ModelView v = make_view(ctx, m);
-	const int* cur_table  = ctx->part[r].table;
 	const int* cur_keys	  = ctx->part[r].keys;
-	const int* prev_table = ctx->part[n].table;
 	switch(m.material) {
-		case MPM_J_FLUID: g2p2g_kernel<0><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_table, cur_keys, prev_table, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
-		case MPM_FIXED_COROTATED: g2p2g_kernel<1><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_table, cur_keys, prev_table, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
+		case MPM_J_FLUID: g2p2g_kernel<0><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
+		case MPM_FIXED_COROTATED: g2p2g_kernel<1><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
 		case MPM_SAND:
 			switch(ctx->ablate) {// profiling builds only (MPM_G2P2G_ABLATE), see mpm_kernels.hpp
 #define MPM_ABL(n) \
-	case n: g2p2g_kernel<2, n><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_table, cur_keys, prev_table, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
+	case n: g2p2g_kernel<2, n><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
 				MPM_ABL(1)
 				MPM_ABL(2)
 				MPM_ABL(4)
-				MPM_ABL(8)
 				MPM_ABL(3)
 				MPM_ABL(7)
 				MPM_ABL(15)
 				MPM_ABL(32)
 #undef MPM_ABL
-				default: g2p2g_kernel<2><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_table, cur_keys, prev_table, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
+				default: g2p2g_kernel<2><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
 			}
 			break;
-		default: g2p2g_kernel<3><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_table, cur_keys, prev_table, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
+		default: g2p2g_kernel<3><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
 	}
 }
 
@@ -559,6 +565,28 @@ int mpm_g2p2g(mpm_ctx* ctx, float dt, float next_dt) {
 	return MPM_OK;
 }
 
+// Per-block preparation of the next G2P2G (prepare_blocks_kernel): `cur` is the numbering that G2P2G will run in, `prev`
+// the numbering the particle data is laid out in; `list_sel` / `binoff_sel` select the list and bin-offset buffers that
+// G2P2G will read (they differ before and after the roll).  nblocks_max bounds the particle block count (*pbc_ptr).
+static int launch_prepare(mpm_ctx* ctx, int cur, int prev, bool list_is_out, int binoff_sel, const int* pbc_ptr, int nblocks_max, bool sort) {
+	if(nblocks_max <= 0) return MPM_OK;
+	PrepareModels pm {};
+	pm.n = (int) ctx->models.size();
+	for(int mi = 0; mi < pm.n; ++mi) {
+		Model& m		  = ctx->models[mi];
+		pm.list[mi]		  = m.list[list_is_out ? (m.list_in ^ 1) : m.list_in];
+		pm.size[mi]		  = m.size;
+		pm.row_of[mi]	  = m.row_of;
+		pm.binoff_src[mi] = m.binoff[binoff_sel];
+		pm.blockinfo[mi]  = m.blockinfo;
+	}
+	if(sort)
+		prepare_blocks_kernel<true><<<nblocks_max, 64, 0, ctx->s_compute>>>(ctx->g, pm, pbc_ptr, ctx->part[cur].table, ctx->part[cur].keys, ctx->part[prev].table);
+	else
+		prepare_blocks_kernel<false><<<nblocks_max, 64, 0, ctx->s_compute>>>(ctx->g, pm, pbc_ptr, ctx->part[cur].table, ctx->part[cur].keys, ctx->part[prev].table);
+	return MPM_OK;
+}
+
 // partition rebuild, gmpm_simulator.cuh:415-579 (launches only; no host round trip inside)
 static int launch_rebuild(mpm_ctx* ctx) {
 	hipStream_t s = ctx->s_compute;
@@ -587,7 +615,9 @@ static int launch_rebuild(mpm_ctx* ctx) {
 	carry_grid_kernel<<<2048, 256, 0, s>>>(g, &ctx->d_status[ST_NBC], Pn.keys, Pr.table, ctx->nbc, ctx->grid[1], ctx->grid[0]);
 	register_blocks_kernel<-1, 1><<<rg, 256, 0, s>>>(g, &ctx->d_status[ST_PBC], Pn.table, Pn.keys, Pn.count, ctx->d_status);
 	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_EBC], Pn.count, sizeof(int), hipMemcpyDeviceToDevice, s));
-	return MPM_OK;
+	// the next G2P2G runs in the new numbering n with the particle data laid out in r: sort its lists (the ones the last
+	// G2P2G appended to), look up its blocks' neighbours.  The old exterior count bounds the new particle block count.
+	return launch_prepare(ctx, n, r, true, n, &ctx->d_status[ST_PBC], ctx->ebc, true);
 }
 
 // check_capacity() (gmpm_simulator.cuh:283-300): once the exterior block count / a model's bin count passes 3/4 of its
@@ -614,6 +644,7 @@ static int grow_capacity(mpm_ctx* ctx) {
 			HIP_TRY(regrow(&m.size, cap + 1, ncap + 1, s));
 			HIP_TRY(regrow(&m.row_of, cap + 1, ncap + 1, s));
 			HIP_TRY(regrow(&m.out_count, cap + 1, ncap + 1, s));
+			HIP_TRY(regrow(&m.blockinfo, cap * (size_t) kInfoRow, ncap * (size_t) kInfoRow, s));
 		}
 		if(ctx->d_overlap) {
 			HIP_TRY(regrow(&ctx->d_overlap, cap + 1, ncap + 1, s));

@@ -235,6 +235,7 @@ struct ModelView {
 	const int* size;	  // particles per current block
 	const int* row_of;	  // row of list_in that belongs to current block b
 	int* out_count;		  // append counters of list_out
+	const int* blockinfo; // [block][kInfoRow]: source bin offsets, destination / grid block numbers (prepare_blocks_kernel)
 	MaterialConst mc;
 };
 
@@ -473,6 +474,135 @@ __device__ __forceinline__ void p2g_resolve(float4* __restrict__ arena, unsigned
 	}
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Per-block preparation for G2P2G, run once per substep after the partition rebuild with one wave per particle block:
+//  * the block's advection records are counting-sorted IN PLACE into "k-th particle of every key" order, the key being the
+//    stencil base the particle is PREDICTED to have after the coming step (written into the record one step earlier from
+//    x + v dt, exact for > 99.9 % of the particles): the 64 lanes of a G2P2G iteration then scatter to 64 distinct
+//    stencil bases (replaces cell_bucket_to_block, mgmpm_kernels.cuh:70-84);
+//  * the 27 source-block bin offsets, the 27 destination block numbers and the 8 grid-block numbers the block will need are
+//    looked up in the two dense tables and written as one 256-B row.
+// Both used to be the per-block prologue of g2p2g_kernel.  There they were a chain of dependent LDS / global round trips
+// executed at 2 waves per SIMD (the register budget of the main loop); here the same work runs at full occupancy, and
+// G2P2G starts its first particle fetch two round trips earlier.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kInfoRow = 64;// ints per block: [0,27) source bin offsets, [27,54) destination block numbers, [54,62) grid blocks
+struct PrepareModels {
+	int n;
+	int* list[kMaxModels];				// advection lists, sorted in place
+	const int* size[kMaxModels];
+	const int* row_of[kMaxModels];
+	const int* binoff_src[kMaxModels];	// bin offsets in the numbering the particle data is laid out in (previous partition)
+	int* blockinfo[kMaxModels];
+};
+template<bool SORT>
+__global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, PrepareModels pm, const int* __restrict__ pbc_ptr, const int* __restrict__ cur_table, const int* __restrict__ cur_keys, const int* __restrict__ prev_table) {
+	__shared__ int s_sorted[kSortChunk];
+	__shared__ unsigned long long s_mask[kSortRounds][4];// per round: which of the 216 keys still have a k-th particle
+	__shared__ int s_round0[kSortRounds + 1];			  // first sorted position of round k
+	__shared__ unsigned s_wordoff[kSortRounds];			  // packed prefix of the four mask words' popcounts (3 x 8 bit)
+	__shared__ int s_cnt[256 - 32];						  // 216 keys used
+	const int lane = threadIdx.x;
+	const int b	   = blockIdx.x;
+	if(b >= *pbc_ptr) return;
+	const int kx = cur_keys[3 * b], ky = cur_keys[3 * b + 1], kz = cur_keys[3 * b + 2];
+	// ---- look-ups (model independent except for the bin offsets)
+	int srcno = -1, other = -1;
+	if(lane < 27) {
+		int ox, oy, oz;
+		dir_components(lane, ox, oy, oz);
+		srcno = table_query(cfg, prev_table, kx + ox, ky + oy, kz + oz);
+	} else if(lane < 54) {
+		int ox, oy, oz;
+		dir_components(lane - 27, ox, oy, oz);
+		other = table_query(cfg, cur_table, kx - ox, ky - oy, kz - oz);
+	} else if(lane < 62) {
+		const int lb = lane - 54;
+		other		 = table_query(cfg, cur_table, kx + ((lb >> 2) & 1), ky + ((lb >> 1) & 1), kz + (lb & 1));
+	}
+	const int key_shift		= cfg.pid_bits;
+	const int tag_shift		= cfg.pid_bits + kKeyBits;
+	const unsigned rec_mask = (1u << (tag_shift + 5)) - 1u;
+	for(int m = 0; m < pm.n; ++m) {
+		int info = other;
+		if(lane < 27) info = srcno >= 0 ? pm.binoff_src[m][srcno] : -1;
+		pm.blockinfo[m][(size_t) b * kInfoRow + lane] = info;
+		if constexpr(!SORT) continue;
+		const int size = pm.size[m][b];
+		int* list	   = pm.list[m] + (size_t) pm.row_of[m][b] * cfg.ppb;
+		for(int chunk0 = 0; chunk0 < size; chunk0 += kSortChunk) {
+			const int nrec = min(kSortChunk, size - chunk0);
+#pragma unroll
+			for(int q = 0; q < 4; ++q)
+				if(lane + 64 * q < 224) s_cnt[lane + 64 * q] = 0;
+			__syncthreads();
+			unsigned packed[kSortChunk / 64];
+#pragma unroll
+			for(int it = 0; it < kSortChunk / 64; ++it) {
+				const int idx = it * 64 + lane;
+				packed[it]	  = 0u;
+				if(idx < nrec) {
+					const unsigned rec = (unsigned) list[chunk0 + idx] & rec_mask;
+					const int c		   = (rec >> key_shift) & 255;
+					const int k		   = atomicAdd(&s_cnt[c], 1);// ds_add_rtn_u32: integer LDS atomics run at full rate
+					packed[it]		   = rec | ((unsigned) min(k, kSortRounds) << 26);
+				}
+			}
+			__syncthreads();
+			{
+				int my[4];
+				int maxc = 0;
+#pragma unroll
+				for(int q = 0; q < 4; ++q) {
+					my[q] = lane + 64 * q < 224 ? s_cnt[lane + 64 * q] : 0;
+					maxc  = max(maxc, my[q]);
+				}
+#pragma unroll
+				for(int off = 32; off > 0; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off));
+				maxc	= min(maxc, kSortRounds);
+				int run = 0;
+				for(int k = 0; k < maxc; ++k) {
+					const unsigned long long m0 = __ballot(my[0] > k), m1 = __ballot(my[1] > k), m2 = __ballot(my[2] > k), m3 = __ballot(my[3] > k);
+					const int p0 = __popcll(m0), p1 = p0 + __popcll(m1), p2 = p1 + __popcll(m2);
+					if(lane == 0) {
+						s_mask[k][0] = m0;
+						s_mask[k][1] = m1;
+						s_mask[k][2] = m2;
+						s_mask[k][3] = m3;
+						s_wordoff[k] = (unsigned) p0 << 8 | (unsigned) p1 << 16 | (unsigned) p2 << 24;
+						s_round0[k]	 = run;
+					}
+					run += p2 + __popcll(m3);
+				}
+				if(lane == 0) s_round0[kSortRounds] = run;// overflow records (k >= kSortRounds) go behind the sorted ones
+				s_cnt[lane] = 0;
+			}
+			__syncthreads();
+#pragma unroll
+			for(int it = 0; it < kSortChunk / 64; ++it) {
+				if(it * 64 + lane < nrec) {
+					const unsigned rec = packed[it] & rec_mask;
+					const int k		   = packed[it] >> 26;
+					const int c		   = (rec >> key_shift) & 255;
+					int pos;
+					if(k < kSortRounds) {
+						const int w = c >> 6;
+						pos			= s_round0[k] + (int) ((s_wordoff[k] >> (8 * w)) & 255u) + __popcll(s_mask[k][w] & ((1ull << (c & 63)) - 1ull));
+					} else {
+						pos = s_round0[kSortRounds] + atomicAdd(&s_cnt[0], 1);
+					}
+					s_sorted[pos] = (int) rec;
+				}
+			}
+			__syncthreads();
+#pragma unroll
+			for(int it = 0; it < kSortChunk / 64; ++it)
+				if(it * 64 + lane < nrec) list[chunk0 + it * 64 + lane] = s_sorted[it * 64 + lane];
+			__syncthreads();
+		}
+	}
+}
+
 // Phase timing (ABL & 32, profiling builds only): wall cycles (s_memtime) that wave 0..n spend in each part of the
 // iteration, summed over all waves.  [0] sort, [1] wait for prefetched particle data, [2] claim, [3] gather+scatter,
 // [4] F update + stress + particle stores, [5] re-bucket / list append, [6] prologue, [7] epilogue, [8] iterations.
@@ -496,24 +626,19 @@ __device__ unsigned long long g_prof[1024][20];// spread over 1024 rows: same-ad
 // 4 skip the G2P gather, 8 skip the interleave sort, 16 skip the particle stores.  Values are kept live with
 // empty asm statements so that the compiler cannot delete upstream work.
 template<int MAT, int ABL = 0>
-__global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_table, const int* __restrict__ cur_keys, const int* __restrict__ prev_table, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, float dt, float new_dt, int* __restrict__ status) {
+__global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_keys, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, float dt, float new_dt, int* __restrict__ status) {
 	constexpr int NCH = MatTraits<MAT>::nch;
 	__shared__ float4 g2p[kG2PNodes];// node velocities {vx,vy,vz,-} of arena nodes 1..6 per axis
 	__shared__ float4 p2g[kArenaNodes];// {mass, momentum} accumulators
-	__shared__ int s_sorted[kSortChunk];// advection records of the current chunk, interleaved by cell
-	__shared__ unsigned long long s_mask[kSortRounds][4];// per round: which of the 216 keys still have a k-th particle
-	__shared__ int s_round0[kSortRounds + 1];			  // first sorted position of round k
-	__shared__ unsigned s_wordoff[kSortRounds];			  // packed prefix of the four mask words' popcounts (3 x 8 bit)
-	__shared__ int s_cnt[256 - 32];// 216 keys used
+	__shared__ int s_sorted[kSortChunk];// advection records of the current chunk (sorted by prepare_blocks_kernel)
 	__shared__ unsigned char s_owner[216];
 	__shared__ int s_src_binoff[27], s_dst_no[27], s_nb[8];
 
 	const int lane = threadIdx.x;
 	const int b	   = block_list ? block_list[blockIdx.x] : (int) blockIdx.x;
-	// The per-block set-up is a chain of dependent global round trips (~2-4 us each under load, ~8 per block would be a
-	// third of the kernel): they are arranged in three waves of independent loads, and the LDS-only sort runs in the
-	// shadow of the last one.
-	// ---- round trip 1: everything addressed by the block number alone
+	// The per-block set-up is three waves of independent loads (a chain of ~8 dependent round trips of 2-4 us each would
+	// be a third of the kernel); sorting the records and the table look-ups happened in prepare_blocks_kernel.
+	// ---- round trip 1: everything addressed by the block number alone (scalar loads)
 	const int size		 = mv.size[b];
 	const int kx = cur_keys[3 * b], ky = cur_keys[3 * b + 1], kz = cur_keys[3 * b + 2];
 	const int row		 = mv.row_of[b];
@@ -530,31 +655,25 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 	const float mass	 = mv.mc.mass;
 	const int key_shift = cfg.pid_bits;
 	const int tag_shift = cfg.pid_bits + kKeyBits;
-	const unsigned rec_mask = (1u << (tag_shift + 5)) - 1u;
-	// ---- round trip 2: the first chunk's advection records (unconditional, clamped) and the 27 + 27 + 8 table look-ups
-	unsigned recs[kSortChunk / 64];
+	// ---- round trip 2: the first chunk's (sorted) advection records and the block's row of look-up results
 	auto load_records = [&](int chunk0) {
 		const int last = min(kSortChunk, size - chunk0) - 1;
+		int recs[kSortChunk / 64];
 #pragma unroll
-		for(int it = 0; it < kSortChunk / 64; ++it) recs[it] = (unsigned) list[chunk0 + min(it * 64 + lane, last)];
+		for(int it = 0; it < kSortChunk / 64; ++it) recs[it] = list[chunk0 + min(it * 64 + lane, last)];
+#pragma unroll
+		for(int it = 0; it < kSortChunk / 64; ++it) s_sorted[it * 64 + lane] = recs[it];
 	};
+	const int info = mv.blockinfo[(size_t) b * kInfoRow + lane];
 	load_records(0);
-	int srcno = -1;
-	if(lane < 27) {
-		int ox, oy, oz;
-		dir_components(lane, ox, oy, oz);
-		srcno		   = table_query(cfg, prev_table, kx + ox, ky + oy, kz + oz);
-		s_dst_no[lane] = table_query(cfg, cur_table, kx - ox, ky - oy, kz - oz);
-	} else if(lane >= 32 && lane < 40) {
-		const int lb = lane - 32;
-		s_nb[lb]	 = table_query(cfg, cur_table, kx + ((lb >> 2) & 1), ky + ((lb >> 1) & 1), kz + (lb & 1));
-	}
+	if(lane < 27) s_src_binoff[lane] = info;
+	else if(lane < 54) s_dst_no[lane - 27] = info;
+	else if(lane < 62) s_nb[lane - 54] = info;
 	for(int i = lane; i < kArenaNodes; i += 64) p2g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 	__syncthreads();
 	MPM_TICK(13)
-	// ---- round trip 3: source bin offsets and the 8 grid blocks (lane = cell -> 256-B rows per channel, :699-727); both
-	//      are consumed after the first chunk's sort
-	const int src_binoff = srcno >= 0 ? mv.binoff_src[srcno] : -1;
+	// ---- round trip 3: the 8 grid blocks (lane = cell -> 256-B rows per channel, :699-727) and - below, at the top of the
+	//      chunk loop - the first 64 particles
 	const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;// lane == cell of a 4x4x4 block
 	float4 gv[8];
 #pragma unroll
@@ -567,143 +686,53 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 		gv[lb].w		= 0.f;
 		if(nb < 0) gv[lb].x = gv[lb].y = gv[lb].z = 0.f;
 	}
-	auto stage_grid = [&]() {
-		if(lane < 27) s_src_binoff[lane] = src_binoff;
-#pragma unroll
-		for(int lb = 0; lb < 8; ++lb) {
-			const int ax = cx + ((lb & 4) ? 4 : 0) - 1, ay = cy + ((lb & 2) ? 4 : 0) - 1, az = cz + ((lb & 1) ? 4 : 0) - 1;
-			if(((unsigned) ax < 6u) & ((unsigned) ay < 6u) & ((unsigned) az < 6u)) g2p[ax * kG2PStrideX + ay * 8 + az] = gv[lb];
-		}
-	};
-
 	MPM_TICK(6)
-	// The first chunk is sorted here, while round trip 3 is in flight; further chunks (blocks with more than 1024
-	// particles) at the bottom of the chunk loop.  (A lambda inlined twice rather than a loop-carried `recs`: the
-	// records would otherwise occupy 16 registers throughout the main loop.)
-	auto sort_chunk = [&](int nrec) {
-		// ---- counting sort of the chunk's records into "k-th particle of every cell" order, so that the 64 lanes
-		//      of one iteration hold particles of 64 distinct cells (replaces cell_bucket_to_block, :70-84)
-		if constexpr(ABL & 8) {
-#pragma unroll
-			for(int it = 0; it < kSortChunk / 64; ++it)
-				if(it * 64 + lane < nrec) s_sorted[it * 64 + lane] = (int) recs[it];
-			__syncthreads();
+	// Software prefetch: the particle data of iteration i+1 is requested at the top of iteration i (HBM latency under
+	// load is 2-4 us and only two waves share a SIMD).  Two details keep the compiler's s_waitcnt insertion from
+	// turning this into a wait for everything (it only counts memory operations that are issued unconditionally):
+	// the loads are unconditional - lanes past the end of the chunk re-read its last record - and the wait for the
+	// data is forced at the END of iteration i (`touch`), in the same straight-line code as the 13 particle stores,
+	// where it is an exact `vmcnt(13)`; at the loop header it would be `vmcnt(0)`, i.e. include the stores'
+	// acknowledgements and the list-append atomics.
+	struct Prefetch {
+		float pos[3], st[10];
+		int key;// the stencil base this particle was predicted to have after this step (its sort key)
+	};
+	int nrec   = min(kSortChunk, size);
+	auto fetch = [&](int idx0, Prefetch& f) {
+		const int rec	 = s_sorted[min(idx0 + lane, nrec - 1)];
+		const int tag	 = rec >> tag_shift;
+		const int sp	 = rec & (cfg.ppb - 1);
+		const int sbin	 = s_src_binoff[tag] + (sp >> 6);
+		const float* src = mv.bins_src + (size_t) sbin * (NCH * kBin) + (sp & 63);
+		f.key			 = (rec >> key_shift) & 255;
+		f.pos[0]		 = src[0];
+		f.pos[1]		 = src[kBin];
+		f.pos[2]		 = src[2 * kBin];
+		if constexpr(MAT == 0) {
+			f.st[0] = src[3 * kBin];
 		} else {
-		// The sort key is the stencil base the particle is PREDICTED to have after this step's advection (computed one
-		// step ago from x + v dt, exact for > 99.9 % of the particles), so the 64 lanes of an iteration scatter to 64
-		// distinct stencil bases and the conflict-retry pass below almost never runs.
 #pragma unroll
-		for(int q = 0; q < 4; ++q)
-			if(lane + 64 * q < 224) s_cnt[lane + 64 * q] = 0;
-		__syncthreads();
-		unsigned packed[kSortChunk / 64];
-#pragma unroll
-		for(int it = 0; it < kSortChunk / 64; ++it) {
-			const int idx = it * 64 + lane;
-			packed[it]	  = 0u;
-			if(idx < nrec) {
-				const unsigned rec = recs[it] & rec_mask;
-				const int c		   = (rec >> key_shift) & 255;
-				const int k		   = atomicAdd(&s_cnt[c], 1);// ds_add_rtn_u32: integer LDS atomics run at full rate
-				packed[it]		   = rec | ((unsigned) min(k, kSortRounds) << 26);
-			}
-		}
-		__syncthreads();
-		MPM_TICK(14)
-		{
-			int my[4];
-			int maxc = 0;
-#pragma unroll
-			for(int q = 0; q < 4; ++q) {
-				my[q] = lane + 64 * q < 224 ? s_cnt[lane + 64 * q] : 0;
-				maxc  = max(maxc, my[q]);
-			}
-#pragma unroll
-			for(int off = 32; off > 0; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off));
-			maxc	= min(maxc, kSortRounds);
-			int run = 0;
-			for(int k = 0; k < maxc; ++k) {
-				const unsigned long long m0 = __ballot(my[0] > k), m1 = __ballot(my[1] > k), m2 = __ballot(my[2] > k), m3 = __ballot(my[3] > k);
-				const int p0 = __popcll(m0), p1 = p0 + __popcll(m1), p2 = p1 + __popcll(m2);
-				if(lane == 0) {
-					s_mask[k][0] = m0;
-					s_mask[k][1] = m1;
-					s_mask[k][2] = m2;
-					s_mask[k][3] = m3;
-					s_wordoff[k] = (unsigned) p0 << 8 | (unsigned) p1 << 16 | (unsigned) p2 << 24;
-					s_round0[k]	 = run;
-				}
-				run += p2 + __popcll(m3);
-			}
-			if(lane == 0) s_round0[kSortRounds] = run;// overflow records (k >= kSortRounds) go behind the sorted ones
-			s_cnt[lane] = 0;
-		}
-		__syncthreads();
-		MPM_TICK(15)
-#pragma unroll
-		for(int it = 0; it < kSortChunk / 64; ++it) {
-			if(it * 64 + lane < nrec) {
-				const unsigned rec = packed[it] & rec_mask;
-				const int k		   = packed[it] >> 26;
-				const int c		   = (rec >> key_shift) & 255;
-				int pos;
-				if(k < kSortRounds) {
-					const int w = c >> 6;
-					pos			= s_round0[k] + (int) ((s_wordoff[k] >> (8 * w)) & 255u) + __popcll(s_mask[k][w] & ((1ull << (c & 63)) - 1ull));
-				} else {
-					pos = s_round0[kSortRounds] + atomicAdd(&s_cnt[0], 1);
-				}
-				s_sorted[pos] = (int) rec;
-			}
-		}
-		__syncthreads();
+			for(int d = 0; d < 9; ++d) f.st[d] = src[(3 + d) * kBin];
+			if constexpr(NCH == 13) f.st[9] = src[12 * kBin];
 		}
 	};
-	sort_chunk(min(kSortChunk, size));
-	MPM_TICK(16)
-	stage_grid();// the grid blocks and bin offsets requested before the sort have arrived by now
+	auto touch = [&](Prefetch& f) {
+#pragma unroll
+		for(int d = 0; d < 3; ++d) __asm__ volatile("" : "+v"(f.pos[d]));
+#pragma unroll
+		for(int d = 0; d < (MAT == 0 ? 1 : (NCH == 13 ? 10 : 9)); ++d) __asm__ volatile("" : "+v"(f.st[d]));
+	};
+	Prefetch pf;
+	fetch(0, pf);// the first 64 particles are in flight while the grid blocks requested above go to LDS
+#pragma unroll
+	for(int lb = 0; lb < 8; ++lb) {
+		const int ax = cx + ((lb & 4) ? 4 : 0) - 1, ay = cy + ((lb & 2) ? 4 : 0) - 1, az = cz + ((lb & 1) ? 4 : 0) - 1;
+		if(((unsigned) ax < 6u) & ((unsigned) ay < 6u) & ((unsigned) az < 6u)) g2p[ax * kG2PStrideX + ay * 8 + az] = gv[lb];
+	}
 	__syncthreads();
 	MPM_TICK(17)
 	for(int chunk0 = 0;;) {
-		const int nrec = min(kSortChunk, size - chunk0);
-
-		// Software prefetch: the particle data of iteration i+1 is requested at the top of iteration i (HBM latency under
-		// load is 2-4 us and only two waves share a SIMD).  Two details keep the compiler's s_waitcnt insertion from
-		// turning this into a wait for everything (it only counts memory operations that are issued unconditionally):
-		// the loads are unconditional - lanes past the end of the chunk re-read its last record - and the wait for the
-		// data is forced at the END of iteration i (`touch`), in the same straight-line code as the 13 particle stores,
-		// where it is an exact `vmcnt(13)`; at the loop header it would be `vmcnt(0)`, i.e. include the stores'
-		// acknowledgements and the list-append atomics.
-		struct Prefetch {
-			float pos[3], st[10];
-			int key;// the stencil base this particle was predicted to have after this step (its sort key)
-		};
-		auto fetch = [&](int idx0, Prefetch& f) {
-			const int rec	 = s_sorted[min(idx0 + lane, nrec - 1)];
-			const int tag	 = rec >> tag_shift;
-			const int sp	 = rec & (cfg.ppb - 1);
-			const int sbin	 = s_src_binoff[tag] + (sp >> 6);
-			const float* src = mv.bins_src + (size_t) sbin * (NCH * kBin) + (sp & 63);
-			f.key			 = (rec >> key_shift) & 255;
-			f.pos[0]		 = src[0];
-			f.pos[1]		 = src[kBin];
-			f.pos[2]		 = src[2 * kBin];
-			if constexpr(MAT == 0) {
-				f.st[0] = src[3 * kBin];
-			} else {
-#pragma unroll
-				for(int d = 0; d < 9; ++d) f.st[d] = src[(3 + d) * kBin];
-				if constexpr(NCH == 13) f.st[9] = src[12 * kBin];
-			}
-		};
-		auto touch = [&](Prefetch& f) {
-#pragma unroll
-			for(int d = 0; d < 3; ++d) __asm__ volatile("" : "+v"(f.pos[d]));
-#pragma unroll
-			for(int d = 0; d < (MAT == 0 ? 1 : (NCH == 13 ? 10 : 9)); ++d) __asm__ volatile("" : "+v"(f.st[d]));
-		};
-		Prefetch pf;
-		fetch(0, pf);
 		touch(pf);
 		MPM_TICK(1)
 		// Software pipeline: the scatter of iteration i-1 (an ordered chain of 27 LDS round trips) is issued inside
@@ -938,7 +967,9 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 		chunk0 += kSortChunk;
 		if(chunk0 >= size) break;
 		load_records(chunk0);
-		sort_chunk(min(kSortChunk, size - chunk0));
+		__syncthreads();
+		nrec = min(kSortChunk, size - chunk0);
+		fetch(0, pf);
 		MPM_TICK(0)
 	}
 	// ---- arena -> next grid: one hardware f32 atomic per touched node, 256-B rows (:907-936)
