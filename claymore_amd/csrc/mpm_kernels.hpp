@@ -28,6 +28,7 @@
 // copy_selected_grid_blocks :1002-1020, retrieve_particle_buffer :1087-1122.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "mpm_device_math.hpp"
 #include "mpm_collision.hpp"
@@ -497,7 +498,10 @@ struct PrepareModels {
 };
 template<bool SORT>
 __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, PrepareModels pm, const int* __restrict__ pbc_ptr, const int* __restrict__ cur_table, const int* __restrict__ cur_keys, const int* __restrict__ prev_table) {
-	__shared__ int s_sorted[kSortChunk];
+	// records are sorted in chunks of 512 (8 per lane): G2P2G only needs every aligned 64-record slice to hold distinct keys,
+	// and the smaller chunk keeps this kernel at 3.9 KB of LDS, i.e. at the hardware's wave limit
+	constexpr int kPrepChunk = 512;
+	__shared__ int s_sorted[kPrepChunk];
 	__shared__ unsigned long long s_mask[kSortRounds][4];// per round: which of the 216 keys still have a k-th particle
 	__shared__ int s_round0[kSortRounds + 1];			  // first sorted position of round k
 	__shared__ unsigned s_wordoff[kSortRounds];			  // packed prefix of the four mask words' popcounts (3 x 8 bit)
@@ -525,24 +529,31 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 	const unsigned rec_mask = (1u << (tag_shift + 5)) - 1u;
 	for(int m = 0; m < pm.n; ++m) {
 		int info = other;
-		if(lane < 27) info = srcno >= 0 ? pm.binoff_src[m][srcno] : -1;
-		pm.blockinfo[m][(size_t) b * kInfoRow + lane] = info;
-		if constexpr(!SORT) continue;
+		if constexpr(SORT) {
 		const int size = pm.size[m][b];
 		int* list	   = pm.list[m] + (size_t) pm.row_of[m][b] * cfg.ppb;
-		for(int chunk0 = 0; chunk0 < size; chunk0 += kSortChunk) {
-			const int nrec = min(kSortChunk, size - chunk0);
+		constexpr int NIT = kPrepChunk / 64;
+		unsigned recs[NIT];
+		auto load_chunk = [&](int chunk0, int nrec) {// unconditional, clamped: all loads of a chunk are in flight together
+#pragma unroll
+			for(int it = 0; it < NIT; ++it) recs[it] = (unsigned) list[chunk0 + min(it * 64 + lane, nrec - 1)];
+		};
+		if(size > 0) load_chunk(0, min(kPrepChunk, size));
+		// the bin offsets of the 27 source blocks: the look-up issued at the top has arrived by now, this dependent load
+		// overlaps the LDS-only sort below
+		if(lane < 27) info = srcno >= 0 ? pm.binoff_src[m][srcno] : -1;
+		auto sort_chunk = [&](int chunk0, int nrec) {
 #pragma unroll
 			for(int q = 0; q < 4; ++q)
 				if(lane + 64 * q < 224) s_cnt[lane + 64 * q] = 0;
 			__syncthreads();
-			unsigned packed[kSortChunk / 64];
+			unsigned packed[NIT];
 #pragma unroll
-			for(int it = 0; it < kSortChunk / 64; ++it) {
+			for(int it = 0; it < NIT; ++it) {
 				const int idx = it * 64 + lane;
 				packed[it]	  = 0u;
 				if(idx < nrec) {
-					const unsigned rec = (unsigned) list[chunk0 + idx] & rec_mask;
+					const unsigned rec = recs[it] & rec_mask;
 					const int c		   = (rec >> key_shift) & 255;
 					const int k		   = atomicAdd(&s_cnt[c], 1);// ds_add_rtn_u32: integer LDS atomics run at full rate
 					packed[it]		   = rec | ((unsigned) min(k, kSortRounds) << 26);
@@ -579,7 +590,7 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 			}
 			__syncthreads();
 #pragma unroll
-			for(int it = 0; it < kSortChunk / 64; ++it) {
+			for(int it = 0; it < NIT; ++it) {
 				if(it * 64 + lane < nrec) {
 					const unsigned rec = packed[it] & rec_mask;
 					const int k		   = packed[it] >> 26;
@@ -596,10 +607,19 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 			}
 			__syncthreads();
 #pragma unroll
-			for(int it = 0; it < kSortChunk / 64; ++it)
+			for(int it = 0; it < NIT; ++it)
 				if(it * 64 + lane < nrec) list[chunk0 + it * 64 + lane] = s_sorted[it * 64 + lane];
 			__syncthreads();
+		};
+		for(int chunk0 = 0; chunk0 < size; chunk0 += kPrepChunk) {
+			if(chunk0) load_chunk(chunk0, min(kPrepChunk, size - chunk0));
+			sort_chunk(chunk0, min(kPrepChunk, size - chunk0));
 		}
+		}
+		if constexpr(!SORT) {
+			if(lane < 27) info = srcno >= 0 ? pm.binoff_src[m][srcno] : -1;
+		}
+		pm.blockinfo[m][(size_t) b * kInfoRow + lane] = info;
 	}
 }
 
