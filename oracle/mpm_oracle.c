@@ -78,6 +78,7 @@ typedef struct mpmo_ctx {
 	int halo_tagged;
 	float last_max_vel_sqr;
 	int peer_rows_max;
+	int threads; /* OpenMP threads over particle blocks in G2P2G (timing only; 1 = the deterministic serial order) */
 	/* collision object (Projects/MGSP/boundary_condition.cuh) */
 	int has_collision;
 	mpm_collision_object col;
@@ -104,6 +105,13 @@ int mpmo_default_config(int domain_bits, mpm_config* cfg) {
 	cfg->max_blocks		 = 0;
 	cfg->grow			 = 1; /* the oracle does not re-allocate: with grow set, max_blocks is only the INITIAL capacity and the
 						   oracle sizes itself from the models (6 x particle blocks, as with max_blocks = 0) */
+	return MPM_OK;
+}
+
+/* oracle-only: OpenMP threads for G2P2G (bench.py cpu_baseline); 1 restores the deterministic serial order */
+int mpmo_set_threads(mpmo_ctx* c, int n) {
+	if(!c || n < 1) return MPM_ERR_INVALID;
+	c->threads = n;
 	return MPM_OK;
 }
 
@@ -326,9 +334,12 @@ static inline void add_advection(mpmo_ctx* c, orc_pbuf* b, const orc_partition* 
 	const int blockno = part_query(c, table, bx, by, bz);
 	if(blockno == -1) return; /* particle is lost, :105-113 */
 	const int cellno = ((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3);
-	int* cnt		 = b->cell_counts + (size_t) blockno * ORC_BLOCKVOL + cellno;
-	const int slot	 = (*cnt)++;
+	int* cnt = b->cell_counts + (size_t) blockno * ORC_BLOCKVOL + cellno;
+	int slot;
+#pragma omp atomic capture
+	slot = (*cnt)++;
 	if(slot >= c->cfg.max_ppc) {
+#pragma omp atomic
 		(*cnt)--;
 		return;
 	}
@@ -718,9 +729,14 @@ static void g2p2g_model(mpmo_ctx* c, orc_model* m, float dt, float new_dt, const
 	const orc_pbuf* src		  = &m->buf[r];
 	orc_pbuf* dst			  = &m->buf[n];
 	const float dx = c->dx, dx_inv = c->dx_inv, d_inv = c->d_inv;
-	static float g2p[3][8][8][8];
-	static float p2g[4][8][8][8];
-	for(int bi = 0; bi < (block_list ? nlist : c->pbc); ++bi) {
+	const int nloop = block_list ? nlist : c->pbc;
+	/* Serial by default (the parity tests rely on the fixed summation order).  mpmo_set_threads(n > 1) runs the particle
+	 * blocks on n OpenMP threads for the multi-core cpu_baseline of bench.py: arenas become thread private, grid
+	 * accumulation and cell counters atomic - the same algorithm, only the float summation order into the grid varies. */
+#pragma omp parallel for schedule(dynamic, 4) num_threads(c->threads > 1 ? c->threads : 1) if(c->threads > 1)
+	for(int bi = 0; bi < nloop; ++bi) {
+		float g2p[3][8][8][8];
+		float p2g[4][8][8][8];
 		const int b		   = block_list ? block_list[bi] : bi;
 		const int* blockid = cur->keys + 3 * b;
 		const int size	   = dst->bucket_sizes[b];
@@ -852,7 +868,9 @@ static void g2p2g_model(mpmo_ctx* c, orc_model* m, float dt, float new_dt, const
 				for(int cx = 0; cx < 4; ++cx)
 					for(int cy = 0; cy < 4; ++cy)
 						for(int cz = 0; cz < 4; ++cz) {
-							gb[ch * 64 + cx * 16 + cy * 4 + cz] += p2g[ch][cx + ((lb & 4) ? 4 : 0)][cy + ((lb & 2) ? 4 : 0)][cz + ((lb & 1) ? 4 : 0)];
+							const float add = p2g[ch][cx + ((lb & 4) ? 4 : 0)][cy + ((lb & 2) ? 4 : 0)][cz + ((lb & 1) ? 4 : 0)];
+#pragma omp atomic
+							gb[ch * 64 + cx * 16 + cy * 4 + cz] += add;
 						}
 		}
 	}

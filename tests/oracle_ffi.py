@@ -27,4 +27,6 @@ def oracle_api():
         lib.mpmo_fn_jfluid.argtypes = [C.c_void_p, C.c_void_p, sz, f, f, f, f, f, f, C.c_void_p]
         lib.mpmo_check_table.argtypes = [C.c_void_p]
         lib.mpmo_check_table.restype = i
+        lib.mpmo_set_threads.argtypes = [C.c_void_p, i]
+        lib.mpmo_set_threads.restype = i
     return _api
