@@ -19,6 +19,8 @@ namespace mpm {
 #endif
 #endif
 
+typedef float v2f_ __attribute__((ext_vector_type(2)));// rows 0 and 1 of a 3-vector / matrix column: packed fp32 (v_pk_*_f32)
+
 // Projects/GMPM/utility_funcs.hpp:10-19 — quadratic B-spline weights; d = offset from the base node in cells
 MPM_DEV void bspline_weight_cells(float d, float (&w)[3]) {
 	const float a = 1.5f - d;
@@ -39,20 +41,28 @@ MPM_DEV int node_index(float x, float dx_inv) {
 	return lround_pos(x * dx_inv);
 }
 
-// Library/MnBase/Math/Matrix/MatrixUtils.h:147-157 (column-major)
+// Library/MnBase/Math/Matrix/MatrixUtils.h:147-157 (column-major).  Rows 0 and 1 of every column go through packed fp32
+// (v_pk_mul_f32 / v_pk_fma_f32 with the scalar of b broadcast by op_sel): 3 x (3 packed + 3 scalar) instead of 27 instructions.
 MPM_DEV void matmul3(const float (&a)[9], const float (&b)[9], float (&c)[9]) {
+	const v2f_ a0 = {a[0], a[1]}, a1 = {a[3], a[4]}, a2 = {a[6], a[7]};
 #pragma unroll
 	for(int j = 0; j < 3; ++j) {
-#pragma unroll
-		for(int i = 0; i < 3; ++i) c[3 * j + i] = a[i] * b[3 * j] + a[3 + i] * b[3 * j + 1] + a[6 + i] * b[3 * j + 2];
+		const v2f_ xy = a0 * b[3 * j] + a1 * b[3 * j + 1] + a2 * b[3 * j + 2];
+		c[3 * j]	  = xy.x;
+		c[3 * j + 1]  = xy.y;
+		c[3 * j + 2]  = a[2] * b[3 * j] + a[5] * b[3 * j + 1] + a[8] * b[3 * j + 2];
 	}
 }
 // MatrixUtils.h:29-41: out = m1 * diag * m2^T
 MPM_DEV void mat_diag_matT(float (&out)[9], const float (&m1)[9], const float (&dg)[3], const float (&m2)[9]) {
+	const v2f_ c0 = {m1[0], m1[1]}, c1 = {m1[3], m1[4]}, c2 = {m1[6], m1[7]};
 #pragma unroll
 	for(int j = 0; j < 3; ++j) {
-#pragma unroll
-		for(int i = 0; i < 3; ++i) out[3 * j + i] = m1[i] * dg[0] * m2[j] + m1[3 + i] * dg[1] * m2[3 + j] + m1[6 + i] * dg[2] * m2[6 + j];
+		const float t0 = dg[0] * m2[j], t1 = dg[1] * m2[3 + j], t2 = dg[2] * m2[6 + j];
+		const v2f_ xy  = c0 * t0 + c1 * t1 + c2 * t2;
+		out[3 * j]	   = xy.x;
+		out[3 * j + 1] = xy.y;
+		out[3 * j + 2] = m1[2] * t0 + m1[5] * t1 + m1[8] * t2;
 	}
 }
 // P F^T * volume (tail of constitutive_models.cuh:63-72)
@@ -127,12 +137,15 @@ MPM_DEV void jacobi_conj(float& s11, float& s21, float& s22, float& s31, float& 
 	s11				= n11 + t2;
 	s22				= n22 - t2;
 	// V <- V G
-#pragma unroll
-	for(int r = 0; r < 3; ++r) {
-		const float a = vp[r], b = vq[r];
-		vp[r]		  = c * a + s * b;
-		vq[r]		  = c * b - s * a;
-	}
+	const v2f_ p = {vp[0], vp[1]}, q = {vq[0], vq[1]};
+	const v2f_ pn = p * c + q * s, qn = q * c - p * s;
+	const float pz = vp[2], qz = vq[2];
+	vp[0] = pn.x;
+	vp[1] = pn.y;
+	vp[2] = c * pz + s * qz;
+	vq[0] = qn.x;
+	vq[1] = qn.y;
+	vq[2] = c * qz - s * pz;
 }
 
 MPM_DEV void cond_swap(bool c, float& x, float& y) {
@@ -236,11 +249,19 @@ MPM_DEV void svd3(const float (&F)[9], float (&U)[9], float (&S)[3], float (&V)[
 	MPM_MARK("svd_post");
 	// B = F V (svd.cuh:532-588), columns b1 b2 b3
 	float b1[3], b2[3], b3[3];
-#pragma unroll
-	for(int r = 0; r < 3; ++r) {
-		b1[r] = F[r] * v1[0] + F[3 + r] * v1[1] + F[6 + r] * v1[2];
-		b2[r] = F[r] * v2[0] + F[3 + r] * v2[1] + F[6 + r] * v2[2];
-		b3[r] = F[r] * v3[0] + F[3 + r] * v3[1] + F[6 + r] * v3[2];
+	{
+		const v2f_ f0 = {F[0], F[1]}, f1 = {F[3], F[4]}, f2 = {F[6], F[7]};
+#define MPM_FV(bk, vk)                                            \
+	{                                                             \
+		const v2f_ xy = f0 * vk[0] + f1 * vk[1] + f2 * vk[2];     \
+		bk[0]		  = xy.x;                                     \
+		bk[1]		  = xy.y;                                     \
+		bk[2]		  = F[2] * vk[0] + F[5] * vk[1] + F[8] * vk[2]; \
+	}
+		MPM_FV(b1, v1)
+		MPM_FV(b2, v2)
+		MPM_FV(b3, v3)
+#undef MPM_FV
 	}
 	float n1 = b1[0] * b1[0] + b1[1] * b1[1] + b1[2] * b1[2];
 	float n2 = b2[0] * b2[0] + b2[1] * b2[1] + b2[2] * b2[2];
@@ -426,23 +447,24 @@ MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, 
 	// (mu == 0 leaves F as it is and ln S = -inf: the reference's P is NaN then, and so is this.)  No branch here on
 	// purpose: stores to PF in two arms get merged into one store with a variable offset, which keeps PF in scratch.
 	{
-		float d[3], UD[9];
+		float d[3];
 #pragma unroll
 		for(int k = 0; k < 3; ++k) d[k] = (scaled_mu * lnS[k] + mc.lambda * trace_log_S) * mc.volume;
-#pragma unroll
-		for(int k = 0; k < 3; ++k) {
-#pragma unroll
-			for(int i = 0; i < 3; ++i) UD[3 * k + i] = U[3 * k + i] * d[k];
-		}
-		PF[0] = UD[0] * U[0] + UD[3] * U[3] + UD[6] * U[6];
-		PF[1] = UD[1] * U[0] + UD[4] * U[3] + UD[7] * U[6];
-		PF[2] = UD[2] * U[0] + UD[5] * U[3] + UD[8] * U[6];
-		PF[4] = UD[1] * U[1] + UD[4] * U[4] + UD[7] * U[7];
-		PF[5] = UD[2] * U[1] + UD[5] * U[4] + UD[8] * U[7];
-		PF[8] = UD[2] * U[2] + UD[5] * U[5] + UD[8] * U[8];
-		PF[3] = PF[1];
-		PF[6] = PF[2];
-		PF[7] = PF[5];
+		const v2f_ u0 = {U[0], U[1]}, u1 = {U[3], U[4]}, u2 = {U[6], U[7]};
+		const v2f_ ud0 = u0 * d[0], ud1 = u1 * d[1], ud2 = u2 * d[2];
+		const float udz0 = U[2] * d[0], udz1 = U[5] * d[1], udz2 = U[8] * d[2];
+		const v2f_ c0 = ud0 * U[0] + ud1 * U[3] + ud2 * U[6];// (PF00, PF10)
+		const v2f_ c1 = ud0 * U[1] + ud1 * U[4] + ud2 * U[7];// (PF01, PF11)
+		const v2f_ c2 = ud0 * U[2] + ud1 * U[5] + ud2 * U[8];// (PF02, PF12)
+		PF[0] = c0.x;
+		PF[1] = c0.y;
+		PF[3] = c0.y;
+		PF[4] = c1.y;
+		PF[6] = c2.x;
+		PF[7] = c2.y;
+		PF[2] = c2.x;
+		PF[5] = c2.y;
+		PF[8] = udz0 * U[2] + udz1 * U[5] + udz2 * U[8];
 	}
 	hk.template at<BASE + kSvdSites + 3>();
 }

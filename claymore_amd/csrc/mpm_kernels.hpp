@@ -655,7 +655,12 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 	__shared__ int s_src_binoff[27], s_dst_no[27], s_nb[8];
 
 	const int lane = threadIdx.x;
-	const int b	   = block_list ? block_list[blockIdx.x] : (int) blockIdx.x;
+	// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Consecutive block numbers are spatial
+	// neighbours (they share grid blocks: reads in the set-up, atomics in the write-back), so every XCD gets one contiguous
+	// eighth of the block range instead of every eighth block.
+	const int nwg = (int) gridDim.x, xcd = (int) (blockIdx.x & 7u), q = (int) (blockIdx.x >> 3);
+	const int bid = xcd * (nwg >> 3) + min(xcd, nwg & 7) + q;// XCD r owns (nwg / 8) + (r < nwg % 8) consecutive numbers
+	const int b	  = block_list ? block_list[bid] : bid;
 	// The per-block set-up is three waves of independent loads (a chain of ~8 dependent round trips of 2-4 us each would
 	// be a third of the kernel); sorting the records and the table look-ups happened in prepare_blocks_kernel.
 	// ---- round trip 1: everything addressed by the block number alone (scalar loads)
