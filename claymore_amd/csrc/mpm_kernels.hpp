@@ -805,10 +805,11 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 			bool win = false;
 			if constexpr(!(ABL & 1)) {
 				if(have_prev) {
+					// one LDS round trip: the workgroup is a single wave, whose LDS operations execute in order, so the read
+					// below sees the write above without waiting for it in between
 					if(pv_in) s_owner[pv_key] = (unsigned char) lane;
-					__syncthreads();
+					__asm__ volatile("" ::: "memory");// another lane may have written the same byte: no store-to-load forwarding
 					win = pv_in && (int) s_owner[pv_key] == lane;
-					__syncthreads();
 					if constexpr(ABL & 32) {
 						if(__all(win || !pv_in)) t_acc[9] += 1;
 						else t_acc[10] += 1;
