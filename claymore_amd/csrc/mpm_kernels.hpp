@@ -6,13 +6,15 @@
 //   * G2P2G workgroup = ONE wave = one particle block.  The 8 neighbouring grid blocks are staged through LDS
 //     once (float4 {vx,vy,vz,-} per node -> one ds_read_b96 per stencil node).  The P2G scatter is atomic-free:
 //     gfx950 serialises ds_add_f32 (193 cycles per wave-instruction, profiles/r01_lds_microbench.txt), so the
-//     advection records of a block are counting-sorted in LDS into "k-th particle of every cell" order, the 64
-//     lanes of an iteration therefore hold 64 distinct cells, and each lane read-modify-writes its 27 float4
-//     nodes {m, px, py, pz} with plain ds_read_b128/ds_write_b128 (lanes whose particle changed cell and collide
-//     with another lane's stencil base are detected through an LDS owner table and retried).  The arena is
-//     written back with one hardware f32 atomic per touched node and channel;
+//     advection records of a block are counting-sorted (prepare_blocks_kernel, once per substep) into "k-th
+//     particle of every key" order, key = predicted stencil base; the 64 lanes of an iteration therefore hold 64
+//     distinct bases, and each lane read-modify-writes its 27 float4 nodes {m, px, py, pz} with plain
+//     ds_read_b128/ds_write_b128 - a chain of 27 ordered LDS round trips that ScatterChain threads through the
+//     NEXT particle's gather / SVD / stress arithmetic (lanes that collide with another lane's stencil base are
+//     detected through an LDS owner table and retried).  The arena is written back with one hardware f32 atomic
+//     per touched node and channel;
 //   * block-level advection lists instead of the reference's cell buckets + compaction passes: a particle
-//     appends ONE 4-byte record {direction tag, cell, slot} to the list of the block it lands in
+//     appends ONE 4-byte record {direction tag, predicted stencil base, slot} to the list of the block it lands in
 //     (wave-aggregated atomic for the particles that stay), and next step's G2P2G consumes that list
 //     directly through a row indirection - 8 B/particle of bookkeeping traffic instead of 24 B and three
 //     kernels fewer (reference: add_advection + cell_bucket_to_block + update_buckets);
@@ -40,7 +42,7 @@ constexpr int kG2P2GThreads = 64; // ONE wave per particle block: no cross-wave 
 constexpr int kMaxModels  = 8;
 constexpr int kArenaStrideX = 68; // arena x stride in float4 nodes (64 + 4: keeps every b128 lane group on 16 distinct 16-B slots)
 constexpr int kArenaNodes	= 544;// >= 7*68 + 7*8 + 7 + 1
-constexpr int kSortChunk	= 1024;// advection records sorted per pass (a block with more particles takes several passes)
+constexpr int kSortChunk	= 1024;// advection records staged in LDS per pass of g2p2g (a block with more particles takes several passes)
 constexpr int kSortRounds	= 24;  // particles per key (per chunk) that get an exact interleaved position; more -> appended behind
 constexpr int kSortKeys		= 216; // sort key = PREDICTED stencil base of the particle in the arena of its block (6^3 values)
 constexpr int kKeyBits		= 8;
@@ -624,8 +626,7 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 }
 
 // Phase timing (ABL & 32, profiling builds only): wall cycles (s_memtime) that wave 0..n spend in each part of the
-// iteration, summed over all waves.  [0] sort, [1] wait for prefetched particle data, [2] claim, [3] gather+scatter,
-// [4] F update + stress + particle stores, [5] re-bucket / list append, [6] prologue, [7] epilogue, [8] iterations.
+// iteration, summed over all waves (slot names: claymore_hip.hip, mpm_destroy); profiles/r01_phase_timing.txt.
 __device__ unsigned long long g_prof[1024][20];// spread over 1024 rows: same-address atomics serialise
 #define MPM_TICK(slot) \
 	if constexpr(ABL & 32) { \
@@ -643,8 +644,8 @@ __device__ unsigned long long g_prof[1024][20];// spread over 1024 rows: same-ad
 #endif
 
 // ABL: ablation mask for profiling builds (0 in production): 1 skip the P2G scatter, 2 skip the stress (SVD),
-// 4 skip the G2P gather, 8 skip the interleave sort, 16 skip the particle stores.  Values are kept live with
-// empty asm statements so that the compiler cannot delete upstream work.
+// 4 skip the G2P gather, 32 phase timing (below).  Values are kept live with empty asm statements so that the compiler
+// cannot delete upstream work.
 template<int MAT, int ABL = 0>
 __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_keys, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, float dt, float new_dt, int* __restrict__ status) {
 	constexpr int NCH = MatTraits<MAT>::nch;
