@@ -102,7 +102,7 @@ struct mpm_ctx {
 // the grid update leaves its running maximum in kMaxVelSlots slots (non-negative floats; inf marks a NaN velocity)
 static float host_maxvel(const mpm_ctx* ctx) {
 	float m = 0.f;
-	for(int i = 0; i < kMaxVelSlots; ++i) m = std::max(m, ctx->h_maxvel[i]);
+	for(int i = 0; i < kMaxVelSlots; ++i) m = std::max(m, ctx->h_maxvel[i * kMaxVelStride]);
 	return m;
 }
 
@@ -356,8 +356,8 @@ int mpm_initial_setup(mpm_ctx* ctx) {
 	const int r = ctx->rollid, n = r ^ 1;
 	HIP_TRY(dalloc(&ctx->d_status, ST_WORDS));
 	HIP_TRY(hipHostMalloc((void**) &ctx->h_status, sizeof(int) * ST_WORDS));
-	HIP_TRY(dalloc(&ctx->d_maxvel, kMaxVelSlots));
-	HIP_TRY(hipHostMalloc((void**) &ctx->h_maxvel, sizeof(float) * kMaxVelSlots));
+	HIP_TRY(dalloc(&ctx->d_maxvel, kMaxVelSlots * kMaxVelStride));
+	HIP_TRY(hipHostMalloc((void**) &ctx->h_maxvel, sizeof(float) * kMaxVelSlots * kMaxVelStride));
 	HIP_TRY(dalloc(&ctx->d_totals, 4));
 	HIP_TRY(dalloc(&ctx->d_counter, 1));
 	HIP_TRY(hipMemsetAsync(ctx->d_status, 0, sizeof(int) * ST_WORDS, s));
@@ -459,7 +459,7 @@ int mpm_initial_setup(mpm_ctx* ctx) {
 // grid-update phase, gmpm_simulator.cuh:326-347
 static int launch_grid_update(mpm_ctx* ctx, float dt) {
 	hipStream_t s = ctx->s_compute;
-	HIP_TRY(hipMemsetAsync(ctx->d_maxvel, 0, sizeof(unsigned) * kMaxVelSlots, s));
+	HIP_TRY(hipMemsetAsync(ctx->d_maxvel, 0, sizeof(unsigned) * kMaxVelSlots * kMaxVelStride, s));
 	if(ctx->nbc) {
 		if(ctx->has_collision)
 			grid_update_collision_kernel<<<cdiv(ctx->nbc, 4), 256, 0, s>>>(ctx->g, ctx->nbc, ctx->grid[0], ctx->part[ctx->rollid].keys, dt, ctx->collision, ctx->d_maxvel);
@@ -477,7 +477,7 @@ int mpm_grid_update(mpm_ctx* ctx, float dt, float* max_vel_sqr) {
 	int rc = launch_grid_update(ctx, dt);
 	if(rc) return rc;
 	HIP_TRY(hipEventRecord(ctx->ev_b, s));
-	HIP_TRY(hipMemcpyAsync(ctx->h_maxvel, ctx->d_maxvel, sizeof(float) * kMaxVelSlots, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(ctx->h_maxvel, ctx->d_maxvel, sizeof(float) * kMaxVelSlots * kMaxVelStride, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
 	HIP_TRY(hipEventElapsedTime(&ctx->timers.grid_update_ms, ctx->ev_a, ctx->ev_b));
 	if(max_vel_sqr) *max_vel_sqr = host_maxvel(ctx);
@@ -749,7 +749,7 @@ int mpm_run_fixed(mpm_ctx* ctx, int nsteps, float dt) {
 		rc = launch_rebuild(ctx);
 		if(rc) return rc;
 		HIP_TRY(hipEventRecord(ctx->ev_b, s));
-		HIP_TRY(hipMemcpyAsync(ctx->h_maxvel, ctx->d_maxvel, sizeof(float) * kMaxVelSlots, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipMemcpyAsync(ctx->h_maxvel, ctx->d_maxvel, sizeof(float) * kMaxVelSlots * kMaxVelStride, hipMemcpyDeviceToHost, s));
 		HIP_TRY(hipGetLastError());
 		rc = finish_rebuild(ctx, nullptr);
 		if(rc) return rc;

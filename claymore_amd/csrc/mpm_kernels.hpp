@@ -105,7 +105,8 @@ __device__ __forceinline__ int wave_append(int* counter, bool pred) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-constexpr int kMaxVelSlots = 64;// the running maximum is kept in 64 slots (by workgroup): same-address atomics serialise in L2 (~11 ns each)
+constexpr int kMaxVelSlots	 = 64;// the running maximum is kept in 64 slots (by workgroup): same-address atomics serialise in L2 (~11 ns each)
+constexpr int kMaxVelStride = 32;// ... one slot per 128-B line: the filtering loads of 20 k waves then spread over the L2 channels
 // Grid update: momentum -> velocity, gravity, slip walls, max |v|^2.   One wave per grid block, lane = cell.
 // (update_grid_velocity_query_max, mgmpm_kernels.cuh:325-420)
 // ------------------------------------------------------------------------------------------------------
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void grid_update_kernel(GridCfg cfg, int nbloc
 	// the running maximum only grows, so a plain (possibly stale) read filters almost all of them out.
 	if((threadIdx.x & 63) == 0 && vel_sqr > 0.f) {
 		const unsigned bits = __float_as_uint(vel_sqr);
-		unsigned* slot		= max_vel_bits + (blockIdx.x & (kMaxVelSlots - 1));
+		unsigned* slot		= max_vel_bits + (blockIdx.x & (kMaxVelSlots - 1)) * kMaxVelStride;
 		if(bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
 	}
 }
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void grid_update_collision_kernel(GridCfg cfg,
 	for(int off = 32; off > 0; off >>= 1) vel_sqr = fmaxf(vel_sqr, __shfl_xor(vel_sqr, off));
 	if((threadIdx.x & 63) == 0 && vel_sqr > 0.f) {
 		const unsigned bits = __float_as_uint(vel_sqr);
-		unsigned* slot		= max_vel_bits + (blockIdx.x & (kMaxVelSlots - 1));
+		unsigned* slot		= max_vel_bits + (blockIdx.x & (kMaxVelSlots - 1)) * kMaxVelStride;
 		if(bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
 	}
 }
