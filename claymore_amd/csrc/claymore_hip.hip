@@ -236,7 +236,11 @@ int mpm_create(const mpm_config* cfg, int device, mpm_ctx** out) {
 	g.d_inv	   = 4.f * g.dx_inv * g.dx_inv;
 	g.gravity  = cfg->gravity;
 	g.cap	   = 0;
-	if(hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->s_compute, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ctx->s_comm, hipStreamNonBlocking) != hipSuccess) {
+	// the comm stream gets the highest priority: its small collect / reduce kernels (and RCCL's) are enqueued BEHIND the big
+	// interior G2P2G and must not wait for it to drain
+	int prio_lo = 0, prio_hi = 0;
+	if(hipSetDevice(device) == hipSuccess) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+	if(hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->s_compute, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithPriority(&ctx->s_comm, hipStreamNonBlocking, prio_hi) != hipSuccess) {
 		delete ctx;
 		return MPM_ERR_DEVICE;
 	}

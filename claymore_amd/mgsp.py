@@ -154,6 +154,12 @@ class MgspRank:
             self.buf_send = torch.empty(int(need * 1.5) + ROW, dtype=torch.float32, device=self.tdev)
             self.buf_recv = torch.empty_like(self.buf_send)
         send, recv = self.buf_send[: ROW * total], self.buf_recv[: ROW * total]
+        # The big interior G2P2G is enqueued FIRST (compute stream): the collect kernels and the collective below go to
+        # the comm stream behind an event that mgsp_begin / g2p2g_halo recorded after the halo G2P2G, so the device-side
+        # order is unchanged, but the ~100 us of host time that torch spends in the collective no longer delay the launch
+        # of the kernel the GPU is waiting for (0.49 -> 0.43 ms per substep at 5 M particles per rank).
+        if overlap_with is not None:
+            overlap_with()
         off = 0
         for p in range(w):
             c = self.send_counts[p]
@@ -165,8 +171,6 @@ class MgspRank:
             off += ROW * c
         with self._on(self._comm_stream):
             self.comm.all_to_all(recv, send, splits)  # symmetric exchange: recv counts == send counts
-        if overlap_with is not None:
-            overlap_with()
         off = 0
         for p in range(w):
             c = self.send_counts[p]
