@@ -426,9 +426,9 @@ int mpm_initial_setup(mpm_ctx* ctx) {
 	}
 	// neighbours, exterior (gmpm_simulator.cuh:706-734)
 	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_PBC], P.count, sizeof(int), hipMemcpyDeviceToDevice, s));
-	register_blocks_kernel<0, 1><<<std::max(1u, std::min(2048u, cdiv(pbc, 256))), 256, 0, s>>>(g, &ctx->d_status[ST_PBC], P.table, P.keys, P.count, ctx->d_status);
+	register_blocks_kernel<0, 1><<<std::max(1u, std::min(4096u, cdiv((size_t) pbc * 8, 256))), 256, 0, s>>>(g, &ctx->d_status[ST_PBC], P.table, P.keys, P.count, ctx->d_status);
 	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_NBC], P.count, sizeof(int), hipMemcpyDeviceToDevice, s));
-	register_blocks_kernel<-1, 1><<<std::max(1u, std::min(2048u, cdiv(pbc, 256))), 256, 0, s>>>(g, &ctx->d_status[ST_PBC], P.table, P.keys, P.count, ctx->d_status);
+	register_blocks_kernel<-1, 1><<<std::max(1u, std::min(8192u, cdiv((size_t) pbc * 32, 256))), 256, 0, s>>>(g, &ctx->d_status[ST_PBC], P.table, P.keys, P.count, ctx->d_status);
 	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_EBC], P.count, sizeof(int), hipMemcpyDeviceToDevice, s));
 	int rc = read_status(ctx);
 	if(rc) return rc;
@@ -613,11 +613,11 @@ static int launch_rebuild(mpm_ctx* ctx) {
 	}
 	if(ctx->ebc) compact_blocks_kernel<<<cdiv(ctx->ebc, 256), 256, 0, s>>>(g, ctx->ebc, rm, Pr.keys, Pn.keys, Pn.table, Pn.count, ctx->d_status);
 	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_PBC], Pn.count, sizeof(int), hipMemcpyDeviceToDevice, s));
-	const unsigned rg = std::max(1u, std::min(2048u, cdiv(ctx->ebc, 256)));
-	register_blocks_kernel<0, 1><<<rg, 256, 0, s>>>(g, &ctx->d_status[ST_PBC], Pn.table, Pn.keys, Pn.count, ctx->d_status);
+	const unsigned rg8 = std::max(1u, std::min(4096u, cdiv((size_t) ctx->ebc * 8, 256))), rg32 = std::max(1u, std::min(8192u, cdiv((size_t) ctx->ebc * 32, 256)));
+	register_blocks_kernel<0, 1><<<rg8, 256, 0, s>>>(g, &ctx->d_status[ST_PBC], Pn.table, Pn.keys, Pn.count, ctx->d_status);
 	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_NBC], Pn.count, sizeof(int), hipMemcpyDeviceToDevice, s));
 	carry_grid_kernel<<<2048, 256, 0, s>>>(g, &ctx->d_status[ST_NBC], Pn.keys, Pr.table, ctx->nbc, ctx->grid[1], ctx->grid[0]);
-	register_blocks_kernel<-1, 1><<<rg, 256, 0, s>>>(g, &ctx->d_status[ST_PBC], Pn.table, Pn.keys, Pn.count, ctx->d_status);
+	register_blocks_kernel<-1, 1><<<rg32, 256, 0, s>>>(g, &ctx->d_status[ST_PBC], Pn.table, Pn.keys, Pn.count, ctx->d_status);
 	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_EBC], Pn.count, sizeof(int), hipMemcpyDeviceToDevice, s));
 	// the next G2P2G runs in the new numbering n with the particle data laid out in r: sort its lists (the ones the last
 	// G2P2G appended to), look up its blocks' neighbours.  The old exterior count bounds the new particle block count.

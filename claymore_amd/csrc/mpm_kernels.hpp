@@ -1069,14 +1069,42 @@ __global__ __launch_bounds__(256) void compact_blocks_kernel(GridCfg cfg, int eb
 }
 
 // register_neighbor_blocks / register_exterior_blocks (mgmpm_kernels.cuh:117-151); pbc is read from device memory.
+// One LANE per (particle block, offset): the (HI-LO+1)^3 look-ups of a block are independent loads instead of a chain of
+// dependent ones in one thread (27 x ~1 us), and the few lanes that really insert share one counter atomic per wave.
 template<int LO, int HI>
 __global__ __launch_bounds__(256) void register_blocks_kernel(GridCfg cfg, const int* __restrict__ pbc_ptr, int* table, int* keys, int* count, int* status) {
-	const int pbc = *pbc_ptr;
-	for(int b = blockIdx.x * blockDim.x + threadIdx.x; b < pbc; b += gridDim.x * blockDim.x) {
-		const int kx = keys[3 * b], ky = keys[3 * b + 1], kz = keys[3 * b + 2];
-		for(int i = LO; i <= HI; ++i)
-			for(int j = LO; j <= HI; ++j)
-				for(int k = LO; k <= HI; ++k) table_insert(cfg, table, keys, count, kx + i, ky + j, kz + k, status);
+	constexpr int W	   = HI - LO + 1;
+	constexpr int NOFF = W * W * W;
+	constexpr int LPB  = NOFF <= 8 ? 8 : 32;// lanes per block (27 padded to 32)
+	const int pbc	   = *pbc_ptr;
+	const long long total = (long long) pbc * LPB;
+	for(long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x; t < ((total + 63) & ~63ll); t += (long long) gridDim.x * blockDim.x) {
+		const int b = (int) (t / LPB), o = (int) (t % LPB);
+		bool claim	= false;
+		int x = 0, y = 0, z = 0;
+		size_t i = 0;
+		if(t < total && o < NOFF) {
+			x = keys[3 * b] + LO + o / (W * W);
+			y = keys[3 * b + 1] + LO + (o / W) % W;
+			z = keys[3 * b + 2] + LO + o % W;
+			if(key_ok(cfg, x, y, z)) {
+				i = key_index(cfg, x, y, z);
+				// Partition::insert, hash_table.cuh:118-127: claim with CAS (cheap pre-check first: most keys exist already)
+				if(table[i] == -1) claim = atomicCAS(&table[i], -1, -2) == -1;
+			}
+		}
+		const int idx = wave_append(count, claim);// whole waves reach this point together (the loop bound is wave-aligned)
+		if(claim) {
+			if(idx < cfg.cap) {
+				table[i]		  = idx;
+				keys[3 * idx]	  = x;
+				keys[3 * idx + 1] = y;
+				keys[3 * idx + 2] = z;
+			} else {
+				table[i] = -1;
+				atomicOr(&status[ST_OVERFLOW], 1);
+			}
+		}
 	}
 }
 
