@@ -84,10 +84,18 @@ MPM_DEV float rcp_fast(float x) {
 // (--use_fast_math turns logf / expf into lg2.approx / ex2.approx, CMake-Utils/setup_cuda.cmake:50).  Arguments on this
 // path are singular values in [1e-4, ~10] and log-strains of order 1: no denormals, no overflow.
 MPM_DEV float log_fast(float x) {
+#ifdef MPM_EXACT_LOGEXP
+	return logf(x);
+#else
 	return __builtin_amdgcn_logf(x) * 0.693147180559945f;
+#endif
 }
 MPM_DEV float exp_fast(float x) {
+#ifdef MPM_EXACT_LOGEXP
+	return expf(x);
+#else
 	return __builtin_amdgcn_exp2f(x * 1.442695040888963f);
+#endif
 }
 MPM_DEV float rsqrt_approx(float x) {
 	return __builtin_amdgcn_rsqf(x);// v_rsq_f32, ~1 ulp; the algorithm re-normalises (svd.cuh:210-215)

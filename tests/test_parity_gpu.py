@@ -348,3 +348,16 @@ def test_single_particle_and_tiny_models_parity():
     res = run_pair(sc, 200, 1e-4)
     err = match_and_compare(res)
     assert err["n"] == 4 and err["pos_rel"] < POS_TOL, err
+
+
+def test_long_run_sand_stays_close_to_the_oracle():
+    """500 substeps of a 9.7 k-particle sand column.  Plastic flow amplifies rounding differences (yield branches flip for
+    particles on the cone surface), so the 1e-5 bound of the short runs is relaxed here: the error grows smoothly
+    (6e-7 after 100 substeps, 9e-6 after 300, 2e-5 after 500) - the same with libm logf/expf instead of v_log/v_exp, i.e.
+    it is the summation order / SVD rounding sequence, not an approximation, that separates the two trajectories."""
+    sc = scenes.scaled_sand_column(7, 1.0 / 64)
+    res = run_pair(sc, 500, sc["dt"])
+    err = match_and_compare(res)
+    assert err["n"] == scenes.total_particles(sc)
+    assert err["pos_rel"] < 5e-5, err
+    assert err["grid_mass_rel"] < 1e-6, err
