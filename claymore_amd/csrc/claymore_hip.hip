@@ -264,7 +264,7 @@ void mpm_destroy(mpm_ctx* ctx) {
 		if(hipMemcpyFromSymbol(rows.data(), HIP_SYMBOL(mpm::g_prof), rows.size() * sizeof(unsigned long long)) == hipSuccess) {
 			for(int r = 0; r < 1024; ++r)
 				for(int i = 0; i < 20; ++i) h[i] += rows[r * 20 + i];
-			static const char* nm[20] = {"sort(later chunks)", "wait_prefetch", "claim", "gather+chain", "stress+chain", "tail", "tables+zero", "epilogue", "iterations", "fused", "not_fused", "mispredicted", "round trip 1", "rt2 issue+zero", "sort pass 1", "sort masks", "sort placement", "stage grid (rt3)", "", ""};
+			static const char* nm[20] = {"sort(later chunks)", "wait_prefetch", "claim", "gather+chain", "stress+chain", "tail", "tables+zero", "epilogue", "iterations", "all lanes win", "some lanes lose", "mispredicted", "round trip 1", "rt2 issue+zero", "sort pass 1", "sort masks", "sort placement", "stage grid (rt3)", "", ""};
 			unsigned long long tot = 0;
 			for(int i = 0; i < 20; ++i) tot += (i >= 8 && i < 12) ? 0 : h[i];
 			for(int i = 0; i < 18; ++i) fprintf(stderr, "[g2p2g prof] %-18s %14llu  %5.1f %%  %8.0f cycles/iteration\n", nm[i], h[i], (i < 8 || i >= 12) ? 100.0 * h[i] / (double) tot : 0.0, h[8] ? (double) h[i] / (double) h[8] : 0.0);

@@ -671,7 +671,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 	const int row		 = mv.row_of[b];
 	const int binoff_dst = mv.binoff_dst[b];
 	if(size == 0) return;// (:692-697)
-	unsigned long long t_acc[20] = {};// [9] fused iterations, [10] conflict-retry passes, [11] mispredicted keys
+	unsigned long long t_acc[20] = {};// [9] iterations whose lanes all won the claim, [10] iterations with losers, [11] mispredicted keys
 	unsigned long long t_last	= 0;
 	if constexpr(ABL & 32) t_last = __builtin_readcyclecounter();
 	__asm__ volatile("" ::"s"(row), "s"(binoff_dst), "s"(kz));
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, Mo
 			MPM_MARK("loop_end");
 			touch(pf);// the next iteration's particle data must have arrived by now
 			MPM_TICK(5)
-			// ---- hand the payload to the next iteration's fused gather/scatter (:887-905)
+			// ---- hand the payload to the next iteration, whose arithmetic its scatter chain is threaded through (:887-905)
 			if constexpr(ABL & 1) {
 #pragma unroll
 				for(int d = 0; d < 9; ++d) __asm__ volatile("" ::"v"(pl.contrib[d]));
