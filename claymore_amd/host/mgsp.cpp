@@ -191,8 +191,8 @@ int main(int argc, char** argv) {
 			HIPCHK(hipMalloc((void**) &devs[d].recv_b[p], sizeof(float) * 256 * cap_all));
 			if(!same) {
 				int can = 0;
-				hipDeviceCanAccessPeer(&can, devs[d].gpu, devs[p].gpu);
-				if(can) hipDeviceEnablePeerAccess(devs[p].gpu, 0);// Cuda.cu:120-127
+				if(hipDeviceCanAccessPeer(&can, devs[d].gpu, devs[p].gpu) != hipSuccess) can = 0;
+				if(can) (void) hipDeviceEnablePeerAccess(devs[p].gpu, 0);// Cuda.cu:120-127 (already-enabled is not an error worth reporting)
 			}
 		}
 
