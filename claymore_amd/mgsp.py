@@ -32,12 +32,19 @@ from .engine import EngineError, build_engine
 ROW = 3 + 256  # one halo record: key (3 x int32) + grid block (4 x 64 x f32)
 
 
-def partition_scene(scene, rank, world, axis=0):
-    """Static particle partition: every model is cut into `world` equal-count slabs of the initial lattice."""
+def partition_scene(scene, rank, world, axis=None):
+    """Static particle partition: every model is cut into `world` equal-count slabs of the initial lattice.  The cut runs
+    along the model's LONGEST axis (axis=None): slabs as thick as possible keep the interfaces - the halo blocks that have to
+    be computed first, sent and reduced every substep - small against the interior that hides the exchange (the C3 column of
+    128 x 306 x 128 cells cut 8 ways along x would be 4 blocks thick, i.e. almost all halo; along y it is 9.5 blocks thick)."""
     sc = dict(scene)
     sc["models"] = []
     for m in scene["models"]:
-        part = scenes.split_slabs(m["xyz"], world, axis)[rank]
+        ax = axis
+        if ax is None:
+            xyz = m["xyz"]
+            ax = int(np.argmax(xyz.max(axis=0) - xyz.min(axis=0))) if xyz.shape[0] else 0
+        part = scenes.split_slabs(m["xyz"], world, ax)[rank]
         mm = dict(m)
         mm["xyz"] = part
         sc["models"].append(mm)
