@@ -80,7 +80,7 @@ struct mpm_ctx {
 	int* d_inner_list  = nullptr;
 	int* d_halo_counts = nullptr;// [0]=halo blocks, [1]=interior blocks, [2+peer]=send count for peer
 	int* h_halo_counts = nullptr;// pinned mirror
-	int* d_peer_rows   = nullptr;// key-list lengths exported by every rank (fused substep)
+	int* d_peer_rows   = nullptr;// key-list lengths exported by every rank (fused substep); lives behind d_halo_counts
 	int* h_peer_rows   = nullptr;// pinned, behind h_halo_counts
 	int mgsp_world	   = 0;
 	bool halo_tagged   = false;
@@ -297,7 +297,6 @@ void mpm_destroy(mpm_ctx* ctx) {
 	hipFree(ctx->d_halo_list);
 	hipFree(ctx->d_inner_list);
 	hipFree(ctx->d_halo_counts);
-	hipFree(ctx->d_peer_rows);
 	for(auto& p: ctx->d_send_ids) hipFree(p);
 	if(ctx->h_status) hipHostFree(ctx->h_status);
 	if(ctx->h_maxvel) hipHostFree(ctx->h_maxvel);
