@@ -98,8 +98,8 @@ def cpu_baseline(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)   # warm-up 10 substeps, time the next 100
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scene", default="sand40m", choices=["sand40m", "sphere5m", "spheres50k"])
     ap.add_argument("--fraction", type=float, default=1.0, help="debug: shrink the sand column")
     ap.add_argument("--no-cpu-baseline", action="store_true")
