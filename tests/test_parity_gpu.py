@@ -61,6 +61,12 @@ def test_device_svd_vs_reference_golden():
     scale = np.abs(Fm).reshape(n, -1).max(axis=1)
     assert (eg <= 2.0 * ew + 2e-6 * scale).all()
     assert np.abs(np.einsum("nji,njk->nik", Vg, Vg) - np.eye(3)).max() < 5e-6
+    # Where the Jacobi residual ends up: the reference makes U orthogonal by QR and leaves the residual in U S V^T - F (ew),
+    # the device normalises the columns of F V, reconstructs F exactly and leaves it in U^T U - I.  Same size, class by class.
+    ug = np.abs(np.einsum("nji,njk->nik", Ug, Ug) - np.eye(3)).reshape(n, -1).max(axis=1)
+    for c in (0, 1, 2, 3, 4, 5, 7):          # (6 = near-singular inputs: the device switches to the reference's QR there)
+        m = cls == c
+        assert ug[m].max() <= 2.5 * (ew[m] / scale[m]).max() + 5e-6, (c, ug[m].max(), (ew[m] / scale[m]).max())
     assert np.abs(np.linalg.det(Vg) - 1.0).max() < 1e-5
     assert (Sg[:, 0] >= Sg[:, 1] - 1e-6).all() and (Sg[:, 1] >= np.abs(Sg[:, 2]) - 1e-6).all()
     det = np.linalg.det(Fm)
