@@ -67,7 +67,6 @@ struct mpm_ctx {
 	double* d_totals	  = nullptr;
 	unsigned long long* d_counter = nullptr;
 	bool ready = false;
-	int ablate = 0;// MPM_G2P2G_ABLATE (profiling only)
 	int capacity_events = 0;// number of capacity growths so far (check_capacity)
 	bool has_collision = false;// level-set collision object of the MGSP grid update
 	CollisionObject collision {};
@@ -223,7 +222,6 @@ int mpm_create(const mpm_config* cfg, int device, mpm_ctx** out) {
 	mpm_ctx* ctx = new mpm_ctx();
 	ctx->cfg	 = *cfg;
 	ctx->device	 = device;
-	if(const char* e = getenv("MPM_G2P2G_ABLATE")) ctx->ablate = atoi(e);
 	GridCfg& g	 = ctx->g;
 	g.gbits		 = cfg->domain_bits - 2;
 	g.G			 = 1 << g.gbits;
@@ -258,18 +256,6 @@ void mpm_destroy(mpm_ctx* ctx) {
 	if(!ctx) return;
 	hipSetDevice(ctx->device);
 	hipDeviceSynchronize();
-	if(ctx->ablate & 32) {// phase timing of the profiling build (see g_prof in mpm_kernels.hpp)
-		std::vector<unsigned long long> rows(1024 * 20);
-		unsigned long long h[20] = {};
-		if(hipMemcpyFromSymbol(rows.data(), HIP_SYMBOL(mpm::g_prof), rows.size() * sizeof(unsigned long long)) == hipSuccess) {
-			for(int r = 0; r < 1024; ++r)
-				for(int i = 0; i < 20; ++i) h[i] += rows[r * 20 + i];
-			static const char* nm[20] = {"sort(later chunks)", "wait_prefetch", "claim", "gather+chain", "stress+chain", "tail", "tables+zero", "epilogue", "iterations", "all lanes win", "some lanes lose", "mispredicted", "round trip 1", "rt2 issue+zero", "sort pass 1", "sort masks", "sort placement", "stage grid (rt3)", "", ""};
-			unsigned long long tot = 0;
-			for(int i = 0; i < 20; ++i) tot += (i >= 8 && i < 12) ? 0 : h[i];
-			for(int i = 0; i < 18; ++i) fprintf(stderr, "[g2p2g prof] %-18s %14llu  %5.1f %%  %8.0f cycles/iteration\n", nm[i], h[i], (i < 8 || i >= 12) ? 100.0 * h[i] / (double) tot : 0.0, h[8] ? (double) h[i] / (double) h[8] : 0.0);
-		}
-	}
 	hipFree(ctx->d_sdf);
 	for(int i = 0; i < 2; ++i) {
 		hipFree(ctx->part[i].table);
@@ -518,21 +504,7 @@ static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, in
 	switch(m.material) {
 		case MPM_J_FLUID: g2p2g_kernel<0><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
 		case MPM_FIXED_COROTATED: g2p2g_kernel<1><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
-		case MPM_SAND:
-			switch(ctx->ablate) {// profiling builds only (MPM_G2P2G_ABLATE), see mpm_kernels.hpp
-#define MPM_ABL(n) \
-	case n: g2p2g_kernel<2, n><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
-				MPM_ABL(1)
-				MPM_ABL(2)
-				MPM_ABL(4)
-				MPM_ABL(3)
-				MPM_ABL(7)
-				MPM_ABL(15)
-				MPM_ABL(32)
-#undef MPM_ABL
-				default: g2p2g_kernel<2><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
-			}
-			break;
+		case MPM_SAND: g2p2g_kernel<2><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
 		default: g2p2g_kernel<3><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
 	}
 }

@@ -362,6 +362,174 @@ MPM_DEV void svd3(const float (&F)[9], float (&U)[9], float (&S)[3], float (&V)[
 	svd3<0>(F, U, S, V, nh);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Symmetric eigen-decomposition b = F F^T = U diag(lam) U^T by cyclic Jacobi with EXACT rotations.
+//
+// Every constitutive model on this path only needs U and the singular values sigma_k = sqrt(lam_k) of F = U S V^T:
+//   * P F^T = U diag(P_hat_k sigma_k) U^T                                  (V cancels: V^T V = I)
+//   * a projected F_new = U S_new V^T = U diag(S_new_k / sigma_k) U^T F    (V^T = S^-1 U^T F)
+// so the reference's route (math::svd: Jacobi on F^T F for V, B = F V, Givens QR for U and S, svd.cuh:27-1123) is
+// replaced by the left-handed one, which skips B, the QR / column normalisation and the sort.  A rotation annihilates
+// s_pq exactly (t = tan(theta) from the stable quadratic root, one v_sqrt / v_rcp / v_rsq) instead of the reference's
+// approximate Givens angle (svd.cuh:167-252), which costs half the arithmetic per rotation: the updated diagonal is
+// s_pp - t s_pq, s_qq + t s_pq and s_pq := 0.  Sweeps stop for the whole wave once every off-diagonal entry of every
+// lane is below 1e-6 of the smallest diagonal entry (at most 4 sweeps, the reference's fixed count).
+// Hook: see svd3.
+// ---------------------------------------------------------------------------------------------------------------
+MPM_DEV void jacobi_rot(float& spp, float& spq, float& sqq, float& srp, float& srq, float (&up)[3], float (&uq)[3]) {
+	const float delta = sqq - spp;
+	const float o2	  = spq + spq;
+	const float h	  = fmaf(o2, o2, fmaf(delta, delta, 1e-36f));// > 0: no 0/0 for an already diagonal pair
+	const float r	  = __builtin_amdgcn_sqrtf(h);
+	const float den	  = delta + __builtin_copysignf(r, delta);// |den| >= |delta|: the smaller root, |theta| <= pi/4
+	const float t	  = o2 * rcp_fast(den);
+	const float c	  = rsqrt_approx(fmaf(t, t, 1.0f));
+	const float s	  = t * c;
+	spp				  = fmaf(-t, spq, spp);
+	sqq				  = fmaf(t, spq, sqq);
+	spq				  = 0.f;
+	const float x = srp, y = srq;
+	srp = c * x - s * y;
+	srq = s * x + c * y;
+	// U <- U P  (P_pp = P_qq = c, P_pq = s, P_qp = -s)
+	const v2f_ p = {up[0], up[1]}, q = {uq[0], uq[1]};
+	const v2f_ pn = p * c - q * s, qn = p * s + q * c;
+	const float pz = up[2], qz = uq[2];
+	up[0] = pn.x;
+	up[1] = pn.y;
+	up[2] = c * pz - s * qz;
+	uq[0] = qn.x;
+	uq[1] = qn.y;
+	uq[2] = s * pz + c * qz;
+}
+
+constexpr int kEigSites = 13;
+template<int BASE, class Hook>
+MPM_DEV void sym_eig3(const float (&F)[9], float (&lam)[3], float (&U)[9], Hook& hk) {
+	// b = F F^T (column-major F: F[3 j + i] = F_ij)
+	const v2f_ f01 = {F[0], F[1]}, f34 = {F[3], F[4]}, f67 = {F[6], F[7]};
+	const v2f_ f12 = {F[1], F[2]}, f45 = {F[4], F[5]}, f78 = {F[7], F[8]};
+	const v2f_ r0 = f01 * F[0] + f34 * F[3] + f67 * F[6];// (b11, b21)
+	const v2f_ r1 = f12 * F[1] + f45 * F[4] + f78 * F[7];// (b22, b32)
+	float s11 = r0.x, s21 = r0.y, s22 = r1.x, s32 = r1.y;
+	float s31 = F[2] * F[0] + F[5] * F[3] + F[8] * F[6];
+	float s33 = F[2] * F[2] + F[5] * F[5] + F[8] * F[8];
+	float u1[3] = {1.f, 0.f, 0.f}, u2[3] = {0.f, 1.f, 0.f}, u3[3] = {0.f, 0.f, 1.f};
+	MPM_MARK("eig_jacobi");
+	hk.template at<BASE + 0>();
+	bool done = false;
+#define MPM_SWEEP(IT)                                                          \
+	if(!done) jacobi_rot(s11, s21, s22, s31, s32, u1, u2);                     \
+	hk.template at<BASE + 1 + 3 * IT>();                                       \
+	if(!done) jacobi_rot(s22, s32, s33, s21, s31, u2, u3);                     \
+	hk.template at<BASE + 2 + 3 * IT>();                                       \
+	if(!done) {                                                                \
+		jacobi_rot(s33, s31, s11, s32, s21, u3, u1);                           \
+		const float off = fmaxf(fabsf(s21), fabsf(s32));                       \
+		const float dia = fminf(fminf(fabsf(s11), fabsf(s22)), fabsf(s33));    \
+		done			= __all(off <= 1e-6f * dia);                           \
+	}                                                                          \
+	hk.template at<BASE + 3 + 3 * IT>();
+	MPM_SWEEP(0)
+	MPM_SWEEP(1)
+	MPM_SWEEP(2)
+	MPM_SWEEP(3)
+#undef MPM_SWEEP
+	MPM_MARK("eig_end");
+	lam[0] = s11;
+	lam[1] = s22;
+	lam[2] = s33;
+#pragma unroll
+	for(int r = 0; r < 3; ++r) {
+		U[r]	 = u1[r];
+		U[3 + r] = u2[r];
+		U[6 + r] = u3[r];
+	}
+}
+
+MPM_DEV float det3(const float (&F)[9]) {
+	return F[0] * (F[4] * F[8] - F[7] * F[5]) + F[3] * (F[7] * F[2] - F[1] * F[8]) + F[6] * (F[1] * F[5] - F[4] * F[2]);
+}
+
+// The eigenvalues of F F^T carry an absolute error of ~1e-7 lam_max, i.e. no relative accuracy for a strongly compressed
+// direction.  Rare lanes with sigma_min < 1e-2 sigma_max recompute lam_k = |F^T u_k|^2 (accurate relative to lam_k itself)
+// and rebuild a projected F through V (rebuild_through_v) instead of dividing by sigma_k.
+MPM_DEV bool ill_conditioned(const float (&lam)[3]) {
+	return fminf(fminf(lam[0], lam[1]), lam[2]) < 1e-4f * fmaxf(fmaxf(lam[0], lam[1]), lam[2]);
+}
+MPM_DEV void refine_eigs(const float (&F)[9], const float (&U)[9], float (&lam)[3]) {
+#pragma unroll
+	for(int k = 0; k < 3; ++k) {
+		float n = 0.f;
+#pragma unroll
+		for(int j = 0; j < 3; ++j) {
+			const float g = F[3 * j] * U[3 * k] + F[3 * j + 1] * U[3 * k + 1] + F[3 * j + 2] * U[3 * k + 2];
+			n			  = fmaf(g, g, n);
+		}
+		lam[k] = n;
+	}
+}
+
+// out = U diag(d) U^T (symmetric): packed rows 0 / 1, 18 instructions
+MPM_DEV void sym_from_eig(const float (&U)[9], const float (&d)[3], float (&out)[9]) {
+	const v2f_ u0 = {U[0], U[1]}, u1 = {U[3], U[4]}, u2 = {U[6], U[7]};
+	const v2f_ ud0 = u0 * d[0], ud1 = u1 * d[1], ud2 = u2 * d[2];
+	const float udz0 = U[2] * d[0], udz1 = U[5] * d[1], udz2 = U[8] * d[2];
+	const v2f_ c0 = ud0 * U[0] + ud1 * U[3] + ud2 * U[6];// (00, 10)
+	const v2f_ c1 = ud0 * U[1] + ud1 * U[4] + ud2 * U[7];// (01, 11)
+	const v2f_ c2 = ud0 * U[2] + ud1 * U[5] + ud2 * U[8];// (02, 12)
+	out[0] = c0.x;
+	out[1] = c0.y;
+	out[3] = c0.y;
+	out[4] = c1.y;
+	out[6] = c2.x;
+	out[7] = c2.y;
+	out[2] = c2.x;
+	out[5] = c2.y;
+	out[8] = udz0 * U[2] + udz1 * U[5] + udz2 * U[8];
+}
+
+// F <- U diag(S_new) V^T through V (reference form, matmul_mat_diag_mat_t_3d): the rare lanes where the multiplicative
+// form U diag(S_new / sigma) U^T F cannot be used - det F <= 0 (the reference's SVD moves the reflection into the
+// smallest singular value and the projected F comes out with det > 0) or a singular value below the models' clamp.
+// V: v_k = F^T u_k / sigma_k for the two larger singular values, the third column by the cross product (V a rotation).
+MPM_DEV void rebuild_through_v(float (&F)[9], const float (&U)[9], const float (&lam)[3], const float (&Snew)[3]) {
+	float g[3][3], n[3];
+#pragma unroll
+	for(int k = 0; k < 3; ++k) {
+#pragma unroll
+		for(int j = 0; j < 3; ++j) g[k][j] = F[3 * j] * U[3 * k] + F[3 * j + 1] * U[3 * k + 1] + F[3 * j + 2] * U[3 * k + 2];
+		n[k] = rsqrt_approx(fmaxf(g[k][0] * g[k][0] + g[k][1] * g[k][1] + g[k][2] * g[k][2], 1e-30f));
+#pragma unroll
+		for(int j = 0; j < 3; ++j) g[k][j] *= n[k];
+	}
+	const int kmin = (lam[0] <= lam[1] && lam[0] <= lam[2]) ? 0 : (lam[1] <= lam[2] ? 1 : 2);
+#pragma unroll
+	for(int k = 0; k < 3; ++k) {
+		if(k == kmin) {
+			const int a = (k + 1) % 3, b = (k + 2) % 3;
+			g[k][0] = g[a][1] * g[b][2] - g[a][2] * g[b][1];
+			g[k][1] = g[a][2] * g[b][0] - g[a][0] * g[b][2];
+			g[k][2] = g[a][0] * g[b][1] - g[a][1] * g[b][0];
+		}
+	}
+#pragma unroll
+	for(int j = 0; j < 3; ++j) {
+#pragma unroll
+		for(int i = 0; i < 3; ++i) F[3 * j + i] = Snew[0] * U[i] * g[0][j] + Snew[1] * U[3 + i] * g[1][j] + Snew[2] * U[6 + i] * g[2][j];
+	}
+}
+
+// F <- U diag(ratio) U^T F
+MPM_DEV void rescale_principal(float (&F)[9], const float (&U)[9], const float (&ratio)[3]) {
+	float M[9];
+	sym_from_eig(U, ratio, M);
+	float Fn[9];
+	matmul3(M, F, Fn);
+#pragma unroll
+	for(int d = 0; d < 9; ++d) F[d] = Fn[d];
+}
+
 // Material constants passed by value to the kernels (Projects/GMPM/particle_buffer.cuh:141-264)
 struct MaterialConst {
 	float mass, volume, mu, lambda;
@@ -372,42 +540,53 @@ struct MaterialConst {
 	int volume_correction, hardening_on;
 };
 
-// compute_stress<FIXED_COROTATED>, Projects/GMPM/constitutive_models.cuh:36-73
-constexpr int kFcSites = kSvdSites + 2;
+// compute_stress<FIXED_COROTATED>, Projects/GMPM/constitutive_models.cuh:36-73.
+// P F^T = U diag(P_hat_k sigma_k) U^T with P_hat_k sigma_k = 2 mu (sigma_k - 1) sigma_k + lambda (J - 1) J.
+constexpr int kFcSites = kEigSites + 1;
 template<int BASE, class Hook>
 MPM_DEV void stress_fixed_corotated(const MaterialConst& mc, const float (&F)[9], float (&PF)[9], Hook& hk) {
-	float U[9], S[3], V[9];
-	svd3<BASE, Hook, false>(F, U, S, V, hk);
-	const float J			  = S[0] * S[1] * S[2];
-	const float scaled_mu	  = 2.0f * mc.mu;
-	const float scaled_lambda = mc.lambda * (J - 1.0f);
-	float Ph[3];
-	Ph[0] = scaled_mu * (S[0] - 1.f) + scaled_lambda * (S[1] * S[2]);
-	Ph[1] = scaled_mu * (S[1] - 1.f) + scaled_lambda * (S[0] * S[2]);
-	Ph[2] = scaled_mu * (S[2] - 1.f) + scaled_lambda * (S[0] * S[1]);
-	float P[9];
-	mat_diag_matT(P, U, Ph, V);
-	hk.template at<BASE + kSvdSites>();
-	P_Ft_vol(P, F, mc.volume, PF);
-	hk.template at<BASE + kSvdSites + 1>();
+	float lam[3], U[9];
+	sym_eig3<BASE>(F, lam, U, hk);
+	if(ill_conditioned(lam)) refine_eigs(F, U, lam);
+	float sig[3];
+#pragma unroll
+	for(int k = 0; k < 3; ++k) sig[k] = __builtin_amdgcn_sqrtf(lam[k]);
+	if(det3(F) < 0.f) {// reflected F: the smallest singular value carries the sign (svd.cuh:590-770)
+		const bool m0 = lam[0] <= lam[1] && lam[0] <= lam[2], m1 = !m0 && lam[1] <= lam[2];
+		sig[0] = m0 ? -sig[0] : sig[0];
+		sig[1] = m1 ? -sig[1] : sig[1];
+		sig[2] = (!m0 && !m1) ? -sig[2] : sig[2];
+	}
+	const float J  = sig[0] * sig[1] * sig[2];
+	const float vl = mc.volume * mc.lambda * (J - 1.0f) * J;
+	const float vm = 2.0f * mc.mu * mc.volume;
+	float d[3];
+#pragma unroll
+	for(int k = 0; k < 3; ++k) d[k] = fmaf(vm, lam[k] - sig[k], vl);
+	sym_from_eig(U, d, PF);
+	hk.template at<BASE + kEigSites>();
 }
 MPM_DEV void stress_fixed_corotated(const MaterialConst& mc, const float (&F)[9], float (&PF)[9]) {
 	NoHook nh;
 	stress_fixed_corotated<0>(mc, F, PF, nh);
 }
 
-// compute_stress<SAND>, constitutive_models.cuh:238-335 (Drucker-Prager return mapping, StVK-Hencky)
-constexpr int kSandSites = kSvdSites + 4;
+// compute_stress<SAND>, constitutive_models.cuh:238-335 (Drucker-Prager return mapping, StVK-Hencky) in principal
+// log-strains ln sigma_k = 0.5 ln lam_k.  The return mapping moves ln sigma_k by dl_k, so the projected
+// F = U diag(exp(dl_k)) U^T F_trial, and P F^T vol = U diag((2 mu ln S_new_k + lambda tr ln S_new) vol) U^T.
+constexpr int kSandSites = kEigSites + 3;
 template<int BASE, class Hook>
 MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9], Hook& hk, float* __restrict__ Fdst = nullptr, int Fstride = 0) {
-	float U[9], S[3], V[9];
-	svd3<BASE, Hook, false>(F, U, S, V, hk);
+	float lam[3], U[9];
+	sym_eig3<BASE>(F, lam, U, hk);
+	const bool ill = ill_conditioned(lam);
+	if(ill) refine_eigs(F, U, lam);
 	const float scaled_mu = 2.0f * mc.mu;
-	float epsilon[3], New_S[3] = {0.f, 0.f, 0.f};
+	float lns[3], epsilon[3];
 #pragma unroll
 	for(int i = 0; i < 3; i++) {
-		const float abs_S = fmaxf(fabsf(S[i]), 1e-4f);
-		epsilon[i]		  = log_fast(abs_S) - mc.cohesion;
+		lns[i]	   = 0.5f * log_fast(fmaxf(lam[i], 1e-8f));// ln max(|S|, 1e-4) (:262)
+		epsilon[i] = lns[i] - mc.cohesion;
 	}
 	const float sum_epsilon	  = epsilon[0] + epsilon[1] + epsilon[2];
 	const float trace_epsilon = sum_epsilon + log_jp;
@@ -415,154 +594,149 @@ MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, 
 #pragma unroll
 	for(int i = 0; i < 3; i++) epsilon_hat[i] = epsilon[i] - (trace_epsilon * (1.0f / 3.0f));
 	const float epsilon_hat_norm = __builtin_amdgcn_sqrtf(epsilon_hat[0] * epsilon_hat[0] + epsilon_hat[1] * epsilon_hat[1] + epsilon_hat[2] * epsilon_hat[2]);
-	hk.template at<BASE + kSvdSites>();
-	// log(New_S) is needed below; New_S = exp(H), so H itself is used instead of logf(expf(H)) (the reference's
-	// round trip, constitutive_models.cuh:311, differs from H by one rounding of expf: ~6e-8 absolute)
-	float lnS[3];
-	bool rebuild = false;
-	if(trace_epsilon >= 0.0f) {// case II: cone tip
-		New_S[0] = New_S[1] = New_S[2] = exp_fast(mc.cohesion);
-		lnS[0] = lnS[1] = lnS[2] = mc.cohesion;
-		rebuild					 = true;
+	hk.template at<BASE + kEigSites>();
+	float dl[3] = {0.f, 0.f, 0.f};// ln S_new - ln sigma
+	bool rebuild = false, dead = false;
+	if(trace_epsilon >= 0.0f) {// case II: cone tip (:282-290)
+#pragma unroll
+		for(int i = 0; i < 3; i++) dl[i] = -epsilon[i];
+		rebuild = true;
 		if(mc.volume_correction) log_jp = mc.beta * sum_epsilon + log_jp;
 	} else if(mc.mu != 0.f) {
 		log_jp					= 0.f;
 		const float delta_gamma = epsilon_hat_norm + (3.0f * mc.lambda + scaled_mu) * rcp_fast(scaled_mu) * trace_epsilon * mc.yield_surface;
-		if(delta_gamma <= 0.f) {// case I: inside the cone
-#pragma unroll
-			for(int i = 0; i < 3; i++) lnS[i] = epsilon[i] + mc.cohesion;
-		} else {// case III: project to the cone surface
+		if(delta_gamma > 0.f) {// case III: project to the cone surface (case I, inside the cone: dl = 0)
 			const float r = delta_gamma * rcp_fast(epsilon_hat_norm);
 #pragma unroll
-			for(int i = 0; i < 3; i++) lnS[i] = epsilon[i] - r * epsilon_hat[i] + mc.cohesion;
+			for(int i = 0; i < 3; i++) dl[i] = -r * epsilon_hat[i];
 		}
-#pragma unroll
-		for(int i = 0; i < 3; i++) New_S[i] = exp_fast(lnS[i]);
 		rebuild = true;
 	} else {
-		lnS[0] = lnS[1] = lnS[2] = -__builtin_inff();// reference: logf(0) when mu == 0 (:298-300)
+		dead = true;// reference: logf(0) when mu == 0 (:298-300): P is NaN, F is left as it is
 	}
-	hk.template at<BASE + kSvdSites + 1>();
-	if(rebuild) mat_diag_matT(F, U, New_S, V);
+	float lnS[3];
+#pragma unroll
+	for(int i = 0; i < 3; i++) lnS[i] = dead ? -__builtin_inff() : lns[i] + dl[i];
+	if(rebuild) {
+		if(!ill && det3(F) > 0.f) {
+			float ratio[3];
+#pragma unroll
+			for(int i = 0; i < 3; i++) ratio[i] = exp_fast(dl[i]);
+			rescale_principal(F, U, ratio);
+		} else {// reflected or collapsed F (rare)
+			float Sn[3];
+#pragma unroll
+			for(int i = 0; i < 3; i++) Sn[i] = exp_fast(lnS[i]);
+			rebuild_through_v(F, U, lam, Sn);
+		}
+	}
+	hk.template at<BASE + kEigSites + 1>();
 	if(Fdst) {// the kernel has the projected F written out here: nine registers less while P F^T is formed
 #pragma unroll
 		for(int d = 0; d < 9; ++d) Fdst[d * Fstride] = F[d];
 	}
-	hk.template at<BASE + kSvdSites + 2>();
-	const float trace_log_S = lnS[0] + lnS[1] + lnS[2];
-	// P F^T vol (:318-334).  With F = U New_S V^T as rebuilt above, P F^T = U P_hat V^T V New_S U^T = U diag(P_hat_k New_S_k) U^T
-	// with P_hat_k New_S_k = 2 mu ln S_k + lambda tr(ln S): 27 FMAs instead of two 3x3x3 products and three reciprocals
-	// (V^T V = I to ~1e-7, the same order as the reference's own SVD residual).
-	// (mu == 0 leaves F as it is and ln S = -inf: the reference's P is NaN then, and so is this.)  No branch here on
-	// purpose: stores to PF in two arms get merged into one store with a variable offset, which keeps PF in scratch.
 	{
+		const float trace_log_S = lnS[0] + lnS[1] + lnS[2];
 		float d[3];
 #pragma unroll
 		for(int k = 0; k < 3; ++k) d[k] = (scaled_mu * lnS[k] + mc.lambda * trace_log_S) * mc.volume;
-		const v2f_ u0 = {U[0], U[1]}, u1 = {U[3], U[4]}, u2 = {U[6], U[7]};
-		const v2f_ ud0 = u0 * d[0], ud1 = u1 * d[1], ud2 = u2 * d[2];
-		const float udz0 = U[2] * d[0], udz1 = U[5] * d[1], udz2 = U[8] * d[2];
-		const v2f_ c0 = ud0 * U[0] + ud1 * U[3] + ud2 * U[6];// (PF00, PF10)
-		const v2f_ c1 = ud0 * U[1] + ud1 * U[4] + ud2 * U[7];// (PF01, PF11)
-		const v2f_ c2 = ud0 * U[2] + ud1 * U[5] + ud2 * U[8];// (PF02, PF12)
-		PF[0] = c0.x;
-		PF[1] = c0.y;
-		PF[3] = c0.y;
-		PF[4] = c1.y;
-		PF[6] = c2.x;
-		PF[7] = c2.y;
-		PF[2] = c2.x;
-		PF[5] = c2.y;
-		PF[8] = udz0 * U[2] + udz1 * U[5] + udz2 * U[8];
+		sym_from_eig(U, d, PF);
 	}
-	hk.template at<BASE + kSvdSites + 3>();
+	hk.template at<BASE + kEigSites + 2>();
 }
 MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9]) {
 	NoHook nh;
 	stress_sand<0>(mc, F, log_jp, PF, nh);
 }
 
-// compute_stress<NACC>, constitutive_models.cuh:77-234 (USE_JOSH_FRACTURE_PAPER branch)
-constexpr int kNaccSites = kSvdSites + 2;
+// compute_stress<NACC>, constitutive_models.cuh:77-234 (USE_JOSH_FRACTURE_PAPER branch) in principal stretches:
+// B_hat_k = sigma_k^2 = lam_k, the projections return new squared stretches Bn_k; F_new = U diag(sqrt(Bn_k / lam_k)) U^T F,
+// b_new = F_new F_new^T = U diag(Bn) U^T, so dev(b) and P F^T are diagonal in U.  J^(+-2/3), cube roots and logs go
+// through one v_log_f32 / v_exp_f32 each instead of powf (the reference binary's --use_fast_math does the same).
+constexpr int kNaccSites = kEigSites + 2;
 template<int BASE, class Hook>
 MPM_DEV void stress_nacc(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9], Hook& hk) {
-	float U[9], S[3], V[9];
-	svd3<BASE, Hook, false>(F, U, S, V, hk);
-	const float bm	  = mc.bm;
-	const float p0	  = bm * (0.00001f + sinhf(mc.xi * (-log_jp > 0 ? -log_jp : 0)));
+	float lam[3], U[9];
+	sym_eig3<BASE>(F, lam, U, hk);
+	const bool ill = ill_conditioned(lam);
+	if(ill) refine_eigs(F, U, lam);
+	const float bm = mc.bm;
+	const float ex = exp_fast(mc.xi * fmaxf(-log_jp, 0.f));
+	const float p0 = bm * (0.00001f + 0.5f * (ex - rcp_fast(ex)));// sinh
 	const float p_min = -mc.beta * p0;
-	const float Je_trial = S[0] * S[1] * S[2];
-	const float B0 = S[0] * S[0], B1 = S[1] * S[1], B2 = S[2] * S[2];
-	const float trB3   = (B0 + B1 + B2) / 3.f;
-	const float Jm23mu = mc.mu * powf(Je_trial, -2.f / 3.f);
-	const float sh0 = Jm23mu * (B0 - trB3), sh1 = Jm23mu * (B1 - trB3), sh2 = Jm23mu * (B2 - trB3);
-	const float psi_kappa_partial_J = bm * 0.5f * (Je_trial - 1.f / Je_trial);
-	const float p_trial				= -psi_kappa_partial_J * Je_trial;
-	const float y_s_half_coeff		= 3.f / 2.f * (1 + 2.f * mc.beta);
-	const float y_p_half			= (mc.msqr * (p_trial - p_min) * (p_trial - p0));
-	const float s_sqrnorm			= sh0 * sh0 + sh1 * sh1 + sh2 * sh2;
-	const float y					= (y_s_half_coeff * s_sqrnorm) + y_p_half;
-	if(p_trial > p0) {
-		const float Je_new = sqrtf(-2.f * p0 / bm + 1.f);
-		S[0] = S[1] = S[2] = powf(Je_new, 1.f / 3.f);
-		mat_diag_matT(F, U, S, V);
-		if(mc.hardening_on) log_jp += logf(Je_trial / Je_new);
-	} else if(p_trial < p_min) {
-		const float Je_new = sqrtf(-2.f * p_min / bm + 1.f);
-		S[0] = S[1] = S[2] = powf(Je_new, 1.f / 3.f);
-		mat_diag_matT(F, U, S, V);
-		if(mc.hardening_on) log_jp += logf(Je_trial / Je_new);
-	} else if(y >= 1e-4f) {
-		const float B_s_coeff = powf(Je_trial, 2.f / 3.f) / mc.mu * sqrtf(-y_p_half / y_s_half_coeff) / sqrtf(s_sqrnorm);
-		S[0]				  = sqrtf(sh0 * B_s_coeff + trB3);
-		S[1]				  = sqrtf(sh1 * B_s_coeff + trB3);
-		S[2]				  = sqrtf(sh2 * B_s_coeff + trB3);
-		mat_diag_matT(F, U, S, V);
+	const float detF	 = det3(F);
+	const float lg2J	 = 0.5f * __builtin_amdgcn_logf(lam[0] * lam[1] * lam[2]);// log2 |Je_trial|
+	const float Je_abs	 = __builtin_amdgcn_exp2f(lg2J);
+	const float Je_trial = detF < 0.f ? -Je_abs : Je_abs;
+	const float trB3	 = (lam[0] + lam[1] + lam[2]) * (1.f / 3.f);
+	// a reflected F makes the reference's powf(Je_trial, -2/3) NaN (:96); the same happens here through the sign of Je
+	const float Jm23mu = detF < 0.f ? __builtin_nanf("") : mc.mu * __builtin_amdgcn_exp2f(lg2J * (-2.f / 3.f));
+	const float sh0 = Jm23mu * (lam[0] - trB3), sh1 = Jm23mu * (lam[1] - trB3), sh2 = Jm23mu * (lam[2] - trB3);
+	const float p_trial		   = -bm * 0.5f * (Je_trial - rcp_fast(Je_trial)) * Je_trial;
+	const float y_s_half_coeff = 1.5f * (1.f + 2.f * mc.beta);
+	const float y_p_half	   = mc.msqr * (p_trial - p_min) * (p_trial - p0);
+	const float s_sqrnorm	   = sh0 * sh0 + sh1 * sh1 + sh2 * sh2;
+	const float y			   = y_s_half_coeff * s_sqrnorm + y_p_half;
+	float Bn[3] = {lam[0], lam[1], lam[2]};// new squared stretches
+	bool rebuild = false;
+	hk.template at<BASE + kEigSites>();
+	if(p_trial > p0 || p_trial < p_min) {// cases 1, 2: project to a tip of the yield surface (:113-143)
+		const float Je_new2 = -2.f * (p_trial > p0 ? p0 : p_min) * rcp_fast(bm) + 1.f;// Je_new^2
+		const float l2		= __builtin_amdgcn_logf(Je_new2);						// 2 log2 Je_new
+		Bn[0] = Bn[1] = Bn[2] = __builtin_amdgcn_exp2f(l2 * (1.f / 3.f));				// Je_new^(2/3)
+		rebuild				  = true;
+		if(mc.hardening_on) log_jp += (lg2J - 0.5f * l2) * 0.693147180559945f;
+	} else if(y >= 1e-4f) {// case 3: project to the yield surface (:151-203)
+		const float B_s_coeff = __builtin_amdgcn_exp2f(lg2J * (2.f / 3.f)) * rcp_fast(mc.mu) * __builtin_amdgcn_sqrtf(-y_p_half * rcp_fast(y_s_half_coeff)) * rsqrt_approx(s_sqrnorm);
+		Bn[0]				  = sh0 * B_s_coeff + trB3;
+		Bn[1]				  = sh1 * B_s_coeff + trB3;
+		Bn[2]				  = sh2 * B_s_coeff + trB3;
+		rebuild				  = true;
 		if(mc.hardening_on && p0 > 1e-4f && p_trial < p0 - 1e-4f && p_trial > 1e-4f + p_min) {
-			const float p_center = (1.0f - mc.beta) * p0 / 2;
-			const float q_trial	 = sqrtf(3.f / 2.f * s_sqrnorm);
+			const float p_center = (1.0f - mc.beta) * p0 * 0.5f;
+			const float q_trial	 = __builtin_amdgcn_sqrtf(1.5f * s_sqrnorm);
 			float d0 = p_center - p_trial, d1 = -q_trial;
-			const float dn = sqrtf(d0 * d0 + d1 * d1);
-			d0 /= dn;
-			d1 /= dn;
+			const float dn = rsqrt_approx(d0 * d0 + d1 * d1);
+			d0 *= dn;
+			d1 *= dn;
 			const float C  = mc.msqr * (p_center - p_min) * (p_center - p0);
-			const float B  = mc.msqr * d0 * (2 * p_center - p0 - p_min);
-			const float A  = mc.msqr * d0 * d0 + (1 + 2 * mc.beta) * d1 * d1;
-			const float sq = sqrtf(B * B - 4 * A * C);
-			const float l1 = (-B + sq) / (2 * A);
-			const float l2 = (-B - sq) / (2 * A);
-			const float p1 = p_center + l1 * d0;
-			const float p2 = p_center + l2 * d0;
-			const float p_fake		= (p_trial - p_center) * (p1 - p_center) > 0 ? p1 : p2;
-			const float tmp_Je_sqr	= (-2 * p_fake / bm + 1);
-			const float Je_new_fake = sqrtf(tmp_Je_sqr > 0 ? tmp_Je_sqr : -tmp_Je_sqr);
-			if(Je_new_fake > 1e-4f) log_jp += logf(Je_trial / Je_new_fake);
+			const float B  = mc.msqr * d0 * (2.f * p_center - p0 - p_min);
+			const float A  = mc.msqr * d0 * d0 + (1.f + 2.f * mc.beta) * d1 * d1;
+			const float sq = __builtin_amdgcn_sqrtf(B * B - 4.f * A * C);
+			const float ia = rcp_fast(2.f * A);
+			const float p1 = p_center + (-B + sq) * ia * d0;
+			const float p2 = p_center + (-B - sq) * ia * d0;
+			const float p_fake		= (p_trial - p_center) * (p1 - p_center) > 0.f ? p1 : p2;
+			const float Je_new_fake2 = fabsf(-2.f * p_fake * rcp_fast(bm) + 1.f);// Je_new_fake^2
+			if(Je_new_fake2 > 1e-8f) log_jp += (lg2J - 0.5f * __builtin_amdgcn_logf(Je_new_fake2)) * 0.693147180559945f;
 		}
 	}
-	hk.template at<BASE + kSvdSites>();
-	const float J = S[0] * S[1] * S[2];
-	float b[9];
+	if(rebuild) {
+		if(!ill && detF > 0.f) {
+			float ratio[3];
 #pragma unroll
-	for(int j = 0; j < 3; ++j) {
+			for(int i = 0; i < 3; i++) ratio[i] = __builtin_amdgcn_sqrtf(Bn[i] * rcp_fast(lam[i]));
+			rescale_principal(F, U, ratio);
+		} else {
+			float Sn[3];
 #pragma unroll
-		for(int i = 0; i < 3; ++i) b[3 * j + i] = F[i] * F[j] + F[3 + i] * F[3 + j] + F[6 + i] * F[6 + j];
+			for(int i = 0; i < 3; i++) Sn[i] = __builtin_amdgcn_sqrtf(Bn[i]);
+			rebuild_through_v(F, U, lam, Sn);
+		}
 	}
-	const float twothirds = (float) (2.0 / 3.0);
-	const float bd0		  = b[0] * twothirds - (b[4] + b[8]) / 3.0f;
-	const float bd4		  = b[4] * twothirds - (b[0] + b[8]) / 3.0f;
-	const float bd8		  = b[8] * twothirds - (b[0] + b[4]) / 3.0f;
-	const float dev_b_coeff = mc.mu * powf(J, -2.f / 3.f);
-	const float i_coeff		= bm * .5f * ((J * J - 1.f) * 0.5f - logf(J));
-	PF[0]					= (dev_b_coeff * bd0 + i_coeff) * mc.volume;
-	PF[1]					= (dev_b_coeff * b[1]) * mc.volume;
-	PF[2]					= (dev_b_coeff * b[2]) * mc.volume;
-	PF[3]					= (dev_b_coeff * b[3]) * mc.volume;
-	PF[4]					= (dev_b_coeff * bd4 + i_coeff) * mc.volume;
-	PF[5]					= (dev_b_coeff * b[5]) * mc.volume;
-	PF[6]					= (dev_b_coeff * b[6]) * mc.volume;
-	PF[7]					= (dev_b_coeff * b[7]) * mc.volume;
-	PF[8]					= (dev_b_coeff * bd8 + i_coeff) * mc.volume;
-	hk.template at<BASE + kSvdSites + 1>();
+	// elasticity (:206-230): J, dev(b) of the renewed F
+	const float lg2Jn	   = 0.5f * __builtin_amdgcn_logf(Bn[0] * Bn[1] * Bn[2]);
+	const float Jn_abs	   = __builtin_amdgcn_exp2f(lg2Jn);
+	const bool neg		   = detF < 0.f && !rebuild;
+	const float J2		   = Jn_abs * Jn_abs;
+	const float dev_b_coeff = neg ? __builtin_nanf("") : mc.mu * __builtin_amdgcn_exp2f(lg2Jn * (-2.f / 3.f));
+	const float i_coeff	   = bm * .5f * ((J2 - 1.f) * 0.5f - (neg ? __builtin_nanf("") : lg2Jn * 0.693147180559945f));
+	const float trBn3	   = (Bn[0] + Bn[1] + Bn[2]) * (1.f / 3.f);
+	float d[3];
+#pragma unroll
+	for(int k = 0; k < 3; ++k) d[k] = (dev_b_coeff * (Bn[k] - trBn3) + i_coeff) * mc.volume;
+	sym_from_eig(U, d, PF);
+	hk.template at<BASE + kEigSites + 1>();
 }
 MPM_DEV void stress_nacc(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9]) {
 	NoHook nh;
@@ -574,7 +748,7 @@ MPM_DEV float stress_jfluid(const MaterialConst& mc, float J, const float (&A)[9
 	J += (A[0] + A[4] + A[8]) * dt * d_inv * J;
 	if(J < 0.1f) J = 0.1f;// reference compares with the double literal 0.1; no float lies in (0.1, 0.1f), so this is identical
 	const float voln	 = J * mc.volume;
-	const float pressure = mc.bulk * (powf(J, -mc.gamma) - 1.f);
+	const float pressure = mc.bulk * (__builtin_amdgcn_exp2f(-mc.gamma * __builtin_amdgcn_logf(J)) - 1.f);// J^-gamma (J >= 0.1)
 	const float k		 = d_inv * mc.viscosity;
 	contrib[0]			 = ((A[0] + A[0]) * k - pressure) * voln;
 	contrib[1]			 = (A[1] + A[3]) * k * voln;

@@ -1,0 +1,474 @@
+// mpm_g2p2g.hpp — the fused G2P + particle update + P2G kernel (g2p2g, Projects/GMPM/mgmpm_kernels.cuh:665-937 with the
+// per-material bodies :422-663), round-2 design: OCCUPANCY first.
+//
+// What the cost model says (tools/valu_microbench2/3, profiles/r02_cost_model.txt): one gfx950 wave can issue a VALU
+// instruction only every ~4.5-5 cycles (8.9 when it depends on the previous one) while the SIMD itself takes one every
+// ~1.6 (VOP2 / fma) to ~2.7 cycles (packed fp32, SGPR operands, min/max/cmp).  With two waves per SIMD - the round-1
+// kernel: 256 VGPRs, 17.8 KiB of LDS per wave - the SIMD idles most of the time no matter how the instructions are
+// ordered.  This kernel is therefore built to run FOUR waves per SIMD:
+//   * <= 128 VGPRs: the P2G scatter is no longer threaded through the next particle's arithmetic (that software pipeline
+//     cost ~40 live registers to hide the LDS latency inside one wave; with four waves the other waves hide it);
+//   * <= 9 KiB of LDS per wave: the advection records are read straight from global memory (prepare_blocks_kernel left
+//     them sorted), and BOTH arenas hold only nodes 1..6 of the 8^3 node cube around the block.  The gather never touches
+//     nodes 0 and 7; the scatter does only for particles that have just crossed into a neighbouring block (a few per cent
+//     in fast flows, none at rest): those lanes send the shell part of their stencil straight to the grid with global
+//     atomics (p2g_scatter<true>);
+//   * the per-particle math needs only U and sigma (sym_eig3 in mpm_device_math.hpp), not a full SVD.
+// One workgroup = ONE wave = one particle block, as before: LDS operations of a single wave execute in order, which
+// is what makes the atomic-free read-modify-write scatter legal (lanes of an iteration hold distinct stencil bases:
+// prepare_blocks_kernel sorts the records into "k-th particle of every key" order; collisions left over are resolved
+// through an owner table and a retry).
+#pragma once
+#include "mpm_device_math.hpp"
+
+namespace mpm {
+
+#ifndef MPM_G2P2G_WAVES
+#define MPM_G2P2G_WAVES 3// waves per SIMD the register allocation is held to
+#endif
+
+// LDS arenas: nodes 1..6 per axis of the 8^3 cube spanned by the block's 2x2x2 grid blocks.
+// Sort key of a particle = its stencil base in that cube, key = y * 36 + x * 6 + z (y slowest): with the usual population
+// (bases 1..4 per axis) a 16-lane group then holds one y-plane, which both layouts below serve without bank conflicts
+// beyond the hardware's b128 pass structure (tools/valu_microbench3: 4.0 cycles per ds_read_b128 on the gather arena,
+// 8.8 per read-modify-write instruction on the scatter arena, against 4.0 / 8.3 for a linear address pattern).
+constexpr int kP2GStrideX = 36, kP2GStrideY = 6, kP2GNodes = 216;			 // scatter arena: (x-1)*36 + (y-1)*6 + (z-1)
+constexpr int kG2PStrideY = 52, kG2PStrideX2 = 8, kG2PNodes2 = 6 * 52;	 // gather arena:  (y-1)*52 + (x-1)*8 + (z-1)
+
+struct ModelView {
+	const float* bins_src;// [bin][nch][64], laid out by the previous block numbering
+	float* bins_dst;	  // laid out by the current numbering
+	const int* binoff_src;// first bin of a block, previous numbering
+	const int* binoff_dst;// current numbering
+	const int* list_in;	  // advection records written by the previous step (sorted by prepare_blocks_kernel); row = row_of[b]
+	int* list_out;		  // records for the next step; row = destination block (current numbering)
+	const int* size;	  // particles per current block
+	const int* row_of;	  // row of list_in that belongs to current block b
+	int* out_count;		  // append counters of list_out
+	const int* blockinfo; // [block][kInfoRow]: source bin offsets, destination / grid block numbers (prepare_blocks_kernel)
+	MaterialConst mc;
+};
+
+template<int MAT>
+struct MatTraits;
+template<>
+struct MatTraits<0> {
+	static constexpr int nch = 4;
+};
+template<>
+struct MatTraits<1> {
+	static constexpr int nch = 12;
+};
+template<>
+struct MatTraits<2> {
+	static constexpr int nch = 13;
+};
+template<>
+struct MatTraits<3> {
+	static constexpr int nch = 13;
+};
+
+// P2G payload of one particle: everything the scatter needs after the material update.
+struct P2GPayload {
+	float fd[3];	 // offset from the new stencil base node, in cells
+	float mv[3];	 // mass * velocity
+	float contrib[9];// (A m - stress new_dt) D^-1 dx   (:850)
+};
+
+// Tensor-product B-spline gather of one particle per lane (:801-835): vel = sum W v, A = sum W v (x_i - x_p)^T in cell
+// units, separable over the three axes (27 x 6 + 9 x 9 + 3 x 12 multiply-adds instead of 27 x 12), on float2 so that the
+// x / y components and the (w, w (x_i - x_p)) weight pairs go through packed fp32.  A node is {vx, vy, vz, vz}: the
+// duplicate makes the load a full ds_read_b128 (4.0 cycles per wave against 7.1 for ds_read_b96) and gives the z
+// accumulators a natural register pair.
+MPM_DEV void gather_apic(const float4* __restrict__ gbase, const float (&w)[3][3], const float (&fd)[3], float (&vel)[3], float (&A)[9]) {
+	v2f_ wz[3], wy[3], wx[3];// {w, w * (node - particle)} per axis and stencil offset
+#pragma unroll
+	for(int t = 0; t < 3; ++t) {
+		wx[t] = (v2f_) {w[0][t], w[0][t] * ((float) t - fd[0])};
+		wy[t] = (v2f_) {w[1][t], w[1][t] * ((float) t - fd[1])};
+		wz[t] = (v2f_) {w[2][t], w[2][t] * ((float) t - fd[2])};
+	}
+	v2f_ vel_xy = {0.f, 0.f}, A0_xy = {0.f, 0.f}, A3_xy = {0.f, 0.f}, A6_xy = {0.f, 0.f};
+	v2f_ velz_A2 = {0.f, 0.f};
+	float A5 = 0.f, A8 = 0.f;
+#pragma unroll
+	for(int i = 0; i < 3; ++i) {
+		v2f_ u0_xy = {0.f, 0.f}, uy_xy = {0.f, 0.f}, uz_xy = {0.f, 0.f}, u0z_uyz = {0.f, 0.f};
+		float uzz = 0.f;
+#pragma unroll
+		for(int j = 0; j < 3; ++j) {
+			v2f_ t0_xy = {0.f, 0.f}, t1_xy = {0.f, 0.f}, t0z_t1z = {0.f, 0.f};
+#pragma unroll
+			for(int k = 0; k < 3; ++k) {
+				const float4 v = gbase[j * kG2PStrideY + i * kG2PStrideX2 + k];
+				const v2f_ vxy = {v.x, v.y}, vzz = {v.z, v.w};
+				t0_xy		   = vxy * wz[k].x + t0_xy;
+				t1_xy		   = vxy * wz[k].y + t1_xy;
+				t0z_t1z		   = wz[k] * vzz + t0z_t1z;
+			}
+			__builtin_amdgcn_sched_barrier(0);// at most one z-pencil (3 nodes, 12 registers) of loads in flight: the other waves of the SIMD cover the LDS latency, registers are the scarce resource
+			u0_xy	= t0_xy * wy[j].x + u0_xy;
+			uy_xy	= t0_xy * wy[j].y + uy_xy;
+			uz_xy	= t1_xy * wy[j].x + uz_xy;
+			u0z_uyz = wy[j] * t0z_t1z.x + u0z_uyz;
+			uzz += wy[j].x * t0z_t1z.y;
+		}
+		vel_xy	= u0_xy * wx[i].x + vel_xy;
+		A0_xy	= u0_xy * wx[i].y + A0_xy;
+		A3_xy	= uy_xy * wx[i].x + A3_xy;
+		A6_xy	= uz_xy * wx[i].x + A6_xy;
+		velz_A2 = wx[i] * u0z_uyz.x + velz_A2;
+		A5 += wx[i].x * u0z_uyz.y;
+		A8 += wx[i].x * uzz;
+	}
+	vel[0] = vel_xy.x;
+	vel[1] = vel_xy.y;
+	vel[2] = velz_A2.x;
+	A[0]   = A0_xy.x;
+	A[1]   = A0_xy.y;
+	A[2]   = velz_A2.y;
+	A[3]   = A3_xy.x;
+	A[4]   = A3_xy.y;
+	A[5]   = A5;
+	A[6]   = A6_xy.x;
+	A[7]   = A6_xy.y;
+	A[8]   = A8;
+}
+
+// Scatter one particle per active lane into the LDS arena (float4 {mass, px, py, pz} per node) WITHOUT atomics:
+// gfx950 executes ds_add_f32 at one lane per ~3 cycles (193 cycles per wave-instruction, profiles/r01_lds_microbench.txt);
+// a plain ds_read_b128 / 2 v_pk_fma / ds_write_b128 costs 17.  Correctness rests on two facts: (1) the caller only
+// activates lanes with pairwise distinct stencil bases, so for one stencil offset all lanes touch distinct nodes;
+// (2) a workgroup is a single wave, whose LDS operations execute in program order - the compiler barrier keeps the
+// read-modify-write of offset o ahead of the read of offset o+1, which may hit the node another lane just wrote.
+// EDGE: lanes whose stencil reaches cube nodes 0 or 7 (base coordinate 0 or 5) skip those nodes here; p2g_shell sends them
+// straight to the grid.
+template<bool EDGE>
+MPM_DEV void p2g_scatter(float4* __restrict__ arena, const P2GPayload& pl, float mass, bool act, int nx, int ny, int nz) {
+	float w[3][3];
+#pragma unroll
+	for(int d = 0; d < 3; ++d) bspline_weight_cells(pl.fd[d], w[d]);
+	float4* node0 = arena + (nx - 1) * kP2GStrideX + (ny - 1) * kP2GStrideY + (nz - 1);
+	const v2f_ c12 = {pl.contrib[7], pl.contrib[8]};
+#pragma unroll
+	for(int i = 0; i < 3; ++i) {
+		const float px = (float) i - pl.fd[0];
+#pragma unroll
+		for(int j = 0; j < 3; ++j) {
+			const float py	= (float) j - pl.fd[1];
+			const float wij = w[0][i] * w[1][j];
+			const float b0	= pl.mv[0] + pl.contrib[0] * px + pl.contrib[3] * py;
+			const v2f_ b12	= {pl.mv[1] + pl.contrib[1] * px + pl.contrib[4] * py, pl.mv[2] + pl.contrib[2] * px + pl.contrib[5] * py};
+#pragma unroll
+			for(int k = 0; k < 3; ++k) {
+				const float pz = (float) k - pl.fd[2];
+				const float W  = wij * w[2][k];
+				const v2f_ m0  = {mass, b0 + pl.contrib[6] * pz};
+				const v2f_ t12 = c12 * pz + b12;
+				bool in		   = act;
+				if constexpr(EDGE) {
+					if(i == 0) in &= nx != 0;
+					if(i == 2) in &= nx != 5;
+					if(j == 0) in &= ny != 0;
+					if(j == 2) in &= ny != 5;
+					if(k == 0) in &= nz != 0;
+					if(k == 2) in &= nz != 5;
+				}
+				if(in) {
+					float4* node	 = node0 + i * kP2GStrideX + j * kP2GStrideY + k;
+					const float4 acc = *node;
+					v2f_ a01		 = {acc.x, acc.y};
+					v2f_ a23		 = {acc.z, acc.w};
+					a01				 = m0 * W + a01;
+					a23				 = t12 * W + a23;
+					*node			 = make_float4(a01.x, a01.y, a23.x, a23.y);
+				}
+				__asm__ volatile("" ::: "memory");
+				__builtin_amdgcn_sched_barrier(0);// keep the 27 steps' arithmetic from being hoisted (registers)
+			}
+		}
+	}
+}
+
+// The shell part of an edge lane's stencil (cube nodes 0 / 7, i.e. cells of the 2x2x2 grid blocks outside the LDS arena):
+// one global float atomic per node and channel.  Rare (a particle that has just crossed into a neighbouring block), so
+// this is a rolled loop with run-time stencil offsets: small code, few registers.
+MPM_DEV void p2g_shell(const P2GPayload& pl, float mass, bool act, int nx, int ny, int nz, const int* __restrict__ s_nb, float* __restrict__ next_grid) {
+	float w[3][3];
+#pragma unroll
+	for(int d = 0; d < 3; ++d) bspline_weight_cells(pl.fd[d], w[d]);
+#pragma nounroll
+	for(int o = 0; o < 27; ++o) {
+		const int i = o / 9, j = (o / 3) % 3, k = o % 3;
+		const int gx = nx + i, gy = ny + j, gz = nz + k;
+		const bool out = ((gx == 0) | (gx == 7) | (gy == 0) | (gy == 7) | (gz == 0) | (gz == 7)) & act;
+		if(!out) continue;
+		const int nb = s_nb[(gx >> 2) * 4 + (gy >> 2) * 2 + (gz >> 2)];
+		if(nb < 0) continue;
+		const float wi = i == 0 ? w[0][0] : (i == 1 ? w[0][1] : w[0][2]);
+		const float wj = j == 0 ? w[1][0] : (j == 1 ? w[1][1] : w[1][2]);
+		const float wk = k == 0 ? w[2][0] : (k == 1 ? w[2][1] : w[2][2]);
+		const float W  = wi * wj * wk;
+		const float px = (float) i - pl.fd[0], py = (float) j - pl.fd[1], pz = (float) k - pl.fd[2];
+		float* g	   = next_grid + (size_t) nb * 256 + (gx & 3) * 16 + (gy & 3) * 4 + (gz & 3);
+		unsafeAtomicAdd(g, mass * W);
+		unsafeAtomicAdd(g + 64, (pl.mv[0] + pl.contrib[0] * px + pl.contrib[3] * py + pl.contrib[6] * pz) * W);
+		unsafeAtomicAdd(g + 128, (pl.mv[1] + pl.contrib[1] * px + pl.contrib[4] * py + pl.contrib[7] * pz) * W);
+		unsafeAtomicAdd(g + 192, (pl.mv[2] + pl.contrib[2] * px + pl.contrib[5] * py + pl.contrib[8] * pz) * W);
+	}
+}
+
+template<int MAT>
+__global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_keys, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, float dt, float new_dt, int* __restrict__ status) {
+	constexpr int NCH = MatTraits<MAT>::nch;
+	__shared__ float4 g2p[kG2PNodes2];// node velocities {vx, vy, vz, vz} of cube nodes 1..6 per axis
+	__shared__ float4 p2g[kP2GNodes]; // {mass, momentum} accumulators of cube nodes 1..6 per axis
+	__shared__ unsigned char s_owner[216];
+	__shared__ int s_src_binoff[27], s_dst_no[27], s_nb[8];
+
+	const int lane = threadIdx.x;
+	// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Consecutive block numbers are spatial
+	// neighbours (they share grid blocks: reads in the set-up, atomics in the write-back), so every XCD gets one contiguous
+	// eighth of the block range instead of every eighth block.
+	const int nwg = (int) gridDim.x, xcd = (int) (blockIdx.x & 7u), q = (int) (blockIdx.x >> 3);
+	const int bid = xcd * (nwg >> 3) + min(xcd, nwg & 7) + q;// XCD r owns (nwg / 8) + (r < nwg % 8) consecutive numbers
+	const int b	  = block_list ? block_list[bid] : bid;
+	// ---- round trip 1: everything addressed by the block number alone (scalar loads)
+	const int size		 = mv.size[b];
+	const int row		 = mv.row_of[b];
+	const int binoff_dst = mv.binoff_dst[b];
+	if(size == 0) return;// (:692-697)
+	const int* list		= mv.list_in + (size_t) row * cfg.ppb;
+	const float dx_inv	= cfg.dx_inv;
+	const float scale	= 4.f * cfg.dx_inv;// dx * D^-1 (settings.h:66): A is accumulated in cell units
+	const float mass	= mv.mc.mass;
+	const int key_shift = cfg.pid_bits;
+	const int tag_shift = cfg.pid_bits + kKeyBits;
+	// ---- round trip 2: the block's row of look-up results and the records of the first two iterations
+	const int info = mv.blockinfo[(size_t) b * kInfoRow + lane];
+	int rec_cur	   = list[min(lane, size - 1)];
+	int rec_next   = list[min(64 + lane, size - 1)];
+	if(lane < 27) s_src_binoff[lane] = info;
+	else if(lane < 54) s_dst_no[lane - 27] = info;
+	else if(lane < 62) s_nb[lane - 54] = info;
+	for(int i = lane; i < kP2GNodes; i += 64) p2g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+	__syncthreads();
+	// ---- round trip 3: the 8 grid blocks (lane = cell -> 256-B rows per channel, :699-727) and the first 64 particles
+	const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;// lane == cell of a 4x4x4 block
+	float4 gv[8];
+#pragma unroll
+	for(int lb = 0; lb < 8; ++lb) {
+		const int nb	= s_nb[lb];
+		const float* gb = grid + (size_t) (nb < 0 ? 0 : nb) * 256;
+		gv[lb].x		= gb[64 + lane];
+		gv[lb].y		= gb[128 + lane];
+		gv[lb].z		= gb[192 + lane];
+		if(nb < 0) gv[lb].x = gv[lb].y = gv[lb].z = 0.f;
+		gv[lb].w = gv[lb].z;
+	}
+	// Software prefetch: the particle data of iteration i+1 is requested at the top of iteration i (HBM latency under load
+	// is 2-4 us).  The loads are unconditional - lanes past the end of the block re-read its last record - so that the
+	// compiler can count them in s_waitcnt; their arrival is implied by the list-append atomics' results being consumed
+	// at the end of the iteration (memory operations return in order).
+	struct Prefetch {
+		float pos[3], st[10];
+		int key;// the stencil base this particle was predicted to have after this step (its sort key)
+	};
+	auto fetch = [&](int rec, Prefetch& f) {
+		const int tag	 = rec >> tag_shift;
+		const int sp	 = rec & (cfg.ppb - 1);
+		const int sbin	 = s_src_binoff[tag] + (sp >> 6);
+		const float* src = mv.bins_src + (size_t) sbin * (NCH * kBin) + (sp & 63);
+		f.key			 = (rec >> key_shift) & 255;
+		f.pos[0]		 = src[0];
+		f.pos[1]		 = src[kBin];
+		f.pos[2]		 = src[2 * kBin];
+		if constexpr(MAT == 0) {
+			f.st[0] = src[3 * kBin];
+		} else {
+#pragma unroll
+			for(int d = 0; d < 9; ++d) f.st[d] = src[(3 + d) * kBin];
+			if constexpr(NCH == 13) f.st[9] = src[12 * kBin];
+		}
+	};
+	Prefetch pf;
+	fetch(rec_cur, pf);
+#pragma unroll
+	for(int lb = 0; lb < 8; ++lb) {
+		const int ax = cx + ((lb & 4) ? 4 : 0) - 1, ay = cy + ((lb & 2) ? 4 : 0) - 1, az = cz + ((lb & 1) ? 4 : 0) - 1;
+		if(((unsigned) ax < 6u) & ((unsigned) ay < 6u) & ((unsigned) az < 6u)) g2p[ay * kG2PStrideY + ax * kG2PStrideX2 + az] = gv[lb];
+	}
+	__syncthreads();
+	for(int idx0 = 0; idx0 < size; idx0 += 64) {
+		const bool active = idx0 + lane < size;
+		const int pidib	  = idx0 + lane;// slot in the destination bins == position in the sorted order
+		// ---- advection record -> source bin (:747-768): data was requested one iteration ago
+		float pos[3] = {pf.pos[0], pf.pos[1], pf.pos[2]};
+		float st[10];// J, or F[9] (+ logJp)
+#pragma unroll
+		for(int d = 0; d < 10; ++d) st[d] = pf.st[d];
+		const int rec_nn = list[min(idx0 + 128 + lane, size - 1)];
+		// ---- stencil base + weights (:774-797) for ALL lanes (idle lanes of a last partial iteration carry a dummy
+		//      position inside the block); offsets in cell units (exact: dx is a power of two)
+		int base[3], arena[3];
+		float vel[3], A[9];
+		{
+			float fd[3], w[3][3];
+#pragma unroll
+			for(int d = 0; d < 3; ++d) {
+				const float p = pos[d] * dx_inv;
+				base[d]		  = lround_pos(p) - 1;
+				fd[d]		  = p - (float) base[d];
+				bspline_weight_cells(fd[d], w[d]);
+				arena[d] = ((base[d] - 1) & 3) + 1;
+			}
+			gather_apic(g2p + (arena[1] - 1) * kG2PStrideY + (arena[0] - 1) * kG2PStrideX2 + (arena[2] - 1), w, fd, vel, A);
+		}
+		P2GPayload pl;
+		// Every lane runs the whole body: the idle lanes of a last partial iteration carry a dummy particle and write it into
+		// the padding slots of the block's last bin (slot == pidib < 64 * ceil(size / 64), allocated but never read), which
+		// keeps the 13 stores out of divergent control flow (countable for s_waitcnt).
+		// ---- advect (:838)
+#pragma unroll
+		for(int d = 0; d < 3; ++d) pos[d] += vel[d] * dt;
+		// ---- new base, re-bucket (:852-866, add_advection particle_buffer.cuh:100-135).  The list-append atomics are
+		//      issued BEFORE the stress computation, which hides their round trip to L2.
+		int nbase[3], narena[3], dirv[3];
+		bool in_arena = active;
+#pragma unroll
+		for(int d = 0; d < 3; ++d) {
+			const float p = pos[d] * dx_inv;
+			nbase[d]	  = lround_pos(p) - 1;
+			pl.fd[d]	  = p - (float) nbase[d];
+			pl.mv[d]	  = mass * vel[d];
+			dirv[d]		  = ((base[d] - 1) >> 2) - ((nbase[d] - 1) >> 2);
+			narena[d]	  = arena[d] + (nbase[d] - base[d]);
+			in_arena &= (narena[d] >= 0) & (narena[d] <= 5);
+		}
+		const int key	  = narena[1] * 36 + narena[0] * 6 + narena[2];
+		const bool dir_ok = ((unsigned) (dirv[0] + 1) < 3u) & ((unsigned) (dirv[1] + 1) < 3u) & ((unsigned) (dirv[2] + 1) < 3u);
+		const int ntag	  = dir_ok ? (dirv[0] + 1) * 9 + (dirv[1] + 1) * 3 + dirv[2] + 1 : kStay;
+		const int dno	  = (active && dir_ok) ? s_dst_no[ntag] : -1;
+		// sort key for the NEXT step: predicted stencil base after one more advection with the current velocity,
+		// expressed in the cube of the block the particle is in after THIS step (clamped to the 6^3 range)
+		int pk[3];
+#pragma unroll
+		for(int d = 0; d < 3; ++d) {
+			const int pb = (int) __builtin_rintf((pos[d] + vel[d] * new_dt) * dx_inv) - 1;// a prediction: ties do not matter
+			pk[d]		 = min(max(((nbase[d] - 1) & 3) + 1 + (pb - nbase[d]), 0), 5);
+		}
+		const int pkey	= pk[1] * 36 + pk[0] * 6 + pk[2];
+		const int rec	= (ntag << tag_shift) | (pkey << key_shift) | pidib;
+		const bool stay = dno >= 0 && ntag == kStay;
+		// particles that stay in this block share one wave-aggregated atomic
+		const unsigned long long stay_m = __ballot(stay);
+		const int stay_leader			= stay_m ? __ffsll((long long) stay_m) - 1 : 0;
+		const int stay_rank				= __popcll(stay_m & ((1ull << lane) - 1ull));
+		int raw_stay = 0, raw_move = 0;
+		int b_opaque = b;
+		__asm__("" : "+v"(b_opaque));// hide the uniform address: the compiler's atomic optimiser would broadcast the
+									 // result with v_readfirstlane right here, i.e. wait for the round trip
+		if(stay_m != 0ull && lane == stay_leader) raw_stay = atomicAdd(&mv.out_count[b_opaque], __popcll(stay_m));
+		if(dno >= 0 && !stay) raw_move = atomicAdd(&mv.out_count[dno], 1);
+		if(active) {
+			if(dno < 0) atomicAdd(&status[ST_LOST], 1);// reference: particle silently lost (particle_buffer.cuh:105-113)
+			if(!in_arena) atomicAdd(&status[ST_ARENA], 1);// (:877-885) contribution discarded
+		}
+		// ---- material update, store to the destination bin (coalesced: slot == pidib) (:470-663)
+		float* dst = mv.bins_dst + (size_t) (binoff_dst + (pidib >> 6)) * (NCH * kBin) + (pidib & 63);
+		dst[0]		  = pos[0];
+		dst[kBin]	  = pos[1];
+		dst[2 * kBin] = pos[2];
+		if constexpr(MAT == 0) {
+			float Aw[9];
+#pragma unroll
+			for(int d = 0; d < 9; ++d) Aw[d] = A[d] * cfg.dx;
+			const float J = stress_jfluid(mv.mc, st[0], Aw, dt, cfg.d_inv, pl.contrib);
+			dst[3 * kBin] = J;
+		} else {
+			float dws[9], Fold[9], F[9];
+#pragma unroll
+			for(int d = 0; d < 9; ++d) {
+				dws[d]	= (A[d] * dt) * scale + ((d & 0x3) != 0 ? 0.f : 1.f);
+				Fold[d] = st[d];
+			}
+			matmul3(dws, Fold, F);
+			NoHook nh;
+			if constexpr(MAT == 1) {
+				stress_fixed_corotated<0>(mv.mc, F, pl.contrib, nh);
+#pragma unroll
+				for(int d = 0; d < 9; ++d) dst[(3 + d) * kBin] = F[d];
+			} else if constexpr(MAT == 2) {
+				float lj = st[9];
+				stress_sand<0>(mv.mc, F, lj, pl.contrib, nh, dst + 3 * kBin, kBin);
+				dst[12 * kBin] = lj;
+			} else {
+				float lj = st[9];
+				stress_nacc<0>(mv.mc, F, lj, pl.contrib, nh);
+#pragma unroll
+				for(int d = 0; d < 9; ++d) dst[(3 + d) * kBin] = F[d];
+				dst[12 * kBin] = lj;
+			}
+		}
+		// (:850) contrib = (A m - contrib new_dt) D^-1, pre-multiplied by dx so that P2G can stay in cell units
+		{
+			const float am = mass * cfg.dx * cfg.dx * cfg.d_inv;
+			const float cs = new_dt * cfg.d_inv * cfg.dx;
+#pragma unroll
+			for(int d = 0; d < 9; ++d) pl.contrib[d] = A[d] * am - pl.contrib[d] * cs;
+		}
+		// ---- the next iteration's particle data is requested here: in flight during the scatter (27 ordered LDS round trips)
+		//      without occupying 14 registers during the gather and the material update
+		fetch(rec_next, pf);
+		rec_next = rec_nn;
+		// ---- P2G (:887-905): lanes whose stencil base is unique in the wave scatter; the others retry (rare: a partial or
+		//      overflowing sort round, a mispredicted key)
+		{
+			const bool edge = (narena[0] == 0) | (narena[0] == 5) | (narena[1] == 0) | (narena[1] == 5) | (narena[2] == 0) | (narena[2] == 5);
+			const int okey	= in_arena ? key : 0;
+			bool pending	= in_arena;
+			if(__any(in_arena && edge)) p2g_shell(pl, mass, in_arena && edge, narena[0], narena[1], narena[2], s_nb, next_grid);
+			while(__any(pending)) {
+				// one LDS round trip: the workgroup is a single wave, whose LDS operations execute in order, so the read
+				// below sees the writes above without waiting for them in between
+				if(pending) s_owner[okey] = (unsigned char) lane;
+				__asm__ volatile("" ::: "memory");// another lane may have written the same byte: no store-to-load forwarding
+				const bool win = pending && (int) s_owner[okey] == lane;
+				// the payload arithmetic of the 27 steps is invariant in this retry loop: without this the compiler hoists all of
+				// it out of the loop (135 live values)
+#pragma unroll
+				for(int d = 0; d < 3; ++d) __asm__ volatile("" : "+v"(pl.fd[d]));
+				if(__any(win && edge)) p2g_scatter<true>(p2g, pl, mass, win, narena[0], narena[1], narena[2]);
+				else p2g_scatter<false>(p2g, pl, mass, win, narena[0], narena[1], narena[2]);
+				pending = pending && !win;
+			}
+		}
+		// ---- list append: the atomics' results are in by now (and with them the next iteration's particle data)
+		{
+			const int basev = __shfl(raw_stay, stay_leader);
+			if(dno >= 0) {
+				const int slot = stay ? basev + stay_rank : raw_move;
+				if(slot >= cfg.ppb)
+					atomicOr(&status[ST_OVERFLOW], 2);// reference drops beyond 128 per cell (:122-130)
+				else
+					mv.list_out[(size_t) dno * cfg.ppb + slot] = rec;
+			}
+		}
+	}
+	__syncthreads();
+	// ---- arena -> next grid: one hardware f32 atomic per touched node and channel (:907-936).  216 nodes, 4 rounds.
+	for(int n = lane; n < kP2GNodes; n += 64) {
+		const int x = n / 36 + 1, y = (n / 6) % 6 + 1, z = n % 6 + 1;// cube coordinates 1..6
+		const int nb = s_nb[(x >> 2) * 4 + (y >> 2) * 2 + (z >> 2)];
+		const float4 v = p2g[n];
+		if(nb >= 0) {
+			float* g = next_grid + (size_t) nb * 256 + (x & 3) * 16 + (y & 3) * 4 + (z & 3);
+			if(v.x != 0.f) unsafeAtomicAdd(g, v.x);
+			if(v.y != 0.f) unsafeAtomicAdd(g + 64, v.y);
+			if(v.z != 0.f) unsafeAtomicAdd(g + 128, v.z);
+			if(v.w != 0.f) unsafeAtomicAdd(g + 192, v.w);
+		}
+	}
+}
+
+}// namespace mpm

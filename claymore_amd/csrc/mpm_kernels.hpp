@@ -40,14 +40,9 @@ namespace mpm {
 constexpr int kBin		  = 64; // particles per AoSoA bin == wavefront width
 constexpr int kG2P2GThreads = 64; // ONE wave per particle block: no cross-wave LDS hazards, no barriers that wait
 constexpr int kMaxModels  = 8;
-constexpr int kArenaStrideX = 68; // arena x stride in float4 nodes (64 + 4: keeps every b128 lane group on 16 distinct 16-B slots)
-constexpr int kArenaNodes	= 544;// >= 7*68 + 7*8 + 7 + 1
-constexpr int kSortChunk	= 1024;// advection records staged in LDS per pass of g2p2g (a block with more particles takes several passes)
 constexpr int kSortRounds	= 24;  // particles per key (per chunk) that get an exact interleaved position; more -> appended behind
 constexpr int kSortKeys		= 216; // sort key = PREDICTED stencil base of the particle in the arena of its block (6^3 values)
 constexpr int kKeyBits		= 8;
-constexpr int kG2PStrideX	= 52;  // G2P arena holds only nodes 1..6 of the 8^3 arena (the gather never touches 0 and 7):
-constexpr int kG2PNodes		= 312; // index (x-1)*52 + (y-1)*8 + (z-1); 52 = 48 + 4 keeps ds_read_b96 lane groups conflict-free
 constexpr int kStay		  = 13; // dir_offset(0,0,0), utility_funcs.hpp:25-27
 
 // status block indices (device ints, read back once per substep)
@@ -226,256 +221,10 @@ __global__ __launch_bounds__(256) void pack_sdf_kernel(size_t n, const float* __
 	if(i < n) out[i] = make_float4(sd[i], gx[i], gy[i], gz[i]);
 }
 
-// ------------------------------------------------------------------------------------------------------
-// G2P2G
-// ------------------------------------------------------------------------------------------------------
-struct ModelView {
-	const float* bins_src;// [bin][nch][64], laid out by the previous block numbering
-	float* bins_dst;	  // laid out by the current numbering
-	const int* binoff_src;// first bin of a block, previous numbering
-	const int* binoff_dst;// current numbering
-	const int* list_in;	  // advection records written by the previous step; row = row_of[b]
-	int* list_out;		  // records for the next step; row = destination block (current numbering)
-	const int* size;	  // particles per current block
-	const int* row_of;	  // row of list_in that belongs to current block b
-	int* out_count;		  // append counters of list_out
-	const int* blockinfo; // [block][kInfoRow]: source bin offsets, destination / grid block numbers (prepare_blocks_kernel)
-	MaterialConst mc;
-};
-
-template<int MAT>
-struct MatTraits;
-template<>
-struct MatTraits<0> {
-	static constexpr int nch = 4;
-};
-template<>
-struct MatTraits<1> {
-	static constexpr int nch = 12;
-};
-template<>
-struct MatTraits<2> {
-	static constexpr int nch = 13;
-};
-template<>
-struct MatTraits<3> {
-	static constexpr int nch = 13;
-};
-
 __device__ __forceinline__ void dir_components(int dir, int& dx, int& dy, int& dz) {
 	dz = (dir % 3) - 1;
 	dy = ((dir / 3) % 3) - 1;
 	dx = (dir / 9) - 1;
-}
-
-// P2G payload of one particle: everything the scatter needs after the material update.
-struct P2GPayload {
-	float fd[3];	 // offset from the new stencil base node, in cells
-	float mv[3];	 // mass * velocity
-	float contrib[9];// (A m - stress new_dt) D^-1 dx   (see :850)
-};
-
-// Scatter one particle per active lane into the LDS arena (float4 {mass, px, py, pz} per node) WITHOUT atomics:
-// gfx950 executes ds_add_f32 at one lane per ~3 cycles (193 cycles per wave-instruction, tools/lds_microbench),
-// a plain ds_read_b128 / 4 v_add / ds_write_b128 costs 17.  Correctness rests on two facts: (1) the caller only
-// activates lanes with pairwise distinct stencil bases, so for one stencil offset all lanes touch distinct nodes;
-// (2) a workgroup is a single wave, whose LDS operations execute in program order - the compiler barrier keeps the
-// read-modify-write of offset o ahead of the read of offset o+1, which may hit the node another lane just wrote.
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void p2g_scatter_rmw(float4* __restrict__ node0, const P2GPayload& pl, float mass) {
-	float w[3][3];
-#pragma unroll
-	for(int d = 0; d < 3; ++d) bspline_weight_cells(pl.fd[d], w[d]);
-	// packed fp32 (v_pk_fma_f32) on the naturally paired halves of the float4 node: {m, px} and {py, pz}
-	const v2f c12 = {pl.contrib[7], pl.contrib[8]};
-#pragma unroll
-	for(int i = 0; i < 3; ++i) {
-		const float px = (float) i - pl.fd[0];
-#pragma unroll
-		for(int j = 0; j < 3; ++j) {
-			const float py	= (float) j - pl.fd[1];
-			const float wij = w[0][i] * w[1][j];
-			const float b0	= pl.mv[0] + pl.contrib[0] * px + pl.contrib[3] * py;
-			v2f b12			= {pl.mv[1] + pl.contrib[1] * px + pl.contrib[4] * py, pl.mv[2] + pl.contrib[2] * px + pl.contrib[5] * py};
-#pragma unroll
-			for(int k = 0; k < 3; ++k) {
-				const float pz = (float) k - pl.fd[2];
-				const float W  = wij * w[2][k];
-				float4* node   = node0 + i * kArenaStrideX + j * 8 + k;
-				float4 acc	   = *node;
-				v2f m0		   = {mass, b0 + pl.contrib[6] * pz};
-				v2f t12		   = c12 * pz + b12;
-				v2f a01		   = {acc.x, acc.y};
-				v2f a23		   = {acc.z, acc.w};
-				a01			   = m0 * W + a01;
-				a23			   = t12 * W + a23;
-				*node		   = make_float4(a01.x, a01.y, a23.x, a23.y);
-				__asm__ volatile("" ::: "memory");
-				__builtin_amdgcn_sched_barrier(0);// rare path: keep the 27 steps' arithmetic from being hoisted (registers)
-			}
-		}
-	}
-}
-
-// Tensor-product B-spline gather of one particle per lane (:801-835): vel = sum W v, A = sum W v (x_i - x_p)^T in cell
-// units, separable over the three axes (27 x 6 + 9 x 9 + 3 x 12 multiply-adds instead of 27 x 12).  Written on float2
-// so that the x and y components, and the (w, w (x_i - x_p)) weight pairs, go through packed fp32 FMAs (v_pk_fma_f32 with
-// op_sel broadcasts): 3 packed instructions per node instead of 6 scalar ones.
-constexpr int kGatherSites = 9;
-template<int BASE, class Hook>
-__device__ __forceinline__ void gather_apic(const float4* __restrict__ gbase, const float (&w)[3][3], const float (&fd)[3], float (&vel)[3], float (&A)[9], Hook& hk) {
-	v2f wz[3], wy[3], wx[3];// {w, w * (node - particle)} per axis and stencil offset
-#pragma unroll
-	for(int t = 0; t < 3; ++t) {
-		wx[t] = (v2f) {w[0][t], w[0][t] * ((float) t - fd[0])};
-		wy[t] = (v2f) {w[1][t], w[1][t] * ((float) t - fd[1])};
-		wz[t] = (v2f) {w[2][t], w[2][t] * ((float) t - fd[2])};
-	}
-	v2f vel_xy = {0.f, 0.f}, A0_xy = {0.f, 0.f}, A3_xy = {0.f, 0.f}, A6_xy = {0.f, 0.f};
-	v2f velz_A2 = {0.f, 0.f};
-	float A5 = 0.f, A8 = 0.f;
-	v2f u0_xy, uy_xy, uz_xy, u0z_uyz;
-	float uzz;
-#define MPM_GATHER_ROW(i, j)                                                     \
-	{                                                                            \
-		v2f t0_xy = {0.f, 0.f}, t1_xy = {0.f, 0.f}, t0z_t1z = {0.f, 0.f};        \
-		_Pragma("unroll") for(int k = 0; k < 3; ++k) {                           \
-			const float4 v = gbase[i * kG2PStrideX + j * 8 + k];                 \
-			const v2f vxy  = {v.x, v.y};                                         \
-			t0_xy		   = vxy * wz[k].x + t0_xy;                              \
-			t1_xy		   = vxy * wz[k].y + t1_xy;                              \
-			t0z_t1z		   = wz[k] * v.z + t0z_t1z;                              \
-		}                                                                        \
-		if(j == 0) {                                                             \
-			u0_xy = uy_xy = uz_xy = u0z_uyz = (v2f) {0.f, 0.f};                  \
-			uzz											= 0.f;                   \
-		}                                                                        \
-		u0_xy	= t0_xy * wy[j].x + u0_xy;                                       \
-		uy_xy	= t0_xy * wy[j].y + uy_xy;                                       \
-		uz_xy	= t1_xy * wy[j].x + uz_xy;                                       \
-		u0z_uyz = wy[j] * t0z_t1z.x + u0z_uyz;                                   \
-		uzz += wy[j].x * t0z_t1z.y;                                              \
-		if(j == 2) {                                                             \
-			vel_xy	= u0_xy * wx[i].x + vel_xy;                                  \
-			A0_xy	= u0_xy * wx[i].y + A0_xy;                                   \
-			A3_xy	= uy_xy * wx[i].x + A3_xy;                                   \
-			A6_xy	= uz_xy * wx[i].x + A6_xy;                                   \
-			velz_A2 = wx[i] * u0z_uyz.x + velz_A2;                               \
-			A5 += wx[i].x * u0z_uyz.y;                                           \
-			A8 += wx[i].x * uzz;                                                 \
-		}                                                                        \
-		hk.template at<BASE + 3 * i + j>();                                      \
-	}
-	MPM_GATHER_ROW(0, 0)
-	MPM_GATHER_ROW(0, 1)
-	MPM_GATHER_ROW(0, 2)
-	MPM_GATHER_ROW(1, 0)
-	MPM_GATHER_ROW(1, 1)
-	MPM_GATHER_ROW(1, 2)
-	MPM_GATHER_ROW(2, 0)
-	MPM_GATHER_ROW(2, 1)
-	MPM_GATHER_ROW(2, 2)
-#undef MPM_GATHER_ROW
-	vel[0] = vel_xy.x;
-	vel[1] = vel_xy.y;
-	vel[2] = velz_A2.x;
-	A[0]   = A0_xy.x;
-	A[1]   = A0_xy.y;
-	A[2]   = velz_A2.y;
-	A[3]   = A3_xy.x;
-	A[4]   = A3_xy.y;
-	A[5]   = A5;
-	A[6]   = A6_xy.x;
-	A[7]   = A6_xy.y;
-	A[8]   = A8;
-}
-
-// The P2G scatter of one particle per lane as a chain of 27 ordered LDS read-modify-write steps that is threaded
-// through unrelated register-only arithmetic (the NEXT particle's re-bucketing, F update, SVD and stress).  Each step
-// is an LDS round trip (~130-200 cycles under load) and the steps cannot overlap each other - step o+1 may hit the node
-// another lane wrote in step o (see p2g_scatter_rmw) - so issued back to back they leave the wave idle; spread over
-// NSITES call sites `at<SITE>()` of the host computation (~30 VALU instructions apart) the round trips disappear
-// behind it.  Site s completes steps [27 s / NSITES, 27 (s+1) / NSITES): the accumulator of the following step is
-// requested right after a step's write and consumed at the next site.  Only lanes with `win` (pairwise distinct
-// stencil bases) take part; the others are scattered afterwards by p2g_resolve.
-template<int NSITES>
-struct ScatterChain {
-	float4* node0;
-	P2GPayload pp;// element-wise copy: a reference member or a struct copy keeps the payload in scratch memory
-	float mass;
-	int win;// (int, not bool: a 1-byte member makes the compiler slice its neighbours into bytes)
-	float pw[3][3];
-	float b0, wij;
-	v2f b12, c12;
-	float4 acc;
-	MPM_DEV ScatterChain(float4* n0, const P2GPayload& p, float m, bool w)
-		: node0(n0)
-		, mass(m)
-		, win(w) {
-#pragma unroll
-		for(int d = 0; d < 3; ++d) {
-			pp.fd[d] = p.fd[d];
-			pp.mv[d] = p.mv[d];
-		}
-#pragma unroll
-		for(int d = 0; d < 9; ++d) pp.contrib[d] = p.contrib[d];
-#pragma unroll
-		for(int d = 0; d < 3; ++d) bspline_weight_cells(pp.fd[d], pw[d]);
-		c12 = (v2f) {pp.contrib[7], pp.contrib[8]};
-		if(win) acc = node0[0];
-	}
-	MPM_DEV void step(int o) {// o is a compile-time constant after unrolling
-		const int i = o / 9, j = (o / 3) % 3, k = o % 3;
-		if(k == 0) {
-			const float px = (float) i - pp.fd[0], py = (float) j - pp.fd[1];
-			b0	= pp.mv[0] + pp.contrib[0] * px + pp.contrib[3] * py;
-			b12 = (v2f) {pp.mv[1] + pp.contrib[1] * px + pp.contrib[4] * py, pp.mv[2] + pp.contrib[2] * px + pp.contrib[5] * py};
-			wij = pw[0][i] * pw[1][j];
-		}
-		const float pz = (float) k - pp.fd[2];
-		const float W  = wij * pw[2][k];
-		const v2f m0   = {mass, b0 + pp.contrib[6] * pz};
-		const v2f t12  = c12 * pz + b12;
-		if(win) {
-			v2f a01			 = {acc.x, acc.y};
-			v2f a23			 = {acc.z, acc.w};
-			a01				 = m0 * W + a01;
-			a23				 = t12 * W + a23;
-			const int off	 = i * kArenaStrideX + j * 8 + k;
-			node0[off]		 = make_float4(a01.x, a01.y, a23.x, a23.y);
-			__asm__ volatile("" ::: "memory");
-			if(o + 1 < 27) {
-				const int i1 = (o + 1) / 9, j1 = ((o + 1) / 3) % 3, k1 = (o + 1) % 3;
-				acc			 = node0[i1 * kArenaStrideX + j1 * 8 + k1];
-			}
-		}
-	}
-	template<int SITE>
-	MPM_DEV void at() {
-		static_assert(SITE >= 0 && SITE < NSITES, "site out of range");
-#pragma unroll
-		for(int o = SITE * 27 / NSITES; o < (SITE + 1) * 27 / NSITES; ++o) step(o);
-	}
-	template<int LO, int HI>
-	MPM_DEV void range() {
-		if constexpr(LO < HI) {
-			at<LO>();
-			range<LO + 1, HI>();
-		}
-	}
-};
-
-// Resolve intra-wave conflicts for one batch of payloads: lanes whose stencil base (key) is unique in the wave
-// scatter immediately; the others retry.  key < 216 (6^3 possible new cells around a block).
-__device__ __forceinline__ void p2g_resolve(float4* __restrict__ arena, unsigned char* __restrict__ owner, bool pending, int key, int nodeoff, const P2GPayload& pl, float mass, int lane) {
-	while(__any(pending)) {
-		if(pending) owner[key] = (unsigned char) lane;
-		__syncthreads();// single-wave workgroup: orders the LDS write before the read-back (and fences the compiler)
-		const bool win = pending && (int) owner[key] == lane;
-		__syncthreads();
-		if(win) p2g_scatter_rmw(arena + nodeoff, pl, mass);
-		pending = pending && !win;
-	}
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -626,402 +375,9 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 	}
 }
 
-// Phase timing (ABL & 32, profiling builds only): wall cycles (s_memtime) that wave 0..n spend in each part of the
-// iteration, summed over all waves (slot names: claymore_hip.hip, mpm_destroy); profiles/r01_phase_timing.txt.
-__device__ unsigned long long g_prof[1024][20];// spread over 1024 rows: same-address atomics serialise
-#define MPM_TICK(slot) \
-	if constexpr(ABL & 32) { \
-		__asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-		const unsigned long long t_now = __builtin_readcyclecounter(); \
-		t_acc[slot] += t_now - t_last; \
-		t_last = t_now; \
-	}
-
-// tools/asm_stats.sh -DMPM_ASM_MARKS: comment markers in the assembly for per-phase instruction counts
-#ifdef MPM_ASM_MARKS
-#define MPM_MARK(name) __asm__ volatile("; MPM_MARK " name)
-#else
-#define MPM_MARK(name)
-#endif
-
-// ABL: ablation mask for profiling builds (0 in production): 1 skip the P2G scatter, 2 skip the stress (SVD),
-// 4 skip the G2P gather, 32 phase timing (below).  Values are kept live with empty asm statements so that the compiler
-// cannot delete upstream work.
-template<int MAT, int ABL = 0>
-__global__ __launch_bounds__(kG2P2GThreads, 2) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_keys, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, float dt, float new_dt, int* __restrict__ status) {
-	constexpr int NCH = MatTraits<MAT>::nch;
-	__shared__ float4 g2p[kG2PNodes];// node velocities {vx,vy,vz,-} of arena nodes 1..6 per axis
-	__shared__ float4 p2g[kArenaNodes];// {mass, momentum} accumulators
-	__shared__ int s_sorted[kSortChunk];// advection records of the current chunk (sorted by prepare_blocks_kernel)
-	__shared__ unsigned char s_owner[216];
-	__shared__ int s_src_binoff[27], s_dst_no[27], s_nb[8];
-
-	const int lane = threadIdx.x;
-	// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Consecutive block numbers are spatial
-	// neighbours (they share grid blocks: reads in the set-up, atomics in the write-back), so every XCD gets one contiguous
-	// eighth of the block range instead of every eighth block.
-	const int nwg = (int) gridDim.x, xcd = (int) (blockIdx.x & 7u), q = (int) (blockIdx.x >> 3);
-	const int bid = xcd * (nwg >> 3) + min(xcd, nwg & 7) + q;// XCD r owns (nwg / 8) + (r < nwg % 8) consecutive numbers
-	const int b	  = block_list ? block_list[bid] : bid;
-	// The per-block set-up is three waves of independent loads (a chain of ~8 dependent round trips of 2-4 us each would
-	// be a third of the kernel); sorting the records and the table look-ups happened in prepare_blocks_kernel.
-	// ---- round trip 1: everything addressed by the block number alone (scalar loads)
-	const int size		 = mv.size[b];
-	const int kx = cur_keys[3 * b], ky = cur_keys[3 * b + 1], kz = cur_keys[3 * b + 2];
-	const int row		 = mv.row_of[b];
-	const int binoff_dst = mv.binoff_dst[b];
-	if(size == 0) return;// (:692-697)
-	unsigned long long t_acc[20] = {};// [9] iterations whose lanes all won the claim, [10] iterations with losers, [11] mispredicted keys
-	unsigned long long t_last	= 0;
-	if constexpr(ABL & 32) t_last = __builtin_readcyclecounter();
-	__asm__ volatile("" ::"s"(row), "s"(binoff_dst), "s"(kz));
-	MPM_TICK(12)
-	const int* list		 = mv.list_in + (size_t) row * cfg.ppb;
-	const float dx_inv	 = cfg.dx_inv;
-	const float scale	 = 4.f * cfg.dx_inv;// dx * D^-1 (settings.h:66): A is accumulated in cell units
-	const float mass	 = mv.mc.mass;
-	const int key_shift = cfg.pid_bits;
-	const int tag_shift = cfg.pid_bits + kKeyBits;
-	// ---- round trip 2: the first chunk's (sorted) advection records and the block's row of look-up results
-	auto load_records = [&](int chunk0) {
-		const int last = min(kSortChunk, size - chunk0) - 1;
-		int recs[kSortChunk / 64];
-#pragma unroll
-		for(int it = 0; it < kSortChunk / 64; ++it) recs[it] = list[chunk0 + min(it * 64 + lane, last)];
-#pragma unroll
-		for(int it = 0; it < kSortChunk / 64; ++it) s_sorted[it * 64 + lane] = recs[it];
-	};
-	const int info = mv.blockinfo[(size_t) b * kInfoRow + lane];
-	load_records(0);
-	if(lane < 27) s_src_binoff[lane] = info;
-	else if(lane < 54) s_dst_no[lane - 27] = info;
-	else if(lane < 62) s_nb[lane - 54] = info;
-	for(int i = lane; i < kArenaNodes; i += 64) p2g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-	__syncthreads();
-	MPM_TICK(13)
-	// ---- round trip 3: the 8 grid blocks (lane = cell -> 256-B rows per channel, :699-727) and - below, at the top of the
-	//      chunk loop - the first 64 particles
-	const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;// lane == cell of a 4x4x4 block
-	float4 gv[8];
-#pragma unroll
-	for(int lb = 0; lb < 8; ++lb) {
-		const int nb	= s_nb[lb];
-		const float* gb = grid + (size_t) (nb < 0 ? 0 : nb) * 256;
-		gv[lb].x		= gb[64 + lane];
-		gv[lb].y		= gb[128 + lane];
-		gv[lb].z		= gb[192 + lane];
-		gv[lb].w		= 0.f;
-		if(nb < 0) gv[lb].x = gv[lb].y = gv[lb].z = 0.f;
-	}
-	MPM_TICK(6)
-	// Software prefetch: the particle data of iteration i+1 is requested at the top of iteration i (HBM latency under
-	// load is 2-4 us and only two waves share a SIMD).  Two details keep the compiler's s_waitcnt insertion from
-	// turning this into a wait for everything (it only counts memory operations that are issued unconditionally):
-	// the loads are unconditional - lanes past the end of the chunk re-read its last record - and the wait for the
-	// data is forced at the END of iteration i (`touch`), in the same straight-line code as the 13 particle stores,
-	// where it is an exact `vmcnt(13)`; at the loop header it would be `vmcnt(0)`, i.e. include the stores'
-	// acknowledgements and the list-append atomics.
-	struct Prefetch {
-		float pos[3], st[10];
-		int key;// the stencil base this particle was predicted to have after this step (its sort key)
-	};
-	int nrec   = min(kSortChunk, size);
-	auto fetch = [&](int idx0, Prefetch& f) {
-		const int rec	 = s_sorted[min(idx0 + lane, nrec - 1)];
-		const int tag	 = rec >> tag_shift;
-		const int sp	 = rec & (cfg.ppb - 1);
-		const int sbin	 = s_src_binoff[tag] + (sp >> 6);
-		const float* src = mv.bins_src + (size_t) sbin * (NCH * kBin) + (sp & 63);
-		f.key			 = (rec >> key_shift) & 255;
-		f.pos[0]		 = src[0];
-		f.pos[1]		 = src[kBin];
-		f.pos[2]		 = src[2 * kBin];
-		if constexpr(MAT == 0) {
-			f.st[0] = src[3 * kBin];
-		} else {
-#pragma unroll
-			for(int d = 0; d < 9; ++d) f.st[d] = src[(3 + d) * kBin];
-			if constexpr(NCH == 13) f.st[9] = src[12 * kBin];
-		}
-	};
-	auto touch = [&](Prefetch& f) {
-#pragma unroll
-		for(int d = 0; d < 3; ++d) __asm__ volatile("" : "+v"(f.pos[d]));
-#pragma unroll
-		for(int d = 0; d < (MAT == 0 ? 1 : (NCH == 13 ? 10 : 9)); ++d) __asm__ volatile("" : "+v"(f.st[d]));
-	};
-	Prefetch pf;
-	fetch(0, pf);// the first 64 particles are in flight while the grid blocks requested above go to LDS
-#pragma unroll
-	for(int lb = 0; lb < 8; ++lb) {
-		const int ax = cx + ((lb & 4) ? 4 : 0) - 1, ay = cy + ((lb & 2) ? 4 : 0) - 1, az = cz + ((lb & 1) ? 4 : 0) - 1;
-		if(((unsigned) ax < 6u) & ((unsigned) ay < 6u) & ((unsigned) az < 6u)) g2p[ax * kG2PStrideX + ay * 8 + az] = gv[lb];
-	}
-	__syncthreads();
-	MPM_TICK(17)
-	for(int chunk0 = 0;;) {
-		touch(pf);
-		MPM_TICK(1)
-		// Software pipeline: the scatter of iteration i-1 (an ordered chain of 27 LDS round trips) is issued inside
-		// the gather of iteration i; `pv` is the payload in flight.
-		P2GPayload pv;
-		int pv_key = 0, pv_off = 0;
-		bool pv_in = false, have_prev = false;
-		for(int idx0 = 0; idx0 < nrec; idx0 += 64) {
-			MPM_MARK("loop_top");
-			const bool active = idx0 + lane < nrec;
-			const int pidib	  = chunk0 + idx0 + lane;// slot in the destination bins == position in the sorted order
-			// ---- advection record -> source bin (:747-768): data was requested one iteration ago
-			float pos[3] = {pf.pos[0], pf.pos[1], pf.pos[2]};
-			float st[10];// J, or F[9] (+ logJp)
-#pragma unroll
-			for(int d = 0; d < 10; ++d) st[d] = pf.st[d];
-			const int predicted_key = pf.key;
-			if constexpr(ABL & 32) {
-#pragma unroll
-				for(int d = 0; d < 10; ++d) __asm__ volatile("" ::"v"(st[d]));
-#pragma unroll
-				for(int d = 0; d < 3; ++d) __asm__ volatile("" ::"v"(pos[d]));
-				t_acc[8] += 1;
-			}
-			MPM_TICK(1)
-			fetch(idx0 + 64, pf);
-			// ---- stencil base + weights (:774-797) for ALL lanes (idle lanes of a last partial iteration carry a dummy
-			//      position inside the block); offsets in cell units (exact: dx is a power of two)
-			int base[3], arena[3];
-			float fd[3], w[3][3];
-#pragma unroll
-			for(int d = 0; d < 3; ++d) {
-				const float p = pos[d] * dx_inv;
-				base[d]		  = lround_pos(p) - 1;
-				fd[d]		  = p - (float) base[d];
-				bspline_weight_cells(fd[d], w[d]);
-				arena[d] = ((base[d] - 1) & 3) + 1;
-			}
-			float vel[3] = {0.f, 0.f, 0.f};
-			float A[9]	 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-			const float4* gbase = g2p + (arena[0] - 1) * kG2PStrideX + (arena[1] - 1) * 8 + (arena[2] - 1);
-			MPM_MARK("claim");
-			// ---- claim the stencil bases of the payload in flight: lanes whose base is unique in the wave (`win`) scatter
-			//      in the chain threaded through this iteration's arithmetic, the others afterwards
-			bool win = false;
-			if constexpr(!(ABL & 1)) {
-				if(have_prev) {
-					// one LDS round trip: the workgroup is a single wave, whose LDS operations execute in order, so the read
-					// below sees the write above without waiting for it in between
-					if(pv_in) s_owner[pv_key] = (unsigned char) lane;
-					__asm__ volatile("" ::: "memory");// another lane may have written the same byte: no store-to-load forwarding
-					win = pv_in && (int) s_owner[pv_key] == lane;
-					if constexpr(ABL & 32) {
-						if(__all(win || !pv_in)) t_acc[9] += 1;
-						else t_acc[10] += 1;
-					}
-				}
-			}
-			MPM_MARK("gather");
-			MPM_TICK(2)
-			constexpr int kPreSites = kGatherSites + 3, kStressSites = MAT == 0 ? 1 : (MAT == 1 ? kFcSites : (MAT == 2 ? kSandSites : kNaccSites));
-			constexpr int kSites	= kPreSites + kStressSites + 1;
-			ScatterChain<kSites> chain(p2g + pv_off, pv, mass, win);
-			if constexpr(ABL & 4) {
-				chain.template range<0, kGatherSites>();
-				const float4 v = gbase[0];
-				vel[0] = v.x * w[0][0]; vel[1] = v.y * w[1][1]; vel[2] = v.z * w[2][2];
-				A[0] = v.x * fd[0]; A[4] = v.y * fd[1]; A[8] = v.z * fd[2];
-			} else {
-				gather_apic<0>(gbase, w, fd, vel, A, chain);
-			}
-			if constexpr(ABL & 32) {
-#pragma unroll
-				for(int d = 0; d < 9; ++d) __asm__ volatile("" ::"v"(A[d]));
-			}
-			MPM_TICK(3)
-			MPM_MARK("rebucket");
-			P2GPayload pl;
-			// Every lane runs the whole body: the idle lanes of a last partial iteration carry a dummy particle and write
-			// it into the padding slots of the block's last bin (slot == pidib < 64 * ceil(size / 64), allocated but never
-			// read).  Keeping the 13 stores out of divergent control flow matters: the wait for the NEXT iteration's
-			// prefetched data at the loop back-edge is then `vmcnt(13)` instead of `vmcnt(0)` (the compiler can only count
-			// unconditional operations), i.e. it no longer includes the store acknowledgements.
-			// ---- advect (:838)
-#pragma unroll
-			for(int d = 0; d < 3; ++d) pos[d] += vel[d] * dt;
-			// ---- new base, re-bucket (:852-866, add_advection particle_buffer.cuh:100-135).  The list-append atomics are
-			//      issued BEFORE the stress computation, which hides their round trip to L2 (~3 k cycles).
-			int nbase[3], narena[3], dirv[3];
-			bool in_arena = active;
-#pragma unroll
-			for(int d = 0; d < 3; ++d) {
-				const float p = pos[d] * dx_inv;
-				nbase[d]	  = lround_pos(p) - 1;
-				pl.fd[d]	  = p - (float) nbase[d];
-				pl.mv[d]	  = mass * vel[d];
-				dirv[d]		  = ((base[d] - 1) >> 2) - ((nbase[d] - 1) >> 2);
-				narena[d]	  = arena[d] + (nbase[d] - base[d]);
-				in_arena &= (narena[d] >= 0) & (narena[d] + 2 < 8);
-			}
-			chain.template at<kGatherSites + 0>();
-			const int key	  = narena[0] * 36 + narena[1] * 6 + narena[2];
-			const int nodeoff = narena[0] * kArenaStrideX + narena[1] * 8 + narena[2];
-			if constexpr(ABL & 32) t_acc[11] += __popcll(__ballot(in_arena && key != predicted_key));
-			const bool dir_ok = ((unsigned) (dirv[0] + 1) < 3u) & ((unsigned) (dirv[1] + 1) < 3u) & ((unsigned) (dirv[2] + 1) < 3u);
-			const int ntag	  = dir_ok ? (dirv[0] + 1) * 9 + (dirv[1] + 1) * 3 + dirv[2] + 1 : kStay;
-			const int dno	  = (active && dir_ok) ? s_dst_no[ntag] : -1;
-			// sort key for the NEXT step: predicted stencil base after one more advection with the current velocity,
-			// expressed in the arena of the block the particle is in after THIS step (clamped to the 6^3 range)
-			int pkey = 0;
-#pragma unroll
-			for(int d = 0; d < 3; ++d) {
-				const int pb = (int) __builtin_rintf((pos[d] + vel[d] * new_dt) * dx_inv) - 1;// a prediction: ties do not matter
-				const int nk = min(max(((nbase[d] - 1) & 3) + 1 + (pb - nbase[d]), 0), 5);
-				pkey		 = pkey * 6 + nk;
-			}
-			chain.template at<kGatherSites + 1>();
-			const int rec	= (ntag << tag_shift) | (pkey << key_shift) | pidib;
-			const bool stay = dno >= 0 && ntag == kStay;
-			// particles that stay in this block share one wave-aggregated atomic
-			const unsigned long long stay_m = __ballot(stay);
-			const int stay_leader			= stay_m ? __ffsll((long long) stay_m) - 1 : 0;
-			const int stay_rank				= __popcll(stay_m & ((1ull << lane) - 1ull));
-			int raw_stay = 0, raw_move = 0;
-			int b_opaque = b;
-			__asm__("" : "+v"(b_opaque));// hide the uniform address: the compiler's atomic optimiser would broadcast the
-										 // result with v_readfirstlane right here, i.e. wait for the round trip
-			if(stay_m != 0ull && lane == stay_leader) raw_stay = atomicAdd(&mv.out_count[b_opaque], __popcll(stay_m));
-			if(dno >= 0 && !stay) raw_move = atomicAdd(&mv.out_count[dno], 1);
-			if(active) {
-				if(dno < 0) atomicAdd(&status[ST_LOST], 1);// reference: particle silently lost (particle_buffer.cuh:105-113)
-				if(!in_arena) atomicAdd(&status[ST_ARENA], 1);// (:877-885) contribution discarded
-			}
-			MPM_MARK("stress");
-			// ---- material update, store to the destination bin (coalesced: slot == pidib) (:470-663)
-			float* dst = mv.bins_dst + (size_t) (binoff_dst + (pidib >> 6)) * (NCH * kBin) + (pidib & 63);
-			dst[0]		  = pos[0];
-			dst[kBin]	  = pos[1];
-			dst[2 * kBin] = pos[2];
-			if constexpr(MAT == 0) {
-				float Aw[9];
-#pragma unroll
-				for(int d = 0; d < 9; ++d) Aw[d] = A[d] * cfg.dx;
-				chain.template at<kGatherSites + 2>();
-				const float J = stress_jfluid(mv.mc, st[0], Aw, dt, cfg.d_inv, pl.contrib);
-				chain.template at<kPreSites>();
-				dst[3 * kBin] = J;
-			} else {
-				float dws[9], Fold[9], F[9];
-#pragma unroll
-				for(int d = 0; d < 9; ++d) {
-					dws[d]	= (A[d] * dt) * scale + ((d & 0x3) != 0 ? 0.f : 1.f);
-					Fold[d] = st[d];
-				}
-				matmul3(dws, Fold, F);
-				chain.template at<kGatherSites + 2>();
-				if constexpr(ABL & 2) {
-#pragma unroll
-					for(int d = 0; d < 9; ++d) pl.contrib[d] = F[d] * mv.mc.mu;
-					if constexpr(NCH == 13) dst[12 * kBin] = st[9];
-					chain.template range<kPreSites, kPreSites + kStressSites>();
-				} else if constexpr(MAT == 1) {
-					stress_fixed_corotated<kPreSites>(mv.mc, F, pl.contrib, chain);
-				} else if constexpr(MAT == 2) {
-					float lj = st[9];
-					stress_sand<kPreSites>(mv.mc, F, lj, pl.contrib, chain, dst + 3 * kBin, kBin);
-					dst[12 * kBin] = lj;
-				} else {
-					float lj = st[9];
-					stress_nacc<kPreSites>(mv.mc, F, lj, pl.contrib, chain);
-					dst[12 * kBin] = lj;
-				}
-				if constexpr(MAT != 2 || (ABL & 2)) {
-#pragma unroll
-					for(int d = 0; d < 9; ++d) dst[(3 + d) * kBin] = F[d];
-				}
-			}
-			MPM_MARK("tail");
-			// (:850) contrib = (A m - contrib new_dt) D^-1, pre-multiplied by dx so that P2G can stay in cell units
-			{
-				const float am = mass * cfg.dx * cfg.dx * cfg.d_inv;
-				const float cs = new_dt * cfg.d_inv * cfg.dx;
-#pragma unroll
-				for(int d = 0; d < 9; ++d) pl.contrib[d] = A[d] * am - pl.contrib[d] * cs;
-			}
-			chain.template at<kSites - 1>();
-			// ---- the lanes that lost the claim scatter now (rare: a partial or overflowing sort round)
-			if constexpr(!(ABL & 1)) {
-				if(have_prev) {
-					const bool lost = pv_in && !win;
-					if(__any(lost)) p2g_resolve(p2g, s_owner, lost, pv_key, pv_off, pv, mass, lane);
-				}
-			}
-			if constexpr(ABL & 32) {
-#pragma unroll
-				for(int d = 0; d < 9; ++d) __asm__ volatile("" ::"v"(pl.contrib[d]));
-			}
-			MPM_TICK(4)
-			// ---- list append: the atomics' results are in by now
-			{
-				const int basev = __shfl(raw_stay, stay_leader);
-				if(dno >= 0) {
-					const int slot = stay ? basev + stay_rank : raw_move;
-					if(slot >= cfg.ppb)
-						atomicOr(&status[ST_OVERFLOW], 2);// reference drops beyond 128 per cell (:122-130)
-					else
-						mv.list_out[(size_t) dno * cfg.ppb + slot] = rec;
-				}
-			}
-			MPM_MARK("loop_end");
-			touch(pf);// the next iteration's particle data must have arrived by now
-			MPM_TICK(5)
-			// ---- hand the payload to the next iteration, whose arithmetic its scatter chain is threaded through (:887-905)
-			if constexpr(ABL & 1) {
-#pragma unroll
-				for(int d = 0; d < 9; ++d) __asm__ volatile("" ::"v"(pl.contrib[d]));
-#pragma unroll
-				for(int d = 0; d < 3; ++d) __asm__ volatile("" ::"v"(pl.fd[d]), "v"(pl.mv[d]));
-				__asm__ volatile("" ::"v"(key), "v"(nodeoff));
-			}
-			pv		  = pl;
-			pv_key	  = in_arena ? key : 0;
-			pv_off	  = in_arena ? nodeoff : 0;
-			pv_in	  = in_arena;
-			have_prev = true;
-		}
-		// drain the pipeline: scatter of the chunk's last iteration
-		if constexpr(!(ABL & 1)) {
-			if(have_prev) p2g_resolve(p2g, s_owner, pv_in, pv_key, pv_off, pv, mass, lane);
-		}
-		__syncthreads();
-		MPM_TICK(3)
-		chunk0 += kSortChunk;
-		if(chunk0 >= size) break;
-		load_records(chunk0);
-		__syncthreads();
-		nrec = min(kSortChunk, size - chunk0);
-		fetch(0, pf);
-		MPM_TICK(0)
-	}
-	// ---- arena -> next grid: one hardware f32 atomic per touched node, 256-B rows (:907-936)
-#pragma unroll
-	for(int lb = 0; lb < 8; ++lb) {
-		const int nb   = s_nb[lb];
-		const float4 v = p2g[(cx + ((lb & 4) ? 4 : 0)) * kArenaStrideX + (cy + ((lb & 2) ? 4 : 0)) * 8 + (cz + ((lb & 1) ? 4 : 0))];
-		if(nb >= 0) {
-			float* g = next_grid + (size_t) nb * 256 + lane;
-			if(v.x != 0.f) unsafeAtomicAdd(g, v.x);
-			if(v.y != 0.f) unsafeAtomicAdd(g + 64, v.y);
-			if(v.z != 0.f) unsafeAtomicAdd(g + 128, v.z);
-			if(v.w != 0.f) unsafeAtomicAdd(g + 192, v.w);
-		}
-	}
-	if constexpr(ABL & 32) {
-		__asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		MPM_TICK(7)
-		if(lane == 0) {
-#pragma unroll
-			for(int i = 0; i < 20; ++i) atomicAdd(&g_prof[blockIdx.x & 1023][i], t_acc[i]);
-		}
-	}
-}
+}// namespace mpm
+#include "mpm_g2p2g.hpp"
+namespace mpm {
 
 // ------------------------------------------------------------------------------------------------------
 // Partition rebuild
@@ -1195,7 +551,7 @@ __global__ __launch_bounds__(256) void fill_bins_kernel(GridCfg cfg, int nch, fl
 			if(nch == 13) dst[12 * kBin] = log_jp0;
 		}
 		const int cx = node_index(xyz[3 * (size_t) pid], cfg.dx_inv) - 2, cy = node_index(xyz[3 * (size_t) pid + 1], cfg.dx_inv) - 2, cz = node_index(xyz[3 * (size_t) pid + 2], cfg.dx_inv) - 2;
-		const int key = (((cx & 3) + 1) * 6 + ((cy & 3) + 1)) * 6 + ((cz & 3) + 1);// stencil base in the block's arena (no motion predicted)
+		const int key = (((cy & 3) + 1) * 6 + ((cx & 3) + 1)) * 6 + ((cz & 3) + 1);// stencil base in the block's node cube, y slowest (mpm_g2p2g.hpp); no motion predicted
 		list_in[(size_t) b * cfg.ppb + pidib] = (kStay << (cfg.pid_bits + kKeyBits)) | (key << cfg.pid_bits) | pidib;
 	}
 }
