@@ -24,7 +24,7 @@
 namespace mpm {
 
 #ifndef MPM_G2P2G_WAVES
-#define MPM_G2P2G_WAVES 3// waves per SIMD the register allocation is held to
+#define MPM_G2P2G_WAVES 4// waves per SIMD the register allocation is held to
 #endif
 
 // LDS arenas: nodes 1..6 per axis of the 8^3 cube spanned by the block's 2x2x2 grid blocks.
@@ -133,6 +133,12 @@ MPM_DEV void gather_apic(const float4* __restrict__ gbase, const float (&w)[3][3
 	A[6]   = A6_xy.x;
 	A[7]   = A6_xy.y;
 	A[8]   = A8;
+	// A is first used in the material update, far below: pin the results here, or the compiler sinks two thirds of the
+	// accumulation down to that use and keeps the x / y / z components of all 27 loaded nodes alive until then (81 VGPRs)
+#pragma unroll
+	for(int d = 0; d < 9; ++d) __asm__ volatile("" : "+v"(A[d]));
+#pragma unroll
+	for(int d = 0; d < 3; ++d) __asm__ volatile("" : "+v"(vel[d]));
 }
 
 // Scatter one particle per active lane into the LDS arena (float4 {mass, px, py, pz} per node) WITHOUT atomics:
@@ -218,6 +224,106 @@ MPM_DEV void p2g_shell(const P2GPayload& pl, float mass, bool act, int nx, int n
 	}
 }
 
+// The P2G scatter of one particle per lane as a chain of 27 ordered LDS read-modify-write steps that is threaded through
+// unrelated register-only arithmetic: the NEXT particle's F update, eigen-decomposition and material model, a latency-
+// bound dependent VALU stream itself (a dependent VALU instruction issues every ~9 cycles).  Each step is an LDS round
+// trip and the steps cannot overlap each other - step o+1 may hit the node another lane wrote in step o - so issued back
+// to back they leave the wave waiting 27 times.  Site s of NSITES completes steps [27 s / NSITES, 27 (s+1) / NSITES): the
+// accumulator of the following step is requested right after a step's write and consumed at the next site.  Only lanes
+// with `win` (pairwise distinct stencil bases, no shell nodes) take part; the others go through p2g_resolve.
+template<int NSITES>
+struct ScatterChain {
+	float4* node0;
+	P2GPayload pp;// element-wise copy: a reference member or a struct copy keeps the payload in scratch memory
+	float mass;
+	int win;// (int, not bool: a 1-byte member makes the compiler slice its neighbours into bytes)
+	float pw[3][3];
+	float b0, wij;
+	v2f_ b12, c12;
+	float4 acc;
+	MPM_DEV ScatterChain(float4* n0, const P2GPayload& p, float m, bool w)
+		: node0(n0)
+		, mass(m)
+		, win(w) {
+#pragma unroll
+		for(int d = 0; d < 3; ++d) {
+			pp.fd[d] = p.fd[d];
+			pp.mv[d] = p.mv[d];
+		}
+#pragma unroll
+		for(int d = 0; d < 9; ++d) pp.contrib[d] = p.contrib[d];
+#pragma unroll
+		for(int d = 0; d < 3; ++d) bspline_weight_cells(pp.fd[d], pw[d]);
+		c12 = (v2f_) {pp.contrib[7], pp.contrib[8]};
+		if(win) acc = node0[0];
+	}
+	MPM_DEV void step(int o) {// o is a compile-time constant after unrolling
+		const int i = o / 9, j = (o / 3) % 3, k = o % 3;
+		if(k == 0) {
+			const float px = (float) i - pp.fd[0], py = (float) j - pp.fd[1];
+			b0	= pp.mv[0] + pp.contrib[0] * px + pp.contrib[3] * py;
+			b12 = (v2f_) {pp.mv[1] + pp.contrib[1] * px + pp.contrib[4] * py, pp.mv[2] + pp.contrib[2] * px + pp.contrib[5] * py};
+			wij = pw[0][i] * pw[1][j];
+		}
+		const float pz = (float) k - pp.fd[2];
+		const float W  = wij * pw[2][k];
+		const v2f_ m0  = {mass, b0 + pp.contrib[6] * pz};
+		const v2f_ t12 = c12 * pz + b12;
+		if(win) {
+			v2f_ a01 = {acc.x, acc.y};
+			v2f_ a23 = {acc.z, acc.w};
+			a01		 = m0 * W + a01;
+			a23		 = t12 * W + a23;
+			node0[i * kP2GStrideX + j * kP2GStrideY + k] = make_float4(a01.x, a01.y, a23.x, a23.y);
+			__asm__ volatile("" ::: "memory");
+			if(o + 1 < 27) {
+				const int i1 = (o + 1) / 9, j1 = ((o + 1) / 3) % 3, k1 = (o + 1) % 3;
+				acc			 = node0[i1 * kP2GStrideX + j1 * kP2GStrideY + k1];
+			}
+		}
+	}
+	template<int SITE>
+	MPM_DEV void at() {
+		static_assert(SITE >= 0 && SITE < NSITES, "site out of range");
+#pragma unroll
+		for(int o = SITE * 27 / NSITES; o < (SITE + 1) * 27 / NSITES; ++o) step(o);
+	}
+};
+
+// packed stencil base in the node cube (x | y << 4 | z << 8), -1 = outside (contribution discarded, :877-885)
+MPM_DEV int code_key(int c) {
+	return ((c >> 4) & 15) * 36 + (c & 15) * 6 + (c >> 8);
+}
+MPM_DEV bool code_edge(int c) {
+	const int x = c & 15, y = (c >> 4) & 15, z = c >> 8;
+	return (x == 0) | (x == 5) | (y == 0) | (y == 5) | (z == 0) | (z == 5);
+}
+MPM_DEV int code_off(int c) {
+	return ((c & 15) - 1) * kP2GStrideX + (((c >> 4) & 15) - 1) * kP2GStrideY + ((c >> 8) - 1);
+}
+
+// Scatter the lanes in `pending` (their payloads are final): lanes whose stencil base is unique among the pending ones
+// (LDS owner table) go first, the others retry; shell nodes of edge lanes go to the grid directly.
+MPM_DEV void p2g_resolve(float4* __restrict__ arena, unsigned char* __restrict__ owner, bool pending, int code, P2GPayload& pl, float mass, int lane, const int* __restrict__ s_nb, float* __restrict__ next_grid) {
+	const int okey	= code >= 0 ? code_key(code) : 0;
+	const bool edge = code_edge(code);
+	const int nx = code & 15, ny = (code >> 4) & 15, nz = code >> 8;
+	if(__any(pending && edge)) p2g_shell(pl, mass, pending && edge, nx, ny, nz, s_nb, next_grid);
+	while(__any(pending)) {
+		// one LDS round trip: the workgroup is a single wave, whose LDS operations execute in order, so the read below sees
+		// the writes above without waiting for them in between
+		if(pending) owner[okey] = (unsigned char) lane;
+		__asm__ volatile("" ::: "memory");// another lane may have written the same byte: no store-to-load forwarding
+		const bool win = pending && (int) owner[okey] == lane;
+		// the payload arithmetic of the 27 steps is invariant in this retry loop: keep the compiler from hoisting it
+#pragma unroll
+		for(int d = 0; d < 3; ++d) __asm__ volatile("" : "+v"(pl.fd[d]));
+		if(__any(win && edge)) p2g_scatter<true>(arena, pl, mass, win, nx, ny, nz);
+		else p2g_scatter<false>(arena, pl, mass, win, nx, ny, nz);
+		pending = pending && !win;
+	}
+}
+
 template<int MAT>
 __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_keys, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, float dt, float new_dt, int* __restrict__ status) {
 	constexpr int NCH = MatTraits<MAT>::nch;
@@ -299,7 +405,19 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 		if(((unsigned) ax < 6u) & ((unsigned) ay < 6u) & ((unsigned) az < 6u)) g2p[ay * kG2PStrideY + ax * kG2PStrideX2 + az] = gv[lb];
 	}
 	__syncthreads();
-	for(int idx0 = 0; idx0 < size; idx0 += 64) {
+	// Software pipeline: the scatter of iteration i-1 (an ordered chain of 27 LDS round trips) is issued inside the material
+	// update of iteration i; `pv` is the payload in flight, pv_code its stencil base (-1: none).
+	P2GPayload pv;
+	int pv_code = -1;
+	for(int idx0 = 0;; idx0 += 64) {
+		// one pass more than there are iterations: the last one only drains the pipeline (scatter of the last payload)
+		const bool drain = idx0 >= size;
+		bool win		 = false;
+		const bool pv_in = pv_code >= 0;
+		P2GPayload pl;
+		bool in_arena = false;
+		int ncode	  = -1;
+		if(!drain) {
 		const bool active = idx0 + lane < size;
 		const int pidib	  = idx0 + lane;// slot in the destination bins == position in the sorted order
 		// ---- advection record -> source bin (:747-768): data was requested one iteration ago
@@ -324,7 +442,6 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 			}
 			gather_apic(g2p + (arena[1] - 1) * kG2PStrideY + (arena[0] - 1) * kG2PStrideX2 + (arena[2] - 1), w, fd, vel, A);
 		}
-		P2GPayload pl;
 		// Every lane runs the whole body: the idle lanes of a last partial iteration carry a dummy particle and write it into
 		// the padding slots of the block's last bin (slot == pidib < 64 * ceil(size / 64), allocated but never read), which
 		// keeps the 13 stores out of divergent control flow (countable for s_waitcnt).
@@ -334,7 +451,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 		// ---- new base, re-bucket (:852-866, add_advection particle_buffer.cuh:100-135).  The list-append atomics are
 		//      issued BEFORE the stress computation, which hides their round trip to L2.
 		int nbase[3], narena[3], dirv[3];
-		bool in_arena = active;
+		in_arena = active;
 #pragma unroll
 		for(int d = 0; d < 3; ++d) {
 			const float p = pos[d] * dx_inv;
@@ -345,7 +462,6 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 			narena[d]	  = arena[d] + (nbase[d] - base[d]);
 			in_arena &= (narena[d] >= 0) & (narena[d] <= 5);
 		}
-		const int key	  = narena[1] * 36 + narena[0] * 6 + narena[2];
 		const bool dir_ok = ((unsigned) (dirv[0] + 1) < 3u) & ((unsigned) (dirv[1] + 1) < 3u) & ((unsigned) (dirv[2] + 1) < 3u);
 		const int ntag	  = dir_ok ? (dirv[0] + 1) * 9 + (dirv[1] + 1) * 3 + dirv[2] + 1 : kStay;
 		const int dno	  = (active && dir_ok) ? s_dst_no[ntag] : -1;
@@ -374,6 +490,15 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 			if(dno < 0) atomicAdd(&status[ST_LOST], 1);// reference: particle silently lost (particle_buffer.cuh:105-113)
 			if(!in_arena) atomicAdd(&status[ST_ARENA], 1);// (:877-885) contribution discarded
 		}
+		// ---- claim the stencil bases of the payload in flight: lanes whose base is unique in the wave (`win`) scatter in the
+		//      chain threaded through this iteration's material update, the others (and the edge lanes) afterwards
+		constexpr int kStressSites = MAT == 0 ? 1 : (MAT == 1 ? kFcSites : (MAT == 2 ? kSandSites : kNaccSites));
+		constexpr int kSites	   = kStressSites + 2;
+		const int pv_key = pv_in ? code_key(pv_code) : 0;
+		if(pv_in) s_owner[pv_key] = (unsigned char) lane;
+		__asm__ volatile("" ::: "memory");// another lane may have written the same byte: no store-to-load forwarding
+		win = pv_in && !code_edge(pv_code) && (int) s_owner[pv_key] == lane;
+		ScatterChain<kSites> chain(p2g + (win ? code_off(pv_code) : 0), pv, mass, win);
 		// ---- material update, store to the destination bin (coalesced: slot == pidib) (:470-663)
 		float* dst = mv.bins_dst + (size_t) (binoff_dst + (pidib >> 6)) * (NCH * kBin) + (pidib & 63);
 		dst[0]		  = pos[0];
@@ -383,7 +508,9 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 			float Aw[9];
 #pragma unroll
 			for(int d = 0; d < 9; ++d) Aw[d] = A[d] * cfg.dx;
+			chain.template at<0>();
 			const float J = stress_jfluid(mv.mc, st[0], Aw, dt, cfg.d_inv, pl.contrib);
+			chain.template at<1>();
 			dst[3 * kBin] = J;
 		} else {
 			float dws[9], Fold[9], F[9];
@@ -393,18 +520,18 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 				Fold[d] = st[d];
 			}
 			matmul3(dws, Fold, F);
-			NoHook nh;
+			chain.template at<0>();
 			if constexpr(MAT == 1) {
-				stress_fixed_corotated<0>(mv.mc, F, pl.contrib, nh);
+				stress_fixed_corotated<1>(mv.mc, F, pl.contrib, chain);
 #pragma unroll
 				for(int d = 0; d < 9; ++d) dst[(3 + d) * kBin] = F[d];
 			} else if constexpr(MAT == 2) {
 				float lj = st[9];
-				stress_sand<0>(mv.mc, F, lj, pl.contrib, nh, dst + 3 * kBin, kBin);
+				stress_sand<1>(mv.mc, F, lj, pl.contrib, chain, dst + 3 * kBin, kBin);
 				dst[12 * kBin] = lj;
 			} else {
 				float lj = st[9];
-				stress_nacc<0>(mv.mc, F, lj, pl.contrib, nh);
+				stress_nacc<1>(mv.mc, F, lj, pl.contrib, chain);
 #pragma unroll
 				for(int d = 0; d < 9; ++d) dst[(3 + d) * kBin] = F[d];
 				dst[12 * kBin] = lj;
@@ -417,32 +544,12 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 #pragma unroll
 			for(int d = 0; d < 9; ++d) pl.contrib[d] = A[d] * am - pl.contrib[d] * cs;
 		}
-		// ---- the next iteration's particle data is requested here: in flight during the scatter (27 ordered LDS round trips)
-		//      without occupying 14 registers during the gather and the material update
+		chain.template at<kSites - 1>();
+		// ---- the next iteration's particle data is requested here: in flight during the tail of this iteration and the
+		//      gather of the next one, without occupying 14 registers during the material update
 		fetch(rec_next, pf);
 		rec_next = rec_nn;
-		// ---- P2G (:887-905): lanes whose stencil base is unique in the wave scatter; the others retry (rare: a partial or
-		//      overflowing sort round, a mispredicted key)
-		{
-			const bool edge = (narena[0] == 0) | (narena[0] == 5) | (narena[1] == 0) | (narena[1] == 5) | (narena[2] == 0) | (narena[2] == 5);
-			const int okey	= in_arena ? key : 0;
-			bool pending	= in_arena;
-			if(__any(in_arena && edge)) p2g_shell(pl, mass, in_arena && edge, narena[0], narena[1], narena[2], s_nb, next_grid);
-			while(__any(pending)) {
-				// one LDS round trip: the workgroup is a single wave, whose LDS operations execute in order, so the read
-				// below sees the writes above without waiting for them in between
-				if(pending) s_owner[okey] = (unsigned char) lane;
-				__asm__ volatile("" ::: "memory");// another lane may have written the same byte: no store-to-load forwarding
-				const bool win = pending && (int) s_owner[okey] == lane;
-				// the payload arithmetic of the 27 steps is invariant in this retry loop: without this the compiler hoists all of
-				// it out of the loop (135 live values)
-#pragma unroll
-				for(int d = 0; d < 3; ++d) __asm__ volatile("" : "+v"(pl.fd[d]));
-				if(__any(win && edge)) p2g_scatter<true>(p2g, pl, mass, win, narena[0], narena[1], narena[2]);
-				else p2g_scatter<false>(p2g, pl, mass, win, narena[0], narena[1], narena[2]);
-				pending = pending && !win;
-			}
-		}
+		ncode = in_arena ? (narena[0] | (narena[1] << 4) | (narena[2] << 8)) : -1;
 		// ---- list append: the atomics' results are in by now (and with them the next iteration's particle data)
 		{
 			const int basev = __shfl(raw_stay, stay_leader);
@@ -454,6 +561,22 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 					mv.list_out[(size_t) dno * cfg.ppb + slot] = rec;
 			}
 		}
+		}// !drain
+		// ---- the lanes that lost the claim and the edge lanes scatter now (rare); in the draining pass: every lane
+		{
+			const bool left = pv_in && !win;
+			if(__any(left)) p2g_resolve(p2g, s_owner, left, pv_code, pv, mass, lane, s_nb, next_grid);
+		}
+		if(drain) break;
+		// ---- hand the payload to the next iteration (:887-905)
+#pragma unroll
+		for(int d = 0; d < 3; ++d) {
+			pv.fd[d] = pl.fd[d];
+			pv.mv[d] = pl.mv[d];
+		}
+#pragma unroll
+		for(int d = 0; d < 9; ++d) pv.contrib[d] = pl.contrib[d];
+		pv_code = ncode;
 	}
 	__syncthreads();
 	// ---- arena -> next grid: one hardware f32 atomic per touched node and channel (:907-936).  216 nodes, 4 rounds.
