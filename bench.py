@@ -29,7 +29,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 BYTES_PER_PARTICLE = {0: 72, 1: 136, 2: 144, 3: 144}  # BASELINE.md section 4 / SURVEY.md 8(d)
+# SURVEY.md 8(d) "ALGORITHMIC FLOPs (secondary)": the reference formulation (27-node G2P ~1.0 k, P2G ~0.75 k, F update
+# ~0.1 k, SVD ~0.8 k, stress 0.1-0.2 k); this engine executes fewer (tensor-product gather, eigen-decomposition)
+FLOPS_PER_PARTICLE = {0: 1800, 1: 2700, 2: 2700, 3: 2700}
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8 TB/s spec
+FP32_VECTOR_PEAK_TFLOPS = 157.3                        # MI355X_MICROARCH.md: peak FP32 (vector)
 
 
 def make_scene(args):
@@ -43,6 +47,9 @@ def make_scene(args):
     elif args.scene == "spheres50k":
         sc = scenes.two_spheres()
         name = "C1 two elastic spheres, 128^3 grid"
+    elif args.scene == "fluid12m":
+        sc = scenes.fluid_dam(10, (32, 192, 256))
+        name = "C5 per-rank share (1/8): weakly compressible J-fluid slab 32x192x256 cells, 1024^3 sparse grid"
     else:
         raise SystemExit(f"unknown scene {args.scene}")
     return sc, name
@@ -100,7 +107,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)   # warm-up 10 substeps, time the next 100
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--scene", default="sand40m", choices=["sand40m", "sphere5m", "spheres50k"])
+    ap.add_argument("--scene", default="sand40m", choices=["sand40m", "sphere5m", "spheres50k", "fluid12m"])
+    ap.add_argument("--start-step", type=int, default=0,
+                    help="untimed substeps before the warm-up: moves the timed window into the flow (the default window of C3 "
+                         "starts at rest; after ~3000 substeps the column is collapsing: block churn, mispredicted sort keys)")
     ap.add_argument("--fraction", type=float, default=1.0, help="debug: shrink the sand column")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mgsp", action="store_true", help="debug: drive the multi-GPU code path even with one rank")
@@ -139,6 +149,8 @@ def main():
         from claymore_amd.engine import build_engine
         eng = build_engine(sc, device=local_rank)
         eng.initial_setup()
+        if args.start_step:
+            eng.run_fixed(args.start_step, dt)
         eng.run_fixed(args.warmup, dt)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -152,6 +164,17 @@ def main():
         cnt = eng.counts()
         blocks = {"particle": cnt.particle_blocks, "neighbor": cnt.neighbor_blocks, "exterior": cnt.exterior_blocks}
         n_rank = n_total
+        # self-check (gmpm_simulator.cuh:617 prints the particle total; the reference loses particles silently): nothing
+        # was lost, no P2G contribution was discarded, the grid carries the whole mass
+        diag = eng.diagnostics()
+        bucketed = sum(cnt.particles[i] for i in range(cnt.model_count))
+        totals = eng.grid_totals()
+        mass_expected = sum(eng.model_mass(i) * m["xyz"].shape[0] for i, m in enumerate(sc["models"]))
+        check = {"particles_bucketed": int(bucketed), "lost_particles": int(diag.lost_particles),
+                 "discarded_p2g": int(diag.discarded_p2g), "grid_mass_rel_err": abs(totals[0] - mass_expected) / mass_expected}
+        assert bucketed == n_total, check
+        assert diag.lost_particles == 0 and diag.discarded_p2g == 0, check
+        assert check["grid_mass_rel_err"] < 1e-4 and np.isfinite(totals).all(), check
         eng.close()
     else:
         from claymore_amd.mgsp import MgspRank
@@ -172,6 +195,7 @@ def main():
         phases = sim.phase_ms()
         blocks = sim.block_counts()
         n_rank = sim.n_local
+        check = None
         sim.close()
 
     if rank == 0:
@@ -191,6 +215,16 @@ def main():
                          "kernel": "g2p2g_kernel", "bytes_per_particle": bpp, "particles_per_launch": n_rank,
                          "kernel_ms": g2p2g_ms},
         }
+        # the kernel's arithmetic intensity sits at the fp32-vector ridge, so the VALU bound is reported too
+        fpp = FLOPS_PER_PARTICLE[material]
+        tfl = (n_rank * fpp) / (g2p2g_ms * 1e-3) / 1e12 if g2p2g_ms > 0 else 0.0
+        out["roofline"]["valu"] = {"flops_per_particle": fpp, "achieved_tflops": tfl, "peak": FP32_VECTOR_PEAK_TFLOPS,
+                                   "frac": tfl / FP32_VECTOR_PEAK_TFLOPS,
+                                   "note": "algorithmic FLOPs of the reference formulation (SURVEY.md 8d), not executed instructions"}
+        if args.start_step:
+            out["config"]["start_step"] = args.start_step
+        if check is not None:
+            out["config"]["self_check"] = check
         # measured HBM traffic of the same kernel on the same workload (PMC passes are separate runs, see profiles/)
         tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
         if world == 1 and args.scene == "sand40m" and args.fraction >= 1.0 and os.path.exists(tf):

@@ -38,6 +38,11 @@ class Counts(C.Structure):
                 ("model_count", C.c_int), ("bins", C.c_int64 * 8), ("particles", C.c_int64 * 8)]
 
 
+class Diagnostics(C.Structure):
+    _fields_ = [("lost_particles", C.c_int64), ("discarded_p2g", C.c_int64), ("overflow_flags", C.c_int),
+                ("reserved", C.c_int * 5)]
+
+
 class Timers(C.Structure):
     _fields_ = [("grid_update_ms", C.c_float), ("g2p2g_ms", C.c_float), ("partition_ms", C.c_float),
                 ("halo_ms", C.c_float), ("total_ms", C.c_float), ("reserved", C.c_float * 3)]
@@ -94,6 +99,7 @@ HIP_ONLY = {
     "streams": (_i, [_vp, _P(_vp), _P(_vp)]),
     "sync": (_i, [_vp]),
     "get_capacity": (_i, [_vp, _P(C.c_int64), _P(C.c_int64), _ip]),
+    "get_diagnostics": (_i, [_vp, _P(Diagnostics)]),
     "checkpoint_size": (_i, [_vp, _P(_sz)]),
     "checkpoint_save": (_i, [_vp, _vp, _sz, _P(_sz)]),
     "checkpoint_load": (_i, [_vp, _vp, _sz]),

@@ -311,7 +311,7 @@ int mpm_add_model(mpm_ctx* ctx, int material, const mpm_material_params* params,
 	m.material = material;
 	m.p		   = *params;
 	m.mc	   = make_material_const(*params);
-	m.nch	   = material == MPM_J_FLUID ? 4 : (material == MPM_FIXED_COROTATED ? 12 : 13);
+	m.nch	   = material == MPM_J_FLUID ? 4 : (material == MPM_FIXED_COROTATED ? 12 : 16);// floats per particle record (mpm_g2p2g.hpp)
 	m.n		   = n;
 	for(int d = 0; d < 3; ++d) m.v0[d] = v0 ? v0[d] : 0.f;
 	HIP_TRY(dalloc(&m.d_xyz, 3 * n));
@@ -823,6 +823,18 @@ int mpm_get_capacity(mpm_ctx* ctx, int64_t* block_capacity, int64_t* bin_capacit
 	if(bin_capacity)
 		for(size_t i = 0; i < ctx->models.size() && i < 8; ++i) bin_capacity[i] = (int64_t) ctx->models[i].bin_cap;
 	if(growth_events) *growth_events = ctx->capacity_events;
+	return MPM_OK;
+}
+
+int mpm_get_diagnostics(mpm_ctx* ctx, mpm_diagnostics* d) {
+	if(!ctx || !ctx->ready || !d) return MPM_ERR_NOT_READY;
+	memset(d, 0, sizeof(*d));
+	d->lost_particles = ctx->h_status[ST_LOST];
+	d->discarded_p2g  = ctx->h_status[ST_ARENA];
+	d->overflow_flags = ctx->h_status[ST_OVERFLOW];
+#ifdef MPM_G2P2G_STATS
+	for(int i = 0; i < 5; ++i) d->reserved[i] = ctx->h_status[24 + i];// cumulative: iterations, loser lanes, edge lanes, iterations with a retry, idle lanes
+#endif
 	return MPM_OK;
 }
 

@@ -12,7 +12,7 @@
 //     them sorted), and BOTH arenas hold only nodes 1..6 of the 8^3 node cube around the block.  The gather never touches
 //     nodes 0 and 7; the scatter does only for particles that have just crossed into a neighbouring block (a few per cent
 //     in fast flows, none at rest): those lanes send the shell part of their stencil straight to the grid with global
-//     atomics (p2g_scatter<true>);
+//     atomics (p2g_serial);
 //   * the per-particle math needs only U and sigma (sym_eig3 in mpm_device_math.hpp), not a full SVD.
 // One workgroup = ONE wave = one particle block, as before: LDS operations of a single wave execute in order, which
 // is what makes the atomic-free read-modify-write scatter legal (lanes of an iteration hold distinct stencil bases:
@@ -32,11 +32,11 @@ namespace mpm {
 // (bases 1..4 per axis) a 16-lane group then holds one y-plane, which both layouts below serve without bank conflicts
 // beyond the hardware's b128 pass structure (tools/valu_microbench3: 4.0 cycles per ds_read_b128 on the gather arena,
 // 8.8 per read-modify-write instruction on the scatter arena, against 4.0 / 8.3 for a linear address pattern).
-constexpr int kP2GStrideX = 36, kP2GStrideY = 6, kP2GNodes = 216;			 // scatter arena: (x-1)*36 + (y-1)*6 + (z-1)
-constexpr int kG2PStrideY = 52, kG2PStrideX2 = 8, kG2PNodes2 = 6 * 52;	 // gather arena:  (y-1)*52 + (x-1)*8 + (z-1)
+constexpr int kP2GStrideX = 36, kP2GStrideY = 6, kP2GNodes = 216;// scatter arenas (two): (x-1)*36 + (y-1)*6 + (z-1)
+constexpr int kG2PStrideX = 36, kG2PStrideY = 6, kG2PNodes = 216;// gather arena, same dense layout
 
 struct ModelView {
-	const float* bins_src;// [bin][nch][64], laid out by the previous block numbering
+	const float* bins_src;// [bin][64 records][nch floats], laid out by the previous block numbering
 	float* bins_dst;	  // laid out by the current numbering
 	const int* binoff_src;// first bin of a block, previous numbering
 	const int* binoff_dst;// current numbering
@@ -49,6 +49,12 @@ struct ModelView {
 	MaterialConst mc;
 };
 
+// Particle storage: bins of 64 particle RECORDS, a record = {x, y, z, state...} contiguous in memory (16 B for the J-fluid
+// {x, y, z, J}, 48 B fixed-corotated {x, y, z, F[9]}, 64 B sand / NACC {x, y, z, F[9], log Jp, 3 x pad}), moved with 16-byte
+// loads and stores.  The reference's (and round 1's) AoSoA bins [channel][slot] are ideal only while the sorted order of a
+// step equals the order the particles were written in; in a flow the 64 lanes of an iteration read 64 scattered slots, and
+// with one 256-B row per channel that is 13 x ~16 cache lines per wave-load and a 6x HBM read amplification
+// (profiles/r02_moving_window_pmc.txt).  A record is one 64-B sector whatever the permutation.
 template<int MAT>
 struct MatTraits;
 template<>
@@ -61,11 +67,11 @@ struct MatTraits<1> {
 };
 template<>
 struct MatTraits<2> {
-	static constexpr int nch = 13;
+	static constexpr int nch = 16;
 };
 template<>
 struct MatTraits<3> {
-	static constexpr int nch = 13;
+	static constexpr int nch = 16;
 };
 
 // P2G payload of one particle: everything the scatter needs after the material update.
@@ -100,7 +106,7 @@ MPM_DEV void gather_apic(const float4* __restrict__ gbase, const float (&w)[3][3
 			v2f_ t0_xy = {0.f, 0.f}, t1_xy = {0.f, 0.f}, t0z_t1z = {0.f, 0.f};
 #pragma unroll
 			for(int k = 0; k < 3; ++k) {
-				const float4 v = gbase[j * kG2PStrideY + i * kG2PStrideX2 + k];
+				const float4 v = gbase[i * kG2PStrideX + j * kG2PStrideY + k];
 				const v2f_ vxy = {v.x, v.y}, vzz = {v.z, v.w};
 				t0_xy		   = vxy * wz[k].x + t0_xy;
 				t1_xy		   = vxy * wz[k].y + t1_xy;
@@ -141,86 +147,62 @@ MPM_DEV void gather_apic(const float4* __restrict__ gbase, const float (&w)[3][3
 	for(int d = 0; d < 3; ++d) __asm__ volatile("" : "+v"(vel[d]));
 }
 
-// Scatter one particle per active lane into the LDS arena (float4 {mass, px, py, pz} per node) WITHOUT atomics:
-// gfx950 executes ds_add_f32 at one lane per ~3 cycles (193 cycles per wave-instruction, profiles/r01_lds_microbench.txt);
-// a plain ds_read_b128 / 2 v_pk_fma / ds_write_b128 costs 17.  Correctness rests on two facts: (1) the caller only
-// activates lanes with pairwise distinct stencil bases, so for one stencil offset all lanes touch distinct nodes;
-// (2) a workgroup is a single wave, whose LDS operations execute in program order - the compiler barrier keeps the
-// read-modify-write of offset o ahead of the read of offset o+1, which may hit the node another lane just wrote.
-// EDGE: lanes whose stencil reaches cube nodes 0 or 7 (base coordinate 0 or 5) skip those nodes here; p2g_shell sends them
-// straight to the grid.
-template<bool EDGE>
-MPM_DEV void p2g_scatter(float4* __restrict__ arena, const P2GPayload& pl, float mass, bool act, int nx, int ny, int nz) {
-	float w[3][3];
+// P2G of the particles the chain cannot take - lanes that lost the claim of their stencil base (another lane of the
+// iteration holds the same base) and edge lanes, whose stencil reaches cube nodes 0 or 7 (cells of the 2x2x2 grid blocks
+// outside the LDS arena; the particle has just crossed into a neighbouring block).  They are served ONE PARTICLE AT A TIME
+// with the 27 stencil nodes spread over 27 lanes: the particle's payload is broadcast (v_readlane), lane o computes the
+// contribution to node o and adds it - a plain read-modify-write for arena nodes (the 27 nodes of one particle are
+// distinct, and a single wave's LDS operations execute in order), a global float atomic per channel for shell nodes.
+// One LDS round trip per particle whatever the multiplicity of its base, no claim rounds, no second 27-step pass.
+MPM_DEV void p2g_serial(float4* __restrict__ arena, bool pending, int code, const P2GPayload& pl, float mass, int lane, int info, float* __restrict__ next_grid) {
+	__asm__ volatile("" : "+v"(lane));// (recomputed here every time: hoisted out of the main loop these would hold six registers)
+	const int oi = lane / 9, oj = (lane / 3) % 3, ok = lane % 3;// this lane's stencil offset (lanes 0..26)
+	const float fi = (float) oi, fj = (float) oj, fk = (float) ok;
+	unsigned long long todo = __ballot(pending);
+	while(todo) {
+		const int src = __ffsll((long long) todo) - 1;
+		todo &= todo - 1;
+		float fd[3], mvv[3], c[9];
 #pragma unroll
-	for(int d = 0; d < 3; ++d) bspline_weight_cells(pl.fd[d], w[d]);
-	float4* node0 = arena + (nx - 1) * kP2GStrideX + (ny - 1) * kP2GStrideY + (nz - 1);
-	const v2f_ c12 = {pl.contrib[7], pl.contrib[8]};
+		for(int d = 0; d < 3; ++d) {
+			fd[d]  = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pl.fd[d]), src));
+			mvv[d] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pl.mv[d]), src));
+		}
 #pragma unroll
-	for(int i = 0; i < 3; ++i) {
-		const float px = (float) i - pl.fd[0];
+		for(int d = 0; d < 9; ++d) c[d] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pl.contrib[d]), src));
+		const int cd = __builtin_amdgcn_readlane(code, src);
+		const int nx = cd & 15, ny = (cd >> 4) & 15, nz = cd >> 8;
+		float w[3][3];
 #pragma unroll
-		for(int j = 0; j < 3; ++j) {
-			const float py	= (float) j - pl.fd[1];
-			const float wij = w[0][i] * w[1][j];
-			const float b0	= pl.mv[0] + pl.contrib[0] * px + pl.contrib[3] * py;
-			const v2f_ b12	= {pl.mv[1] + pl.contrib[1] * px + pl.contrib[4] * py, pl.mv[2] + pl.contrib[2] * px + pl.contrib[5] * py};
-#pragma unroll
-			for(int k = 0; k < 3; ++k) {
-				const float pz = (float) k - pl.fd[2];
-				const float W  = wij * w[2][k];
-				const v2f_ m0  = {mass, b0 + pl.contrib[6] * pz};
-				const v2f_ t12 = c12 * pz + b12;
-				bool in		   = act;
-				if constexpr(EDGE) {
-					if(i == 0) in &= nx != 0;
-					if(i == 2) in &= nx != 5;
-					if(j == 0) in &= ny != 0;
-					if(j == 2) in &= ny != 5;
-					if(k == 0) in &= nz != 0;
-					if(k == 2) in &= nz != 5;
+		for(int d = 0; d < 3; ++d) bspline_weight_cells(fd[d], w[d]);
+		const float wx = oi == 0 ? w[0][0] : (oi == 1 ? w[0][1] : w[0][2]);
+		const float wy = oj == 0 ? w[1][0] : (oj == 1 ? w[1][1] : w[1][2]);
+		const float wz = ok == 0 ? w[2][0] : (ok == 1 ? w[2][1] : w[2][2]);
+		const float W  = wx * wy * wz;
+		const float px = fi - fd[0], py = fj - fd[1], pz = fk - fd[2];
+		const float v0 = mass * W;
+		const float v1 = (mvv[0] + c[0] * px + c[3] * py + c[6] * pz) * W;
+		const float v2 = (mvv[1] + c[1] * px + c[4] * py + c[7] * pz) * W;
+		const float v3 = (mvv[2] + c[2] * px + c[5] * py + c[8] * pz) * W;
+		const int gx = nx + oi, gy = ny + oj, gz = nz + ok;// cube coordinates 0..7
+		const bool inside = ((unsigned) (gx - 1) < 6u) & ((unsigned) (gy - 1) < 6u) & ((unsigned) (gz - 1) < 6u);
+		const int nb	  = __shfl(info, 54 + ((gx >> 2) & 1) * 4 + ((gy >> 2) & 1) * 2 + ((gz >> 2) & 1));// grid block of the node (all lanes active here)
+		if(lane < 27) {
+			if(inside) {
+				float4* node	 = arena + (gx - 1) * kP2GStrideX + (gy - 1) * kP2GStrideY + (gz - 1);
+				const float4 acc = *node;
+				*node			 = make_float4(acc.x + v0, acc.y + v1, acc.z + v2, acc.w + v3);
+			} else {
+				if(nb >= 0) {
+					float* g = next_grid + (size_t) nb * 256 + (gx & 3) * 16 + (gy & 3) * 4 + (gz & 3);
+					unsafeAtomicAdd(g, v0);
+					unsafeAtomicAdd(g + 64, v1);
+					unsafeAtomicAdd(g + 128, v2);
+					unsafeAtomicAdd(g + 192, v3);
 				}
-				if(in) {
-					float4* node	 = node0 + i * kP2GStrideX + j * kP2GStrideY + k;
-					const float4 acc = *node;
-					v2f_ a01		 = {acc.x, acc.y};
-					v2f_ a23		 = {acc.z, acc.w};
-					a01				 = m0 * W + a01;
-					a23				 = t12 * W + a23;
-					*node			 = make_float4(a01.x, a01.y, a23.x, a23.y);
-				}
-				__asm__ volatile("" ::: "memory");
-				__builtin_amdgcn_sched_barrier(0);// keep the 27 steps' arithmetic from being hoisted (registers)
 			}
 		}
-	}
-}
-
-// The shell part of an edge lane's stencil (cube nodes 0 / 7, i.e. cells of the 2x2x2 grid blocks outside the LDS arena):
-// one global float atomic per node and channel.  Rare (a particle that has just crossed into a neighbouring block), so
-// this is a rolled loop with run-time stencil offsets: small code, few registers.
-MPM_DEV void p2g_shell(const P2GPayload& pl, float mass, bool act, int nx, int ny, int nz, const int* __restrict__ s_nb, float* __restrict__ next_grid) {
-	float w[3][3];
-#pragma unroll
-	for(int d = 0; d < 3; ++d) bspline_weight_cells(pl.fd[d], w[d]);
-#pragma nounroll
-	for(int o = 0; o < 27; ++o) {
-		const int i = o / 9, j = (o / 3) % 3, k = o % 3;
-		const int gx = nx + i, gy = ny + j, gz = nz + k;
-		const bool out = ((gx == 0) | (gx == 7) | (gy == 0) | (gy == 7) | (gz == 0) | (gz == 7)) & act;
-		if(!out) continue;
-		const int nb = s_nb[(gx >> 2) * 4 + (gy >> 2) * 2 + (gz >> 2)];
-		if(nb < 0) continue;
-		const float wi = i == 0 ? w[0][0] : (i == 1 ? w[0][1] : w[0][2]);
-		const float wj = j == 0 ? w[1][0] : (j == 1 ? w[1][1] : w[1][2]);
-		const float wk = k == 0 ? w[2][0] : (k == 1 ? w[2][1] : w[2][2]);
-		const float W  = wi * wj * wk;
-		const float px = (float) i - pl.fd[0], py = (float) j - pl.fd[1], pz = (float) k - pl.fd[2];
-		float* g	   = next_grid + (size_t) nb * 256 + (gx & 3) * 16 + (gy & 3) * 4 + (gz & 3);
-		unsafeAtomicAdd(g, mass * W);
-		unsafeAtomicAdd(g + 64, (pl.mv[0] + pl.contrib[0] * px + pl.contrib[3] * py + pl.contrib[6] * pz) * W);
-		unsafeAtomicAdd(g + 128, (pl.mv[1] + pl.contrib[1] * px + pl.contrib[4] * py + pl.contrib[7] * pz) * W);
-		unsafeAtomicAdd(g + 192, (pl.mv[2] + pl.contrib[2] * px + pl.contrib[5] * py + pl.contrib[8] * pz) * W);
+		__asm__ volatile("" ::: "memory");// the next particle may hit the same nodes: keep the LDS operations in program order
 	}
 }
 
@@ -230,7 +212,7 @@ MPM_DEV void p2g_shell(const P2GPayload& pl, float mass, bool act, int nx, int n
 // trip and the steps cannot overlap each other - step o+1 may hit the node another lane wrote in step o - so issued back
 // to back they leave the wave waiting 27 times.  Site s of NSITES completes steps [27 s / NSITES, 27 (s+1) / NSITES): the
 // accumulator of the following step is requested right after a step's write and consumed at the next site.  Only lanes
-// with `win` (pairwise distinct stencil bases, no shell nodes) take part; the others go through p2g_resolve.
+// with `win` (pairwise distinct stencil bases, no shell nodes) take part; the others go through p2g_serial.
 template<int NSITES>
 struct ScatterChain {
 	float4* node0;
@@ -302,35 +284,15 @@ MPM_DEV int code_off(int c) {
 	return ((c & 15) - 1) * kP2GStrideX + (((c >> 4) & 15) - 1) * kP2GStrideY + ((c >> 8) - 1);
 }
 
-// Scatter the lanes in `pending` (their payloads are final): lanes whose stencil base is unique among the pending ones
-// (LDS owner table) go first, the others retry; shell nodes of edge lanes go to the grid directly.
-MPM_DEV void p2g_resolve(float4* __restrict__ arena, unsigned char* __restrict__ owner, bool pending, int code, P2GPayload& pl, float mass, int lane, const int* __restrict__ s_nb, float* __restrict__ next_grid) {
-	const int okey	= code >= 0 ? code_key(code) : 0;
-	const bool edge = code_edge(code);
-	const int nx = code & 15, ny = (code >> 4) & 15, nz = code >> 8;
-	if(__any(pending && edge)) p2g_shell(pl, mass, pending && edge, nx, ny, nz, s_nb, next_grid);
-	while(__any(pending)) {
-		// one LDS round trip: the workgroup is a single wave, whose LDS operations execute in order, so the read below sees
-		// the writes above without waiting for them in between
-		if(pending) owner[okey] = (unsigned char) lane;
-		__asm__ volatile("" ::: "memory");// another lane may have written the same byte: no store-to-load forwarding
-		const bool win = pending && (int) owner[okey] == lane;
-		// the payload arithmetic of the 27 steps is invariant in this retry loop: keep the compiler from hoisting it
-#pragma unroll
-		for(int d = 0; d < 3; ++d) __asm__ volatile("" : "+v"(pl.fd[d]));
-		if(__any(win && edge)) p2g_scatter<true>(arena, pl, mass, win, nx, ny, nz);
-		else p2g_scatter<false>(arena, pl, mass, win, nx, ny, nz);
-		pending = pending && !win;
-	}
-}
-
 template<int MAT>
 __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_keys, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, float dt, float new_dt, int* __restrict__ status) {
 	constexpr int NCH = MatTraits<MAT>::nch;
-	__shared__ float4 g2p[kG2PNodes2];// node velocities {vx, vy, vz, vz} of cube nodes 1..6 per axis
-	__shared__ float4 p2g[kP2GNodes]; // {mass, momentum} accumulators of cube nodes 1..6 per axis
-	__shared__ unsigned char s_owner[216];
-	__shared__ int s_src_binoff[27], s_dst_no[27], s_nb[8];
+	// 10.8 KB of LDS per wave: 15 single-wave workgroups per CU.
+	__shared__ float4 g2p[kG2PNodes];	   // node velocities {vx, vy, vz, vz} of cube nodes 1..6 per axis
+	__shared__ float4 p2g[2 * kP2GNodes];  // {mass, momentum} accumulators of cube nodes 1..6 per axis; even lanes use the first
+										   // copy, odd lanes the second: the sort puts two particles of one key that share a slice
+										   // into neighbouring lanes, so both scatter in the same pass (summed in the write-back)
+	__shared__ unsigned char s_owner[2 * 216];
 
 	const int lane = threadIdx.x;
 	// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Consecutive block numbers are spatial
@@ -352,19 +314,21 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 	const int tag_shift = cfg.pid_bits + kKeyBits;
 	// ---- round trip 2: the block's row of look-up results and the records of the first two iterations
 	const int info = mv.blockinfo[(size_t) b * kInfoRow + lane];
-	int rec_cur	   = list[min(lane, size - 1)];
-	int rec_next   = list[min(64 + lane, size - 1)];
-	if(lane < 27) s_src_binoff[lane] = info;
-	else if(lane < 54) s_dst_no[lane - 27] = info;
-	else if(lane < 62) s_nb[lane - 54] = info;
-	for(int i = lane; i < kP2GNodes; i += 64) p2g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+	// (sliced list layout, mpm_kernels.hpp: a 64-slot slice holds its records in its first slots; idle lanes re-read the last one)
+	int cnt_cur	   = slice_records_at(size, 0);
+	int cnt_next   = 64 < size ? slice_records_at(size, 64) : 1;
+	int rec_cur	   = list[min(lane, cnt_cur - 1)];
+	int rec_next   = list[(64 < size ? 64 : 0) + min(lane, cnt_next - 1)];
+	// (`info` stays in its register: lane l < 27 holds the bin offset of source block l, lanes 27..53 the destination block
+	//  numbers, lanes 54..61 the eight grid blocks; they are read with __shfl = ds_bpermute, which costs no LDS space)
+	for(int i = lane; i < 2 * kP2GNodes; i += 64) p2g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 	__syncthreads();
 	// ---- round trip 3: the 8 grid blocks (lane = cell -> 256-B rows per channel, :699-727) and the first 64 particles
 	const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;// lane == cell of a 4x4x4 block
 	float4 gv[8];
 #pragma unroll
 	for(int lb = 0; lb < 8; ++lb) {
-		const int nb	= s_nb[lb];
+		const int nb	= __shfl(info, 54 + lb);
 		const float* gb = grid + (size_t) (nb < 0 ? 0 : nb) * 256;
 		gv[lb].x		= gb[64 + lane];
 		gv[lb].y		= gb[128 + lane];
@@ -377,38 +341,33 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 	// compiler can count them in s_waitcnt; their arrival is implied by the list-append atomics' results being consumed
 	// at the end of the iteration (memory operations return in order).
 	struct Prefetch {
-		float pos[3], st[10];
-		int key;// the stencil base this particle was predicted to have after this step (its sort key)
+		float4 q[NCH / 4];// the particle record
+		int key;		  // the stencil base this particle was predicted to have after this step (its sort key)
 	};
 	auto fetch = [&](int rec, Prefetch& f) {
-		const int tag	 = rec >> tag_shift;
-		const int sp	 = rec & (cfg.ppb - 1);
-		const int sbin	 = s_src_binoff[tag] + (sp >> 6);
-		const float* src = mv.bins_src + (size_t) sbin * (NCH * kBin) + (sp & 63);
-		f.key			 = (rec >> key_shift) & 255;
-		f.pos[0]		 = src[0];
-		f.pos[1]		 = src[kBin];
-		f.pos[2]		 = src[2 * kBin];
-		if constexpr(MAT == 0) {
-			f.st[0] = src[3 * kBin];
-		} else {
+		const int tag	  = (rec >> tag_shift) & 31;
+		const int sp	  = rec & (cfg.ppb - 1);
+		const int sbin	  = __shfl(info, tag) + (sp >> 6);
+		const float4* src = reinterpret_cast<const float4*>(mv.bins_src + ((size_t) sbin * kBin + (sp & 63)) * NCH);
+		f.key			  = (rec >> key_shift) & 255;
 #pragma unroll
-			for(int d = 0; d < 9; ++d) f.st[d] = src[(3 + d) * kBin];
-			if constexpr(NCH == 13) f.st[9] = src[12 * kBin];
-		}
+		for(int d = 0; d < NCH / 4; ++d) f.q[d] = src[d];
 	};
 	Prefetch pf;
 	fetch(rec_cur, pf);
 #pragma unroll
 	for(int lb = 0; lb < 8; ++lb) {
 		const int ax = cx + ((lb & 4) ? 4 : 0) - 1, ay = cy + ((lb & 2) ? 4 : 0) - 1, az = cz + ((lb & 1) ? 4 : 0) - 1;
-		if(((unsigned) ax < 6u) & ((unsigned) ay < 6u) & ((unsigned) az < 6u)) g2p[ay * kG2PStrideY + ax * kG2PStrideX2 + az] = gv[lb];
+		if(((unsigned) ax < 6u) & ((unsigned) ay < 6u) & ((unsigned) az < 6u)) g2p[ax * kG2PStrideX + ay * kG2PStrideY + az] = gv[lb];
 	}
 	__syncthreads();
 	// Software pipeline: the scatter of iteration i-1 (an ordered chain of 27 LDS round trips) is issued inside the material
 	// update of iteration i; `pv` is the payload in flight, pv_code its stencil base (-1: none).
 	P2GPayload pv;
 	int pv_code = -1;
+#ifdef MPM_G2P2G_STATS
+	int st_iter = 0, st_losers = 0, st_edge = 0, st_retry_iters = 0, st_partial = 0;
+#endif
 	for(int idx0 = 0;; idx0 += 64) {
 		// one pass more than there are iterations: the last one only drains the pipeline (scatter of the last payload)
 		const bool drain = idx0 >= size;
@@ -418,14 +377,32 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 		bool in_arena = false;
 		int ncode	  = -1;
 		if(!drain) {
-		const bool active = idx0 + lane < size;
+		const bool active = lane < cnt_cur;
 		const int pidib	  = idx0 + lane;// slot in the destination bins == position in the sorted order
 		// ---- advection record -> source bin (:747-768): data was requested one iteration ago
-		float pos[3] = {pf.pos[0], pf.pos[1], pf.pos[2]};
+		float pos[3] = {pf.q[0].x, pf.q[0].y, pf.q[0].z};
 		float st[10];// J, or F[9] (+ logJp)
-#pragma unroll
-		for(int d = 0; d < 10; ++d) st[d] = pf.st[d];
-		const int rec_nn = list[min(idx0 + 128 + lane, size - 1)];
+		st[0] = pf.q[0].w;
+		if constexpr(MAT != 0) {
+			st[1] = pf.q[1].x;
+			st[2] = pf.q[1].y;
+			st[3] = pf.q[1].z;
+			st[4] = pf.q[1].w;
+			st[5] = pf.q[2].x;
+			st[6] = pf.q[2].y;
+			st[7] = pf.q[2].z;
+			st[8] = pf.q[2].w;
+			if constexpr(NCH == 16) st[9] = pf.q[3].x;
+		}
+		const int slot_nn = idx0 + 128 < size ? idx0 + 128 : 0;
+		const int cnt_nn  = idx0 + 128 < size ? slice_records_at(size, idx0 + 128) : 1;
+		const int rec_nn  = list[slot_nn + min(lane, cnt_nn - 1)];
+#ifdef MPM_EARLY_FETCH
+		fetch(rec_next, pf);
+		rec_next = rec_nn;
+		cnt_cur	 = cnt_next;
+		cnt_next = cnt_nn;
+#endif
 		// ---- stencil base + weights (:774-797) for ALL lanes (idle lanes of a last partial iteration carry a dummy
 		//      position inside the block); offsets in cell units (exact: dx is a power of two)
 		int base[3], arena[3];
@@ -440,7 +417,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 				bspline_weight_cells(fd[d], w[d]);
 				arena[d] = ((base[d] - 1) & 3) + 1;
 			}
-			gather_apic(g2p + (arena[1] - 1) * kG2PStrideY + (arena[0] - 1) * kG2PStrideX2 + (arena[2] - 1), w, fd, vel, A);
+			gather_apic(g2p + (arena[0] - 1) * kG2PStrideX + (arena[1] - 1) * kG2PStrideY + (arena[2] - 1), w, fd, vel, A);
 		}
 		// Every lane runs the whole body: the idle lanes of a last partial iteration carry a dummy particle and write it into
 		// the padding slots of the block's last bin (slot == pidib < 64 * ceil(size / 64), allocated but never read), which
@@ -464,7 +441,8 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 		}
 		const bool dir_ok = ((unsigned) (dirv[0] + 1) < 3u) & ((unsigned) (dirv[1] + 1) < 3u) & ((unsigned) (dirv[2] + 1) < 3u);
 		const int ntag	  = dir_ok ? (dirv[0] + 1) * 9 + (dirv[1] + 1) * 3 + dirv[2] + 1 : kStay;
-		const int dno	  = (active && dir_ok) ? s_dst_no[ntag] : -1;
+		const int dno_raw = __shfl(info, 27 + ntag);
+		const int dno	  = (active && dir_ok) ? dno_raw : -1;
 		// sort key for the NEXT step: predicted stencil base after one more advection with the current velocity,
 		// expressed in the cube of the block the particle is in after THIS step (clamped to the 6^3 range)
 		int pk[3];
@@ -494,16 +472,13 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 		//      chain threaded through this iteration's material update, the others (and the edge lanes) afterwards
 		constexpr int kStressSites = MAT == 0 ? 1 : (MAT == 1 ? kFcSites : (MAT == 2 ? kSandSites : kNaccSites));
 		constexpr int kSites	   = kStressSites + 2;
-		const int pv_key = pv_in ? code_key(pv_code) : 0;
+		const int pv_key = (pv_in ? code_key(pv_code) : 0) + (lane & 1) * 216;// even / odd lanes: separate arenas, separate claims
 		if(pv_in) s_owner[pv_key] = (unsigned char) lane;
 		__asm__ volatile("" ::: "memory");// another lane may have written the same byte: no store-to-load forwarding
 		win = pv_in && !code_edge(pv_code) && (int) s_owner[pv_key] == lane;
-		ScatterChain<kSites> chain(p2g + (win ? code_off(pv_code) : 0), pv, mass, win);
-		// ---- material update, store to the destination bin (coalesced: slot == pidib) (:470-663)
-		float* dst = mv.bins_dst + (size_t) (binoff_dst + (pidib >> 6)) * (NCH * kBin) + (pidib & 63);
-		dst[0]		  = pos[0];
-		dst[kBin]	  = pos[1];
-		dst[2 * kBin] = pos[2];
+		ScatterChain<kSites> chain(p2g + (win ? code_off(pv_code) + (lane & 1) * kP2GNodes : 0), pv, mass, win);
+		// ---- material update, store to the destination bin (slot == pidib: consecutive records) (:470-663)
+		float4* dst = reinterpret_cast<float4*>(mv.bins_dst + ((size_t) (binoff_dst + (pidib >> 6)) * kBin + (pidib & 63)) * NCH);
 		if constexpr(MAT == 0) {
 			float Aw[9];
 #pragma unroll
@@ -511,7 +486,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 			chain.template at<0>();
 			const float J = stress_jfluid(mv.mc, st[0], Aw, dt, cfg.d_inv, pl.contrib);
 			chain.template at<1>();
-			dst[3 * kBin] = J;
+			dst[0] = make_float4(pos[0], pos[1], pos[2], J);
 		} else {
 			float dws[9], Fold[9], F[9];
 #pragma unroll
@@ -521,21 +496,20 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 			}
 			matmul3(dws, Fold, F);
 			chain.template at<0>();
+			float lj = 0.f;
 			if constexpr(MAT == 1) {
 				stress_fixed_corotated<1>(mv.mc, F, pl.contrib, chain);
-#pragma unroll
-				for(int d = 0; d < 9; ++d) dst[(3 + d) * kBin] = F[d];
 			} else if constexpr(MAT == 2) {
-				float lj = st[9];
-				stress_sand<1>(mv.mc, F, lj, pl.contrib, chain, dst + 3 * kBin, kBin);
-				dst[12 * kBin] = lj;
+				lj = st[9];
+				stress_sand<1>(mv.mc, F, lj, pl.contrib, chain);
 			} else {
-				float lj = st[9];
+				lj = st[9];
 				stress_nacc<1>(mv.mc, F, lj, pl.contrib, chain);
-#pragma unroll
-				for(int d = 0; d < 9; ++d) dst[(3 + d) * kBin] = F[d];
-				dst[12 * kBin] = lj;
 			}
+			dst[0] = make_float4(pos[0], pos[1], pos[2], F[0]);
+			dst[1] = make_float4(F[1], F[2], F[3], F[4]);
+			dst[2] = make_float4(F[5], F[6], F[7], F[8]);
+			if constexpr(NCH == 16) dst[3] = make_float4(lj, 0.f, 0.f, 0.f);
 		}
 		// (:850) contrib = (A m - contrib new_dt) D^-1, pre-multiplied by dx so that P2G can stay in cell units
 		{
@@ -547,8 +521,12 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 		chain.template at<kSites - 1>();
 		// ---- the next iteration's particle data is requested here: in flight during the tail of this iteration and the
 		//      gather of the next one, without occupying 14 registers during the material update
+#ifndef MPM_EARLY_FETCH
 		fetch(rec_next, pf);
 		rec_next = rec_nn;
+		cnt_cur	 = cnt_next;
+		cnt_next = cnt_nn;
+#endif
 		ncode = in_arena ? (narena[0] | (narena[1] << 4) | (narena[2] << 8)) : -1;
 		// ---- list append: the atomics' results are in by now (and with them the next iteration's particle data)
 		{
@@ -561,11 +539,28 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 					mv.list_out[(size_t) dno * cfg.ppb + slot] = rec;
 			}
 		}
-		}// !drain
+		} else if(pv_in) {
+			// draining pass: the last payload's winners run the 27 steps back to back
+			const int pv_key = code_key(pv_code) + (lane & 1) * 216;
+			s_owner[pv_key]	 = (unsigned char) lane;
+			__asm__ volatile("" ::: "memory");
+			win = !code_edge(pv_code) && (int) s_owner[pv_key] == lane;
+			ScatterChain<1> chain(p2g + (win ? code_off(pv_code) + (lane & 1) * kP2GNodes : 0), pv, mass, win);
+			chain.template at<0>();
+		}
 		// ---- the lanes that lost the claim and the edge lanes scatter now (rare); in the draining pass: every lane
 		{
 			const bool left = pv_in && !win;
-			if(__any(left)) p2g_resolve(p2g, s_owner, left, pv_code, pv, mass, lane, s_nb, next_grid);
+#ifdef MPM_G2P2G_STATS
+			if(!drain) {
+				st_iter += 1;
+				st_losers += __popcll(__ballot(left && !code_edge(pv_code)));
+				st_edge += __popcll(__ballot(pv_in && code_edge(pv_code)));
+				st_retry_iters += __any(left) ? 1 : 0;
+				st_partial += 64 - cnt_cur;
+			}
+#endif
+			if(__any(left)) p2g_serial(p2g, left, pv_code, pv, mass, lane, info, next_grid);
 		}
 		if(drain) break;
 		// ---- hand the payload to the next iteration (:887-905)
@@ -578,13 +573,25 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 		for(int d = 0; d < 9; ++d) pv.contrib[d] = pl.contrib[d];
 		pv_code = ncode;
 	}
+#ifdef MPM_G2P2G_STATS
+	if(lane == 0) {
+		atomicAdd(&status[24], st_iter);
+		atomicAdd(&status[25], st_losers);
+		atomicAdd(&status[26], st_edge);
+		atomicAdd(&status[27], st_retry_iters);
+		atomicAdd(&status[28], st_partial);
+	}
+#endif
 	__syncthreads();
 	// ---- arena -> next grid: one hardware f32 atomic per touched node and channel (:907-936).  216 nodes, 4 rounds.
-	for(int n = lane; n < kP2GNodes; n += 64) {
+#pragma unroll
+	for(int r = 0; r < (kP2GNodes + 63) / 64; ++r) {// (uniform trip count: __shfl needs its source lanes 54..61 active)
+		const int n = min(r * 64 + lane, kP2GNodes - 1);
 		const int x = n / 36 + 1, y = (n / 6) % 6 + 1, z = n % 6 + 1;// cube coordinates 1..6
-		const int nb = s_nb[(x >> 2) * 4 + (y >> 2) * 2 + (z >> 2)];
-		const float4 v = p2g[n];
-		if(nb >= 0) {
+		const int nb	= __shfl(info, 54 + (x >> 2) * 4 + (y >> 2) * 2 + (z >> 2));
+		const float4 va = p2g[n], vb = p2g[kP2GNodes + n];
+		const float4 v	= make_float4(va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w);
+		if(nb >= 0 && r * 64 + lane < kP2GNodes) {
 			float* g = next_grid + (size_t) nb * 256 + (x & 3) * 16 + (y & 3) * 4 + (z & 3);
 			if(v.x != 0.f) unsafeAtomicAdd(g, v.x);
 			if(v.y != 0.f) unsafeAtomicAdd(g + 64, v.y);

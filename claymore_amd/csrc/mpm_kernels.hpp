@@ -40,7 +40,6 @@ namespace mpm {
 constexpr int kBin		  = 64; // particles per AoSoA bin == wavefront width
 constexpr int kG2P2GThreads = 64; // ONE wave per particle block: no cross-wave LDS hazards, no barriers that wait
 constexpr int kMaxModels  = 8;
-constexpr int kSortRounds	= 24;  // particles per key (per chunk) that get an exact interleaved position; more -> appended behind
 constexpr int kSortKeys		= 216; // sort key = PREDICTED stencil base of the particle in the arena of its block (6^3 values)
 constexpr int kKeyBits		= 8;
 constexpr int kStay		  = 13; // dir_offset(0,0,0), utility_funcs.hpp:25-27
@@ -97,6 +96,44 @@ __device__ __forceinline__ int wave_append(int* counter, bool pred) {
 	if(lane == leader) base = atomicAdd(counter, __popcll(m));
 	base = __shfl(base, leader);
 	return pred ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// Layout of a block's advection list after prepare_blocks_kernel.  The list is cut into chunks of kListChunk slots
+// (records [512 c, 512 c + n) of the block); a chunk with n records is laid out as S = ceil(n / 64) slices of 64 slots
+// (one G2P2G iteration each), slice s holding n / S + (s < n % S) records in its first slots: records of one sort key go
+// to consecutive slices (wrap-around rule), so a slice holds a key twice only if the key has more than S particles.
+// The slots behind a slice's records are holes (never read); a block still occupies ceil(size / 64) * 64 slots.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kListChunk = 512;
+__device__ __forceinline__ int div_small(int n, int d) {// n / d for 0 <= n <= 512, 1 <= d <= 8 (exact, checked exhaustively)
+	return (n * ((65536 + d - 1) / d)) >> 16;
+}
+__device__ __forceinline__ int chunk_records(int size, int chunk) {
+	return min(kListChunk, size - chunk * kListChunk);
+}
+__device__ __forceinline__ int slice_records(int n, int s) {// records in slice s of a chunk with n records
+	const int S = (n + 63) >> 6;
+	const int q = div_small(n, S);
+	return q + (s < n - q * S ? 1 : 0);
+}
+// slot of the i-th record (in slice-major order) of a chunk with n records
+__device__ __forceinline__ int chunk_slot(int n, int i) {
+	const int S = (n + 63) >> 6;
+	const int q = div_small(n, S), r = n - q * S;
+	const int big = r * (q + 1);
+	if(i < big) {
+		const int sl = i / (q + 1);
+		return sl * 64 + (i - sl * (q + 1));
+	}
+	const int j = i - big, sl = j / q;
+	return (r + sl) * 64 + (j - sl * q);
+}
+// number of records in the 64-slot slice that starts at slot idx0 of a block with `size` particles
+__device__ __forceinline__ int slice_records_at(int size, int idx0) {
+	const int chunk = idx0 / kListChunk;
+	return slice_records(chunk_records(size, chunk), (idx0 >> 6) & (kListChunk / 64 - 1));
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -200,13 +237,19 @@ __global__ __launch_bounds__(64) void pack_lists_kernel(int ppb, const int* __re
 	const int b = blockIdx.x;
 	const int n = size[b];
 	const int* row = list + (size_t) row_of[b] * ppb;
-	for(int i = threadIdx.x; i < n; i += 64) packed[offset[b] + i] = row[i];
+	for(int i = threadIdx.x; i < n; i += 64) {
+		const int chunk = i / kListChunk;
+		packed[offset[b] + i] = row[chunk * kListChunk + chunk_slot(chunk_records(n, chunk), i - chunk * kListChunk)];
+	}
 }
 __global__ __launch_bounds__(64) void unpack_lists_kernel(int ppb, const int* __restrict__ size, int* __restrict__ row_of, const long long* __restrict__ offset, int* __restrict__ list, const int* __restrict__ packed) {
 	const int b = blockIdx.x;
 	const int n = size[b];
 	int* row	= list + (size_t) b * ppb;// rows are re-seated at their own block number
-	for(int i = threadIdx.x; i < n; i += 64) row[i] = packed[offset[b] + i];
+	for(int i = threadIdx.x; i < n; i += 64) {
+		const int chunk = i / kListChunk;
+		row[chunk * kListChunk + chunk_slot(chunk_records(n, chunk), i - chunk * kListChunk)] = packed[offset[b] + i];
+	}
 	if(threadIdx.x == 0) row_of[b] = b;
 }
 // dense table from a key list (the inverse of what compact / register build incrementally)
@@ -250,14 +293,10 @@ struct PrepareModels {
 };
 template<bool SORT>
 __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, PrepareModels pm, const int* __restrict__ pbc_ptr, const int* __restrict__ cur_table, const int* __restrict__ cur_keys, const int* __restrict__ prev_table) {
-	// records are sorted in chunks of 512 (8 per lane): G2P2G only needs every aligned 64-record slice to hold distinct keys,
-	// and the smaller chunk keeps this kernel at 3.9 KB of LDS, i.e. at the hardware's wave limit
-	constexpr int kPrepChunk = 512;
+	// records are sorted in chunks of 512 (8 per lane): every 64-slot slice of a chunk is one G2P2G iteration
+	constexpr int kPrepChunk = kListChunk;
 	__shared__ int s_sorted[kPrepChunk];
-	__shared__ unsigned long long s_mask[kSortRounds][4];// per round: which of the 216 keys still have a k-th particle
-	__shared__ int s_round0[kSortRounds + 1];			  // first sorted position of round k
-	__shared__ unsigned s_wordoff[kSortRounds];			  // packed prefix of the four mask words' popcounts (3 x 8 bit)
-	__shared__ int s_cnt[256 - 32];						  // 216 keys used
+	__shared__ int s_cnt[256];// per key (216 used): count, then first position of the key in key-major order
 	const int lane = threadIdx.x;
 	const int b	   = blockIdx.x;
 	if(b >= *pbc_ptr) return;
@@ -296,71 +335,46 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 		if(lane < 27) info = srcno >= 0 ? pm.binoff_src[m][srcno] : -1;
 		auto sort_chunk = [&](int chunk0, int nrec) {
 #pragma unroll
-			for(int q = 0; q < 4; ++q)
-				if(lane + 64 * q < 224) s_cnt[lane + 64 * q] = 0;
+			for(int q = 0; q < 4; ++q) s_cnt[lane + 64 * q] = 0;
 			__syncthreads();
-			unsigned packed[NIT];
+			int rank[NIT];
 #pragma unroll
 			for(int it = 0; it < NIT; ++it) {
-				const int idx = it * 64 + lane;
-				packed[it]	  = 0u;
-				if(idx < nrec) {
-					const unsigned rec = recs[it] & rec_mask;
-					const int c		   = (rec >> key_shift) & 255;
-					const int k		   = atomicAdd(&s_cnt[c], 1);// ds_add_rtn_u32: integer LDS atomics run at full rate
-					packed[it]		   = rec | ((unsigned) min(k, kSortRounds) << 26);
-				}
+				rank[it] = 0;
+				if(it * 64 + lane < nrec) rank[it] = atomicAdd(&s_cnt[(recs[it] >> key_shift) & 255], 1);// ds_add_rtn_u32: integer LDS atomics run at full rate
 			}
 			__syncthreads();
-			{
-				int my[4];
-				int maxc = 0;
+			{// exclusive prefix sum of the counts over the keys: lane owns keys 4 lane .. 4 lane + 3
+				const int c0 = s_cnt[4 * lane], c1 = s_cnt[4 * lane + 1], c2 = s_cnt[4 * lane + 2], c3 = s_cnt[4 * lane + 3];
+				int incl = c0 + c1 + c2 + c3;
 #pragma unroll
-				for(int q = 0; q < 4; ++q) {
-					my[q] = lane + 64 * q < 224 ? s_cnt[lane + 64 * q] : 0;
-					maxc  = max(maxc, my[q]);
+				for(int off = 1; off < 64; off <<= 1) {
+					const int v = __shfl_up(incl, off);
+					if(lane >= off) incl += v;
 				}
-#pragma unroll
-				for(int off = 32; off > 0; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off));
-				maxc	= min(maxc, kSortRounds);
-				int run = 0;
-				for(int k = 0; k < maxc; ++k) {
-					const unsigned long long m0 = __ballot(my[0] > k), m1 = __ballot(my[1] > k), m2 = __ballot(my[2] > k), m3 = __ballot(my[3] > k);
-					const int p0 = __popcll(m0), p1 = p0 + __popcll(m1), p2 = p1 + __popcll(m2);
-					if(lane == 0) {
-						s_mask[k][0] = m0;
-						s_mask[k][1] = m1;
-						s_mask[k][2] = m2;
-						s_mask[k][3] = m3;
-						s_wordoff[k] = (unsigned) p0 << 8 | (unsigned) p1 << 16 | (unsigned) p2 << 24;
-						s_round0[k]	 = run;
-					}
-					run += p2 + __popcll(m3);
-				}
-				if(lane == 0) s_round0[kSortRounds] = run;// overflow records (k >= kSortRounds) go behind the sorted ones
-				s_cnt[lane] = 0;
+				const int excl = incl - (c0 + c1 + c2 + c3);
+				__syncthreads();
+				s_cnt[4 * lane]		= excl;
+				s_cnt[4 * lane + 1] = excl + c0;
+				s_cnt[4 * lane + 2] = excl + c0 + c1;
+				s_cnt[4 * lane + 3] = excl + c0 + c1 + c2;
 			}
 			__syncthreads();
+			// wrap-around rule: the p-th record in key-major order goes to slice p mod S, position p / S
+			const int S = (nrec + 63) >> 6;
 #pragma unroll
 			for(int it = 0; it < NIT; ++it) {
 				if(it * 64 + lane < nrec) {
-					const unsigned rec = packed[it] & rec_mask;
-					const int k		   = packed[it] >> 26;
-					const int c		   = (rec >> key_shift) & 255;
-					int pos;
-					if(k < kSortRounds) {
-						const int w = c >> 6;
-						pos			= s_round0[k] + (int) ((s_wordoff[k] >> (8 * w)) & 255u) + __popcll(s_mask[k][w] & ((1ull << (c & 63)) - 1ull));
-					} else {
-						pos = s_round0[kSortRounds] + atomicAdd(&s_cnt[0], 1);
-					}
-					s_sorted[pos] = (int) rec;
+					const unsigned rec = recs[it] & rec_mask;
+					const int p		   = s_cnt[(rec >> key_shift) & 255] + rank[it];
+					const int pos	   = div_small(p, S);
+					s_sorted[(p - pos * S) * 64 + pos] = (int) rec;
 				}
 			}
 			__syncthreads();
 #pragma unroll
 			for(int it = 0; it < NIT; ++it)
-				if(it * 64 + lane < nrec) list[chunk0 + it * 64 + lane] = s_sorted[it * 64 + lane];
+				if(it < S && lane < slice_records(nrec, it)) list[chunk0 + it * 64 + lane] = s_sorted[it * 64 + lane];
 			__syncthreads();
 		};
 		for(int chunk0 = 0; chunk0 < size; chunk0 += kPrepChunk) {
@@ -540,15 +554,18 @@ __global__ __launch_bounds__(256) void fill_bins_kernel(GridCfg cfg, int nch, fl
 	const int n = size[b];
 	for(int pidib = threadIdx.x; pidib < n; pidib += blockDim.x) {
 		const int pid = ids[(size_t) b * cfg.ppb + pidib];
-		float* dst	  = bins + (size_t) (binoff[b] + (pidib >> 6)) * (nch * kBin) + (pidib & 63);
-		dst[0]		  = xyz[3 * (size_t) pid];
-		dst[kBin]	  = xyz[3 * (size_t) pid + 1];
-		dst[2 * kBin] = xyz[3 * (size_t) pid + 2];
+		float* dst = bins + ((size_t) (binoff[b] + (pidib >> 6)) * kBin + (pidib & 63)) * nch;// record layout: mpm_g2p2g.hpp
+		dst[0]	   = xyz[3 * (size_t) pid];
+		dst[1]	   = xyz[3 * (size_t) pid + 1];
+		dst[2]	   = xyz[3 * (size_t) pid + 2];
 		if(nch == 4) {
-			dst[3 * kBin] = 1.f;
+			dst[3] = 1.f;
 		} else {
-			for(int d = 0; d < 9; ++d) dst[(3 + d) * kBin] = (d % 4 == 0) ? 1.f : 0.f;
-			if(nch == 13) dst[12 * kBin] = log_jp0;
+			for(int d = 0; d < 9; ++d) dst[3 + d] = (d % 4 == 0) ? 1.f : 0.f;
+			if(nch == 16) {
+				dst[12] = log_jp0;
+				dst[13] = dst[14] = dst[15] = 0.f;
+			}
 		}
 		const int cx = node_index(xyz[3 * (size_t) pid], cfg.dx_inv) - 2, cy = node_index(xyz[3 * (size_t) pid + 1], cfg.dx_inv) - 2, cz = node_index(xyz[3 * (size_t) pid + 2], cfg.dx_inv) - 2;
 		const int key = (((cy & 3) + 1) * 6 + ((cx & 3) + 1)) * 6 + ((cz & 3) + 1);// stencil base in the block's node cube, y slowest (mpm_g2p2g.hpp); no motion predicted
@@ -590,27 +607,28 @@ __global__ __launch_bounds__(256) void retrieve_kernel(GridCfg cfg, int nch, con
 	if(n == 0) return;
 	const int kx = cur_keys[3 * b], ky = cur_keys[3 * b + 1], kz = cur_keys[3 * b + 2];
 	const int* list = list_in + (size_t) row_of[b] * cfg.ppb;
-	for(int pidib = threadIdx.x; pidib < n; pidib += blockDim.x) {
+	for(int pidib = threadIdx.x; pidib < ((n + 63) & ~63); pidib += blockDim.x) {
+		if((pidib & 63) >= slice_records_at(n, pidib & ~63)) continue;// a hole of the sliced list layout
 		const int rec = list[pidib];
 		int ox, oy, oz;
-		dir_components(rec >> (cfg.pid_bits + kKeyBits), ox, oy, oz);
+		dir_components((rec >> (cfg.pid_bits + kKeyBits)) & 31, ox, oy, oz);
 		const int sp	 = rec & (cfg.ppb - 1);
 		const int srcno	 = table_query(cfg, prev_table, kx + ox, ky + oy, kz + oz);
-		const float* src = bins_src + (size_t) (binoff_src[srcno] + (sp >> 6)) * (nch * kBin) + (sp & 63);
+		const float* src = bins_src + ((size_t) (binoff_src[srcno] + (sp >> 6)) * kBin + (sp & 63)) * nch;
 		const unsigned long long o = atomicAdd(counter, 1ull);
 		if(o >= capacity) continue;
 		xyz[3 * o]	   = src[0];
-		xyz[3 * o + 1] = src[kBin];
-		xyz[3 * o + 2] = src[2 * kBin];
+		xyz[3 * o + 1] = src[1];
+		xyz[3 * o + 2] = src[2];
 		if(state9) {
 			if(nch == 4) {
-				state9[9 * o] = src[3 * kBin];
+				state9[9 * o] = src[3];
 				for(int d = 1; d < 9; ++d) state9[9 * o + d] = 0.f;
 			} else {
-				for(int d = 0; d < 9; ++d) state9[9 * o + d] = src[(3 + d) * kBin];
+				for(int d = 0; d < 9; ++d) state9[9 * o + d] = src[3 + d];
 			}
 		}
-		if(logjp) logjp[o] = nch == 13 ? src[12 * kBin] : 0.f;
+		if(logjp) logjp[o] = nch == 16 ? src[12] : 0.f;
 	}
 }
 

@@ -185,6 +185,17 @@ class Engine:
         self._check(self.api.get_capacity(self.ctx, C.byref(blocks), bins, C.byref(events)))
         return blocks.value, list(bins), events.value
 
+    def model_mass(self, model=0):
+        """Particle mass of a model: volume * rho (particle_buffer.cuh:158,:186,:252)."""
+        p = self.models[model]["params"]
+        return float(np.float32(p.volume) * np.float32(p.rho))
+
+    def diagnostics(self):
+        """Particles / P2G contributions the reference would have lost silently (HIP library only)."""
+        d = _ffi.Diagnostics()
+        self._check(self.api.get_diagnostics(self.ctx, C.byref(d)))
+        return d
+
     def timers(self):
         t = _ffi.Timers()
         self._check(self.api.get_timers(self.ctx, C.byref(t)))

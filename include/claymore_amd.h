@@ -186,6 +186,17 @@ int mpm_set_collision_object(mpm_ctx* ctx, const mpm_collision_object* obj, cons
  * (exterior count limit), bins per model (bin_capacity[8]).  HIP library only. */
 int mpm_get_capacity(mpm_ctx* ctx, int64_t* block_capacity, int64_t* bin_capacity, int* growth_events);
 int mpm_get_timers(mpm_ctx* ctx, mpm_timers* t);
+/* What the reference loses silently, counted since initial_setup (as of the last completed rebuild): particles that left
+ * the domain or the block neighbourhood (add_advection finds no block, particle_buffer.cuh:105-113) and P2G contributions
+ * discarded because a particle moved more than one cell in a substep (mgmpm_kernels.cuh:877-885, a CFL violation).
+ * A run that conserves mass has both at zero; bench.py and the full-size tests assert that.  HIP library only. */
+typedef struct mpm_diagnostics {
+	int64_t lost_particles;
+	int64_t discarded_p2g;
+	int overflow_flags; /* bit 0: block capacity, bit 1: particles per block (both also raise MPM_ERR_CAPACITY) */
+	int reserved[5];
+} mpm_diagnostics;
+int mpm_get_diagnostics(mpm_ctx* ctx, mpm_diagnostics* d);
 /* Sum over the current grid of {mass, momentum x, y, z} (the reference's sum_grid_mass debug kernel,
  * mgmpm_kernels.cuh:1034-1037, extended to momentum); valid between rebuild and the next grid update. */
 int mpm_grid_totals(mpm_ctx* ctx, double out[4]);
