@@ -131,7 +131,9 @@ def main():
     if use_mgsp:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # host-side rendez-vous only (RCCL unique id, barriers, the max over ranks of the elapsed time): the data path is RCCL
+        # inside the library (claymore_amd/csrc/mpm_group.inc), one communicator per rank on the engine's own streams
+        dist.init_process_group("gloo")
 
     import __graft_entry__ as g
     if rank == 0:
@@ -177,9 +179,17 @@ def main():
         assert check["grid_mass_rel_err"] < 1e-4 and np.isfinite(totals).all(), check
         eng.close()
     else:
-        from claymore_amd.mgsp import MgspRank
-        sim = MgspRank(sc, rank, world, device=local_rank)
+        from claymore_amd.mgsp import MgspGroupRank
+
+        def bootstrap(raw):
+            objs = [raw]
+            dist.broadcast_object_list(objs, src=0)
+            return objs[0]
+
+        sim = MgspGroupRank(sc, rank, world, device=local_rank, bootstrap=bootstrap)
         sim.initial_setup()
+        if args.start_step:
+            sim.run_fixed(args.start_step, dt)
         sim.run_fixed(args.warmup, dt)
         dist.barrier()
         torch.cuda.synchronize()
@@ -188,14 +198,20 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         g2p2g_ms = sim.g2p2g_ms_avg
         phases = sim.phase_ms()
         blocks = sim.block_counts()
         n_rank = sim.n_local
-        check = None
+        # self-check over all ranks: every particle is still bucketed, nothing was lost or discarded
+        d = sim.eng.diagnostics()
+        c = sim.eng.counts()
+        tot = torch.tensor([float(sum(c.particles[i] for i in range(c.model_count))), float(d.lost_particles), float(d.discarded_p2g)], dtype=torch.float64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        check = {"particles_bucketed": int(tot[0].item()), "lost_particles": int(tot[1].item()), "discarded_p2g": int(tot[2].item())}
+        assert check["particles_bucketed"] == n_total and check["lost_particles"] == 0 and check["discarded_p2g"] == 0, check
         sim.close()
 
     if rank == 0:
@@ -208,7 +224,7 @@ def main():
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "particles": n_total, "dt": dt,
-                       "parallelism": "single GPU" if world == 1 else f"mgsp static particle partition x{world}",
+                       "parallelism": "single GPU" if not use_mgsp else f"mgsp static particle partition x{world}, C++ driver on RCCL",
                        "blocks": blocks, "phases_ms": phases},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -103,6 +103,17 @@ HIP_ONLY = {
     "checkpoint_size": (_i, [_vp, _P(_sz)]),
     "checkpoint_save": (_i, [_vp, _vp, _sz, _P(_sz)]),
     "checkpoint_load": (_i, [_vp, _vp, _sz]),
+    "group_unique_id": (_i, [_vp]),
+    "group_create": (_i, [_vp, _i, _i, _vp, _P(_vp)]),
+    "group_create_local": (_i, [_P(_vp), _i, _P(_vp)]),
+    "group_destroy": (None, [_vp]),
+    "group_last_error": (C.c_char_p, [_vp]),
+    "group_initial_setup": (_i, [_vp]),
+    "group_substep": (_i, [_vp, _f, _f, _fp]),
+    "group_run_fixed": (_i, [_vp, _i, _f]),
+    "group_compute_dt": (_f, [_vp, _f, _f, _f, _f]),
+    "group_main_loop": (_i, [_vp, _i, _i, _f, _vp, _vp, _ip]),
+    "group_stats": (_i, [_vp, _ip, _ip, _fp]),
 }
 
 

@@ -954,3 +954,4 @@ int mpm_sync(mpm_ctx* ctx) {
 
 #include "mpm_halo.inc"
 #include "mpm_checkpoint.inc"
+#include "mpm_group.inc"

@@ -243,19 +243,45 @@ class MgspRank:
                 self._t["g2p2g"] += self.eng.last_g2p2g_ms()
             self._t["steps"] += 1
 
+    def compute_dt_mgsp(self, max_vel, cur, nxt, dt_default):
+        """compute_dt of the MGSP project (Projects/MGSP/utility_funcs.hpp:32-55): CFL 0.3 and the 0.51 frame-remainder
+        rule, in float32 like the reference."""
+        f = np.float32
+        max_vel, cur, nxt, dt_default = f(max_vel), f(cur), f(nxt), f(dt_default)
+        if nxt < cur:
+            return 0.0
+        dt = dt_default
+        if max_vel > 0:
+            lim = f(f(self.eng.dx) * f(0.3)) / max_vel
+            if lim < dt_default:
+                dt = lim
+        if f(cur + dt) >= nxt:
+            dt = f(nxt - cur)
+        else:
+            rest = f(f(nxt - cur) * f(0.51))
+            if rest < dt:
+                dt = rest
+        return float(dt)
+
     def run_adaptive(self, nsteps, dt0, dt_default, frame_time=1.0 / 24.0):
-        """Adaptive dt as mgsp_benchmark.cuh:410-418: the CFL limit uses the maximum over all ranks."""
+        """Adaptive dt as MgspBenchmark::main_loop (mgsp_benchmark.cuh:375-418): the CFL limit uses the maximum velocity over
+        all ranks, and the step clock restarts with every frame."""
         t, cur, dts = 0.0, dt0, []
         for _ in range(nsteps):
+            assert cur > 0.0, "time step is not positive"
             api, ctx = self.api, self.ctx
             mv2 = C.c_float(0)
             self._check(api.grid_update(ctx, cur, C.byref(mv2)))
             m = torch.tensor([mv2.value], dtype=torch.float32, device=self.tdev)
             self.comm.all_reduce_max(m)   # host max over GPUs in the reference
             mv = float(np.sqrt(m.item()))
-            nd = self.eng.compute_dt(mv, t, frame_time, dt_default)
+            nd = self.compute_dt_mgsp(mv, t + cur, frame_time, dt_default)
+            if not nd > 0.0:  # the frame is complete: first dt of the next one
+                nd = self.compute_dt_mgsp(mv, 0.0, frame_time, dt_default)
             self._advance(cur, nd)
             t += cur
+            if t >= frame_time:
+                t = 0.0
             dts.append(cur)
             cur = nd
         return dts
@@ -283,6 +309,106 @@ class MgspRank:
             dist.all_gather_object(objs, (xyz, st, lj))
             out.append(tuple(np.concatenate([o[i] for o in objs]) for i in range(3)))
         return out
+
+
+class MgspGroupRank:
+    """One rank of the C++ MGSP driver (claymore_amd/csrc/mpm_group.inc): the whole substep loop - grid update, halo-first
+    G2P2G, collect / ncclSend+ncclRecv / reduce on the comm stream beside the interior G2P2G, rebuild, ncclAllGather of
+    the block keys, tagging - runs inside the library with one host synchronisation per substep.  Python only carries
+    the 128-byte RCCL unique id from rank 0 to the others (`bootstrap`: callable(bytes or None) -> bytes)."""
+
+    def __init__(self, scene, rank, world, device=0, bootstrap=None, local_group=None):
+        self.rank, self.world = rank, world
+        self.api = _ffi.load_hip()
+        local = partition_scene(scene, rank, world)
+        self.n_local = scenes.total_particles(local)
+        self.eng = build_engine(local, device=device, api=self.api)
+        self.ctx = self.eng.ctx
+        self.grp = C.c_void_p()
+        if local_group is not None:      # in-process transport: the LocalGroup creates all handles at once
+            local_group.register(rank, self)
+        else:
+            ident = (C.c_char * 128)()
+            if rank == 0:
+                self._check(self.api.group_unique_id(ident))
+            raw = bootstrap(bytes(ident.raw) if rank == 0 else None) if bootstrap else bytes(ident.raw)
+            ident = (C.c_char * 128).from_buffer_copy(raw)
+            self._check(self.api.group_create(self.ctx, rank, world, ident, C.byref(self.grp)))
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.api.group_last_error(self.grp).decode() if self.grp else self.api.last_error(self.ctx).decode()
+            raise EngineError(rc, msg or self.api.last_error(self.ctx).decode())
+
+    def initial_setup(self):
+        self._check(self.api.group_initial_setup(self.grp))
+
+    def substep(self, dt, next_dt):
+        mv = C.c_float(0)
+        self._check(self.api.group_substep(self.grp, dt, next_dt, C.byref(mv)))
+        return mv.value
+
+    def run_fixed(self, nsteps, dt):
+        self._check(self.api.group_run_fixed(self.grp, int(nsteps), dt))
+
+    def main_loop(self, frames, fps, dt_default):
+        n = C.c_int(0)
+        self._check(self.api.group_main_loop(self.grp, int(frames), int(fps), dt_default, None, None, C.byref(n)))
+        return n.value
+
+    def stats(self):
+        sc, nh, ms = (C.c_int * 32)(), C.c_int(0), C.c_float(0)
+        self._check(self.api.group_stats(self.grp, sc, C.byref(nh), C.byref(ms)))
+        return [int(x) for x in sc], nh.value, ms.value
+
+    @property
+    def send_counts(self):
+        return self.stats()[0]
+
+    @property
+    def n_halo_blocks(self):
+        return self.stats()[1]
+
+    @property
+    def g2p2g_ms_avg(self):
+        return self.stats()[2]
+
+    def phase_ms(self):
+        sc, nh, ms = self.stats()
+        return {"g2p2g_ms": ms, "halo_blocks_sent": int(sum(sc)), "halo_particle_blocks": int(nh)}
+
+    def block_counts(self):
+        c = self.eng.counts()
+        return {"particle": c.particle_blocks, "neighbor": c.neighbor_blocks, "exterior": c.exterior_blocks}
+
+    def local_state(self):
+        return [self.eng.retrieve_state(m) for m in range(len(self.eng.models))]
+
+    def close(self):
+        if self.grp:
+            self.api.group_destroy(self.grp)
+            self.grp = C.c_void_p()
+        self.eng.close()
+
+
+class LocalGroup:
+    """All ranks in one process (one thread each) on the library's in-process transport: contexts may share a GPU."""
+
+    def __init__(self, world):
+        self.world, self.ranks = world, [None] * world
+
+    def register(self, rank, r):
+        self.ranks[rank] = r
+
+    def create(self):
+        api = self.ranks[0].api
+        ctxs = (C.c_void_p * self.world)(*[r.ctx for r in self.ranks])
+        out = (C.c_void_p * self.world)()
+        rc = api.group_create_local(ctxs, self.world, out)
+        if rc != 0:
+            raise EngineError(rc, "mpm_group_create_local failed")
+        for r, g in zip(self.ranks, out):
+            r.grp = C.c_void_p(g)
 
 
 class _Null:

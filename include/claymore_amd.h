@@ -259,6 +259,31 @@ int mpm_mgsp_end(mpm_ctx* ctx, int* send_counts, int* halo_particle_blocks, int*
 int mpm_streams(mpm_ctx* ctx, void** compute_stream, void** comm_stream);
 int mpm_sync(mpm_ctx* ctx);
 
+/* ---- MGSP group driver: the multi-GPU substep loop in C++ on RCCL (MgspBenchmark::main_loop, mgsp_benchmark.cuh:361-559;
+ * worker threads issue()/sync() :309-356; tagging :661-720; halo exchange :723-776, halo_buffer.cuh:54-59).  One group
+ * handle per rank, each on its own context.  Transport of mpm_group_create: RCCL (ncclAllGather for the block keys,
+ * ncclGroup{ncclSend, ncclRecv} for the symmetric halo exchange on the context's comm stream, ncclAllReduce(max) for dt);
+ * the caller only has to carry the 128-byte unique id from rank 0 to the other ranks (MPI, a file, torch.distributed ...).
+ * mpm_group_create_local builds `world` handles in ONE process (contexts may share a device) on device-to-device copies:
+ * single-GPU boxes, tests, and hosts that drive all GPUs from worker threads; its calls must be made concurrently, one
+ * thread per rank.  HIP library only. */
+typedef struct mpm_group mpm_group;
+int mpm_group_unique_id(void* id128);
+int mpm_group_create(mpm_ctx* ctx, int rank, int world, const void* id128, mpm_group** out);
+int mpm_group_create_local(mpm_ctx* const* ctxs, int world, mpm_group** out /* [world] */);
+void mpm_group_destroy(mpm_group* g);
+const char* mpm_group_last_error(const mpm_group* g);
+/* initial_setup of every rank + first tagging + one exchange that sums the rasterised grids (mgsp_benchmark.cuh:561-659). */
+int mpm_group_initial_setup(mpm_group* g);
+/* One substep, one host synchronisation; *max_vel_sqr = this rank's max |v|^2 (not reduced over ranks). */
+int mpm_group_substep(mpm_group* g, float dt, float next_dt, float* max_vel_sqr);
+int mpm_group_run_fixed(mpm_group* g, int nsteps, float dt);
+/* compute_dt of the MGSP project (Projects/MGSP/utility_funcs.hpp:32-55): CFL 0.3 and the 0.51 frame-remainder rule. */
+float mpm_group_compute_dt(const mpm_group* g, float max_vel, float cur_time, float next_time, float dt_default);
+/* main_loop with adaptive dt from the maximum grid velocity over all ranks (:410-418); on_frame may be NULL. */
+int mpm_group_main_loop(mpm_group* g, int frames, int fps, float dt_default, void (*on_frame)(int frame, void* user), void* user, int* steps_out);
+int mpm_group_stats(const mpm_group* g, int* send_counts32, int* halo_particle_blocks, float* g2p2g_ms_avg);
+
 #ifdef __cplusplus
 }
 #endif

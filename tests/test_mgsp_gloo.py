@@ -82,9 +82,15 @@ def _single(kind, nsteps, adaptive=False):
     eng.initial_setup()
     dts = None
     if adaptive:
+        # one rank, phase by phase, with the MGSP project's own compute_dt (utility_funcs.hpp:32-55: CFL 0.3, 0.51 rule)
+        from claymore_amd.mgsp import MgspRank
+        rule = MgspRank.compute_dt_mgsp
         t, cur, dts = 0.0, 1e-4, []
         for _ in range(nsteps):
-            nd, mv = eng.substep(cur, t, 1.0 / 24.0, 2e-3)
+            mv = float(np.sqrt(eng.grid_update(cur)))
+            nd = rule(type("E", (), {"eng": eng})(), mv, t + cur, 1.0 / 24.0, 2e-3)
+            eng.g2p2g(cur, nd)
+            eng.rebuild_partition()
             t += cur
             dts.append(cur)
             cur = nd

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from claymore_amd import _ffi, scenes
-from claymore_amd.mgsp import MgspRank
+from claymore_amd.mgsp import LocalGroup, MgspGroupRank, MgspRank
 from parity_util import match, run_engine
 from oracle_ffi import oracle_api
 
@@ -114,3 +114,106 @@ def test_multi_context_equals_oracle(world, kind, phased):
         rel = np.abs(xm[idx].astype(np.float64) - xo).max(axis=1) / np.abs(xo).max(axis=1)
         assert rel.max() < 1e-5, rel.max()
         assert np.abs(sm[idx] - so).max() < 1e-4
+
+
+# ---- the C++ group driver (claymore_amd/csrc/mpm_group.inc) -----------------------------------------------------------
+def _run_group_threads(scene, world, nsteps, dt, adaptive=None):
+    """`world` engine contexts on one GPU, one thread per rank, every substep inside mpm_group_substep (in-process
+    transport: device-to-device copies; the RCCL transport needs one GPU per rank)."""
+    lg = LocalGroup(world)
+    ranks = [MgspGroupRank(scene, r, world, device=0, local_group=lg) for r in range(world)]
+    lg.create()
+    results, errors = [None] * world, []
+
+    def work(rank):
+        try:
+            sim = ranks[rank]
+            sim.initial_setup()
+            shared = 0
+            if adaptive is None:
+                for _ in range(nsteps):
+                    sim.substep(dt, dt)
+                    shared = max(shared, sum(sim.send_counts))
+                steps = nsteps
+            else:
+                steps = sim.main_loop(*adaptive)
+                shared = sum(sim.send_counts)
+            results[rank] = (sim.local_state(), shared, sim.n_halo_blocks, steps)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    for r in ranks:
+        r.close()
+    assert not errors, errors
+    return results
+
+
+def _compare_with_oracle(sc, res, nsteps, dt, tol=1e-5):
+    ora = run_engine(sc, nsteps, dt, api=oracle_api())
+    for m in range(len(sc["models"])):
+        xm = np.concatenate([r[0][m][0] for r in res])
+        sm = np.concatenate([r[0][m][1] for r in res])
+        xo, so, _ = ora["state"][m]
+        assert xm.shape == xo.shape
+        idx, _ = match(xo.astype(np.float64), xm.astype(np.float64))
+        rel = np.abs(xm[idx].astype(np.float64) - xo).max(axis=1) / np.abs(xo).max(axis=1)
+        assert rel.max() < tol, rel.max()
+        assert np.abs(sm[idx] - so).max() < 1e-4
+
+
+@pytest.mark.parametrize("world,kind", [(2, "collide"), (4, "collide"), (3, "sand")])
+def test_cpp_group_equals_oracle(world, kind):
+    if kind == "collide":
+        sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=0.5, speed=2.0, youngs=2e4)
+        nsteps = 60
+    else:
+        sc = scenes.sphere_drop(bits=6, radius_cells=6.0, center=(0.5, 0.3, 0.5), material=_ffi.SAND)
+        sc["models"][0]["params"] = {}
+        nsteps = 30
+    res = _run_group_threads(sc, world, nsteps, 1e-4)
+    assert max(r[1] for r in res) > 0 and max(r[2] for r in res) > 0
+    _compare_with_oracle(sc, res, nsteps, 1e-4)
+
+
+def test_cpp_group_c5_shaped_fluid_dam_8_ranks():
+    """BASELINE config 5 in miniature: a weakly compressible J-fluid dam break (box in a corner of the domain, reference
+    fluid defaults) at bits 8, cut into 8 equal-count slabs, one engine context per rank, all substeps in the C++ driver."""
+    sc = scenes.fluid_dam(bits=8, size_cells=(48, 36, 40), min_corner=(12, 12, 12))
+    nsteps = 40
+    res = _run_group_threads(sc, 8, nsteps, 1e-4)
+    assert sum(r[1] for r in res) > 0 and max(r[2] for r in res) > 0
+    _compare_with_oracle(sc, res, nsteps, 1e-4)
+
+
+def test_rccl_transport_single_rank_equals_plain_engine():
+    """The RCCL code path itself (communicator, ncclAllGather, grouped send / recv, all-reduce) with the one rank a single
+    GPU can host: the result must be the plain single-GPU engine's."""
+    sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=0.5, speed=2.0, youngs=2e4)
+    sim = MgspGroupRank(sc, 0, 1, device=0)
+    sim.initial_setup()
+    sim.run_fixed(30, 1e-4)
+    got = sim.local_state()
+    sim.close()
+    ref = run_engine(sc, 30, 1e-4)
+    for m in range(2):
+        xo = ref["state"][m][0]
+        idx, _ = match(xo.astype(np.float64), got[m][0].astype(np.float64))
+        assert np.abs(got[m][0][idx] - xo).max() < 2e-6
+
+
+def test_cpp_group_adaptive_main_loop_matches_frames():
+    """mpm_group_main_loop: MGSP's compute_dt (CFL 0.3, 0.51 rule) from the maximum velocity over all ranks; two frames."""
+    sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=0.5, speed=2.0, youngs=2e4)
+    res = _run_group_threads(sc, 2, 0, 0.0, adaptive=(2, 240, 1e-4))
+    steps = [r[3] for r in res]
+    assert steps[0] == steps[1] and steps[0] >= 2 * int(round((1 / 240) / 1e-4))
+    n = sum(m["xyz"].shape[0] for m in sc["models"])
+    assert sum(r[0][m][0].shape[0] for r in res for m in range(2)) == n
+    for r in res:
+        for m in range(2):
+            assert np.isfinite(r[0][m][0]).all()
