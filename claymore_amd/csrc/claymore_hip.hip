@@ -303,7 +303,10 @@ const char* mpm_last_error(const mpm_ctx* ctx) {
 }
 
 int mpm_add_model(mpm_ctx* ctx, int material, const mpm_material_params* params, const float* xyz, size_t n, const float v0[3], int* model_id) {
-	if(!ctx || !params || !xyz || ctx->ready) return MPM_ERR_INVALID;
+	if(!ctx) return MPM_ERR_INVALID;
+	if(!params) return fail(ctx, MPM_ERR_INVALID, "mpm_add_model: material parameters are missing");
+	if(ctx->ready) return fail(ctx, MPM_ERR_INVALID, "mpm_add_model: models must be added before mpm_initial_setup");
+	if(!xyz && n) return fail(ctx, MPM_ERR_INVALID, "mpm_add_model: positions are missing");
 	if(material < 0 || material > 3) return fail(ctx, MPM_ERR_INVALID, "unknown material");
 	if((int) ctx->models.size() >= kMaxModels) return fail(ctx, MPM_ERR_CAPACITY, "too many models");
 	HIP_TRY(hipSetDevice(ctx->device));
@@ -315,8 +318,10 @@ int mpm_add_model(mpm_ctx* ctx, int material, const mpm_material_params* params,
 	m.n		   = n;
 	for(int d = 0; d < 3; ++d) m.v0[d] = v0 ? v0[d] : 0.f;
 	HIP_TRY(dalloc(&m.d_xyz, 3 * n));
-	HIP_TRY(hipMemcpyAsync(m.d_xyz, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, ctx->s_compute));
-	HIP_TRY(hipStreamSynchronize(ctx->s_compute));
+	if(n) {// an empty model is legal (an MGSP rank whose slab of a model is empty, an empty sampled SDF)
+		HIP_TRY(hipMemcpyAsync(m.d_xyz, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, ctx->s_compute));
+		HIP_TRY(hipStreamSynchronize(ctx->s_compute));
+	}
 	if(model_id) *model_id = (int) ctx->models.size();
 	ctx->models.push_back(m);
 	return MPM_OK;
@@ -371,13 +376,41 @@ int mpm_initial_setup(mpm_ctx* ctx) {
 	HIP_TRY(hipStreamSynchronize(s));
 	if(pbc > g.cap) return fail(ctx, MPM_ERR_CAPACITY, "Too much active blocks: " + std::to_string(pbc));
 	ctx->pbc = pbc;
-	// final capacity (reference: compile-time G_MAX_ACTIVE_BLOCK, grown by 1.5x on demand, gmpm_simulator.cuh:283-300)
-	size_t cap = ctx->cfg.max_blocks > 0 ? (size_t) ctx->cfg.max_blocks : std::min(table, (size_t) pbc * 6 + 4096);
-	if(cap < (size_t) pbc) return fail(ctx, MPM_ERR_CAPACITY, "max_blocks smaller than the initial particle block count");
+	// neighbours, exterior (gmpm_simulator.cuh:706-734) - registered now, still in the provisional key list, so that the
+	// capacities below can be sized by the exterior block count that is actually there (a compact body has ~1.15 exterior
+	// blocks per particle block, a thin sheet up to 27: sizing by a fixed multiple of pbc wasted 8 GB at C3)
+	if(ctx->cfg.max_blocks <= 0 && (size_t) pbc * 27 > prov) {// the provisional list must hold every block that can be registered
+		int* keys		  = nullptr;
+		const size_t need = std::min(table, (size_t) pbc * 27 + 1);
+		HIP_TRY(dalloc(&keys, 3 * need));
+		HIP_TRY(hipMemcpyAsync(keys, P.keys, sizeof(int) * 3 * (size_t) pbc, hipMemcpyDeviceToDevice, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		HIP_TRY(hipFree(P.keys));
+		P.keys = keys;
+		prov   = need;
+		g.cap  = (int) prov;
+	}
+	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_PBC], P.count, sizeof(int), hipMemcpyDeviceToDevice, s));
+	register_blocks_kernel<0, 1><<<std::max(1u, std::min(4096u, cdiv((size_t) pbc * 8, 256))), 256, 0, s>>>(g, &ctx->d_status[ST_PBC], P.table, P.keys, P.count, ctx->d_status);
+	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_NBC], P.count, sizeof(int), hipMemcpyDeviceToDevice, s));
+	register_blocks_kernel<-1, 1><<<std::max(1u, std::min(8192u, cdiv((size_t) pbc * 32, 256))), 256, 0, s>>>(g, &ctx->d_status[ST_PBC], P.table, P.keys, P.count, ctx->d_status);
+	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_EBC], P.count, sizeof(int), hipMemcpyDeviceToDevice, s));
+	{
+		int rc0 = read_status(ctx);
+		if(rc0) return rc0;
+		rc0 = check_status(ctx);
+		if(rc0) return rc0;
+	}
+	ctx->nbc = ctx->h_status[ST_NBC];
+	ctx->ebc = ctx->h_status[ST_EBC];
+	// final capacity (reference: compile-time G_MAX_ACTIVE_BLOCK, grown by 1.5x on demand, gmpm_simulator.cuh:283-300):
+	// 3/2 of the exterior blocks + slack, i.e. below the 3/4 fill level at which check_capacity() grows it
+	size_t cap = ctx->cfg.max_blocks > 0 ? (size_t) ctx->cfg.max_blocks : std::min(table, (size_t) ctx->ebc * 3 / 2 + 4096);
+	if(cap < (size_t) ctx->ebc) return fail(ctx, MPM_ERR_CAPACITY, "Too much exterior blocks: " + std::to_string(ctx->ebc) + " (max_blocks " + std::to_string(cap) + ")");
 	{
 		int* keys = nullptr;
 		HIP_TRY(dalloc(&keys, 3 * cap));
-		HIP_TRY(hipMemcpyAsync(keys, P.keys, sizeof(int) * 3 * (size_t) pbc, hipMemcpyDeviceToDevice, s));
+		HIP_TRY(hipMemcpyAsync(keys, P.keys, sizeof(int) * 3 * (size_t) ctx->ebc, hipMemcpyDeviceToDevice, s));
 		HIP_TRY(hipStreamSynchronize(s));
 		HIP_TRY(hipFree(P.keys));
 		P.keys = keys;
@@ -409,19 +442,11 @@ int mpm_initial_setup(mpm_ctx* ctx) {
 		}
 		m.list_in = 0;
 	}
-	// neighbours, exterior (gmpm_simulator.cuh:706-734)
-	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_PBC], P.count, sizeof(int), hipMemcpyDeviceToDevice, s));
-	register_blocks_kernel<0, 1><<<std::max(1u, std::min(4096u, cdiv((size_t) pbc * 8, 256))), 256, 0, s>>>(g, &ctx->d_status[ST_PBC], P.table, P.keys, P.count, ctx->d_status);
-	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_NBC], P.count, sizeof(int), hipMemcpyDeviceToDevice, s));
-	register_blocks_kernel<-1, 1><<<std::max(1u, std::min(8192u, cdiv((size_t) pbc * 32, 256))), 256, 0, s>>>(g, &ctx->d_status[ST_PBC], P.table, P.keys, P.count, ctx->d_status);
-	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_EBC], P.count, sizeof(int), hipMemcpyDeviceToDevice, s));
-	int rc = read_status(ctx);
+	int rc = read_status(ctx);// bin totals of the models
 	if(rc) return rc;
 	rc = check_status(ctx);
 	if(rc) return rc;
 	if(ctx->h_status[ST_LOST]) return fail(ctx, MPM_ERR_INVALID, "particles outside the domain at setup");
-	ctx->nbc = ctx->h_status[ST_NBC];
-	ctx->ebc = ctx->h_status[ST_EBC];
 	for(size_t mi = 0; mi < ctx->models.size(); ++mi) {
 		ctx->models[mi].bincount = ctx->h_status[ST_BINS0 + mi];
 		ctx->models[mi].bincount_src = ctx->models[mi].bincount;

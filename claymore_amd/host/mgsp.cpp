@@ -3,9 +3,9 @@
 // per device, MgspBenchmark::main_loop (mgsp_benchmark.cuh:361-559) through the C ABI, frames written as
 // `model_dev[d]_frame[f].bgeo` (mgsp_benchmark.cuh:582-585).
 //
-// This is the in-process variant (the reference's structure: one process, N devices); halo blocks travel with
-// hipMemcpyPeerAsync over xGMI between staging buffers, exactly where the reference uses cudaMemcpyPeerAsync
-// (halo_buffer.cuh:54-59).  The one-process-per-GPU RCCL variant is claymore_amd/mgsp.py.
+// The reference's structure: one process, N devices, one worker thread per device (mgsp_benchmark.cuh:309-356).  Each
+// worker drives the library's MGSP loop (mpm_group_*, claymore_amd/csrc/mpm_group.inc): halo blocks travel with grouped
+// RCCL send / recv over xGMI where the reference uses cudaMemcpyPeerAsync (halo_buffer.cuh:54-59).
 //
 //   mgsp [--devices N] [--scenario 2|3] [--bits B] [--frames F] [--fps R] [--same-device] [--out DIR]
 //        [--boundary PREFIX [--boundary-type sticky|slip|separate] [--friction MU]]
@@ -15,11 +15,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/claymore_amd.h"
@@ -37,15 +40,7 @@
 struct Dev {
 	int gpu		 = 0;
 	mpm_ctx* ctx = nullptr;
-	hipStream_t compute = nullptr, comm = nullptr;
-	size_t n = 0;
-	int* keys_out = nullptr;// this device's neighbor keys (staging for the "all-gather")
-	std::vector<int*> keys_in;// per peer: that peer's keys, copied here
-	std::vector<int*> send_k, recv_k;
-	std::vector<float*> send_b, recv_b;
-	std::vector<int> send_n;
-	size_t cap_blocks = 0;
-	hipEvent_t sent;
+	size_t n	 = 0;
 };
 
 static void check(Dev& d, int rc) {
@@ -53,23 +48,6 @@ static void check(Dev& d, int rc) {
 		std::fprintf(stderr, "mgsp[%d]: status %d: %s\n", d.gpu, rc, mpm_last_error(d.ctx));
 		std::exit(EXIT_FAILURE);
 	}
-}
-
-// compute_dt of the MGSP project (Projects/MGSP/utility_funcs.hpp:32-55): CFL 0.3 and the 0.51 frame-remainder rule
-static float compute_dt_mgsp(float max_vel, float cur, float next, float dt_default, float dx) {
-	if(next < cur) return 0.f;
-	float dt = dt_default;
-	if(max_vel > 0.f) {
-		max_vel = dx * 0.3f / max_vel;
-		if(max_vel < dt_default) dt = max_vel;
-	}
-	if(cur + dt >= next) {
-		dt = next - cur;
-	} else {
-		max_vel = (next - cur) * 0.51f;
-		if(max_vel < dt) dt = max_vel;
-	}
-	return dt;
 }
 
 int main(int argc, char** argv) {
@@ -158,146 +136,65 @@ int main(int argc, char** argv) {
 		for(auto& D: devs) check(D, mpm_set_collision_object(D.ctx, &obj, field[0].data(), field[1].data(), field[2].data(), field[3].data()));
 		std::printf("[Collision Object] %s, %s\n", boundary.c_str(), boundary_type.c_str());
 	}
-	for(auto& D: devs) check(D, mpm_initial_setup(D.ctx));
-	// staging buffers sized by the block capacity implied by the initial counts
-	for(auto& D: devs) {
-		HIPCHK(hipSetDevice(D.gpu));
-		void *cs, *ms;
-		mpm_streams(D.ctx, &cs, &ms);
-		D.compute = (hipStream_t) cs;
-		D.comm	  = (hipStream_t) ms;
-		mpm_counts c;
-		mpm_get_counts(D.ctx, &c);
-		D.cap_blocks = (size_t) c.exterior_blocks * 4 + 4096;
-		HIPCHK(hipMalloc((void**) &D.keys_out, sizeof(int) * 3 * D.cap_blocks));
-		D.keys_in.assign(ndev, nullptr);
-		D.send_k.assign(ndev, nullptr);
-		D.recv_k.assign(ndev, nullptr);
-		D.send_b.assign(ndev, nullptr);
-		D.recv_b.assign(ndev, nullptr);
-		D.send_n.assign(ndev, 0);
-		HIPCHK(hipEventCreateWithFlags(&D.sent, hipEventDisableTiming));
+	// One worker thread per device, as the reference (mgsp_benchmark.cuh:309-356), each driving the library's MGSP loop
+	// (mpm_group_main_loop: halo-first G2P2G, grouped RCCL send / recv beside the interior G2P2G, all-gather of block keys,
+	// adaptive dt from the maximum velocity over all devices).  --same-device puts all contexts on GPU 0 over the in-process
+	// transport (functional runs on a single-GPU box).
+	std::vector<mpm_group*> groups(ndev, nullptr);
+	unsigned char ident[128] = {};
+	if(same) {
+		std::vector<mpm_ctx*> ctxs;
+		for(auto& D: devs) ctxs.push_back(D.ctx);
+		if(mpm_group_create_local(ctxs.data(), ndev, groups.data()) != MPM_OK) {
+			std::fprintf(stderr, "mpm_group_create_local failed\n");
+			return 1;
+		}
+	} else if(mpm_group_unique_id(ident) != MPM_OK) {
+		std::fprintf(stderr, "RCCL is not available\n");
+		return 1;
 	}
-	size_t cap_all = 0;
-	for(auto& D: devs) cap_all = std::max(cap_all, D.cap_blocks);
-	for(int d = 0; d < ndev; ++d)
-		for(int p = 0; p < ndev; ++p) {
-			if(p == d) continue;
-			HIPCHK(hipSetDevice(devs[d].gpu));
-			HIPCHK(hipMalloc((void**) &devs[d].keys_in[p], sizeof(int) * 3 * cap_all));
-			HIPCHK(hipMalloc((void**) &devs[d].send_k[p], sizeof(int) * 3 * cap_all));
-			HIPCHK(hipMalloc((void**) &devs[d].recv_k[p], sizeof(int) * 3 * cap_all));
-			HIPCHK(hipMalloc((void**) &devs[d].send_b[p], sizeof(float) * 256 * cap_all));
-			HIPCHK(hipMalloc((void**) &devs[d].recv_b[p], sizeof(float) * 256 * cap_all));
-			if(!same) {
-				int can = 0;
-				if(hipDeviceCanAccessPeer(&can, devs[d].gpu, devs[p].gpu) != hipSuccess) can = 0;
-				if(can) (void) hipDeviceEnablePeerAccess(devs[p].gpu, 0);// Cuda.cu:120-127 (already-enabled is not an error worth reporting)
-			}
-		}
-
-	// halo_tagging, mgsp_benchmark.cuh:661-720
-	auto tag = [&]() {
-		std::vector<int> nb(ndev);
-		for(int d = 0; d < ndev; ++d) check(devs[d], mpm_halo_keys(devs[d].ctx, devs[d].keys_out, (int) devs[d].cap_blocks, &nb[d]));
-		for(int d = 0; d < ndev; ++d) {
-			if((size_t) nb[d] > cap_all) {
-				std::fprintf(stderr, "halo key buffer too small\n");
-				std::exit(EXIT_FAILURE);
-			}
-			check(devs[d], mpm_sync(devs[d].ctx));
-		}
-		for(int d = 0; d < ndev; ++d)
-			for(int p = 0; p < ndev; ++p)
-				if(p != d) HIPCHK(hipMemcpyPeer(devs[d].keys_in[p], devs[d].gpu, devs[p].keys_out, devs[p].gpu, sizeof(int) * 3 * (size_t) nb[p]));
-		for(int d = 0; d < ndev; ++d) {
-			Dev& D = devs[d];
-			check(D, mpm_halo_tag_begin(D.ctx));
-			for(int p = 0; p < ndev; ++p)
-				if(p != d) check(D, mpm_halo_tag_peer(D.ctx, p, D.keys_in[p], nb[p]));
-			int nh, sc[32];
-			check(D, mpm_halo_tag_end(D.ctx, &nh, sc));
-			for(int p = 0; p < ndev; ++p) D.send_n[p] = p == d ? 0 : sc[p];
-		}
-	};
-	// collect_halo_grid_blocks / reduce_halo_grid_blocks, mgsp_benchmark.cuh:723-776
-	auto exchange_begin = [&](int gid) {
-		for(int d = 0; d < ndev; ++d) {
-			Dev& D = devs[d];
-			HIPCHK(hipSetDevice(D.gpu));
-			for(int p = 0; p < ndev; ++p) {
-				const int n = D.send_n[p];
-				if(p == d || n == 0) continue;
-				int ns;
-				check(D, mpm_halo_collect(D.ctx, p, gid, D.send_k[p], D.send_b[p], (int) cap_all, &ns));
-				HIPCHK(hipMemcpyPeerAsync(devs[p].recv_k[d], devs[p].gpu, D.send_k[p], D.gpu, sizeof(int) * 3 * (size_t) n, D.comm));
-				HIPCHK(hipMemcpyPeerAsync(devs[p].recv_b[d], devs[p].gpu, D.send_b[p], D.gpu, sizeof(float) * 256 * (size_t) n, D.comm));
-			}
-			HIPCHK(hipEventRecord(D.sent, D.comm));
-		}
-	};
-	auto exchange_end = [&](int gid) {
-		for(int d = 0; d < ndev; ++d) {
-			Dev& D = devs[d];
-			HIPCHK(hipSetDevice(D.gpu));
-			bool any = false;
-			for(int p = 0; p < ndev; ++p) {
-				if(p == d) continue;
-				const int n = devs[p].send_n[d];// what p sent to me (== what I sent to p: the relation is symmetric)
-				if(n == 0) continue;
-				HIPCHK(hipStreamWaitEvent(D.comm, devs[p].sent, 0));
-				check(D, mpm_halo_reduce(D.ctx, gid, D.recv_k[p], D.recv_b[p], n));
-				any = true;
-			}
-			if(!any) check(D, mpm_halo_reduce(D.ctx, gid, nullptr, nullptr, 0));
-		}
-	};
-
-	tag();
-	exchange_begin(0);// initial rasterised grids are summed once (mgsp_benchmark.cuh:653-654)
-	exchange_end(0);
-	for(auto& D: devs) check(D, mpm_sync(D.ctx));
-
-	// main_loop, mgsp_benchmark.cuh:361-559
-	const float dt_default = 1e-4f, spf = 1.f / (float) fps;
-	float dt   = compute_dt_mgsp(0.f, 0.f, spf, dt_default, dx);
-	long steps = 0;
-	std::vector<float> buf;
 	pio::AsyncWriter io;
-	for(int frame = 1; frame <= frames; ++frame) {
-		for(float t = 0.f; t < spf;) {
-			float maxv2 = 0.f;
-			for(auto& D: devs) {
-				float m;
-				check(D, mpm_grid_update(D.ctx, dt, &m));
-				maxv2 = std::max(maxv2, m);// host max over GPUs, :410-416
-			}
-			if(std::isinf(maxv2)) {
-				std::printf("Maximum velocity is infinity\n");
-				return 1;
-			}
-			const float next_dt = compute_dt_mgsp(std::sqrt(maxv2), t, spf, dt_default, dx);
-			for(auto& D: devs) check(D, mpm_g2p2g_halo(D.ctx, dt, next_dt));
-			exchange_begin(1);
-			for(auto& D: devs) check(D, mpm_g2p2g_interior(D.ctx, dt, next_dt));// overlaps with the peer copies
-			exchange_end(1);
-			for(auto& D: devs) check(D, mpm_rebuild_partition(D.ctx, nullptr));
-			tag();
-			t += dt;
-			dt = next_dt;
-			++steps;
-		}
-		for(int d = 0; d < ndev; ++d) {// output_model, :565-591
+	std::mutex io_mutex;
+	std::atomic<int> failed {0};
+	struct FrameCtx {
+		Dev* D;
+		int d;
+		const std::string* out;
+		pio::AsyncWriter* io;
+		std::mutex* m;
+	};
+	auto on_frame = [](int frame, void* user) {// output_model, mgsp_benchmark.cuh:565-591
+		FrameCtx* F = static_cast<FrameCtx*>(user);
+		std::vector<float> buf(3 * F->D->n);
+		size_t n = F->D->n;
+		if(mpm_retrieve_positions(F->D->ctx, 0, buf.data(), &n) != MPM_OK) return;
+		std::lock_guard<std::mutex> lk(*F->m);
+		std::printf("total number of particles %zu\n", n);
+		F->io->write_bgeo_async(*F->out + "/model_dev[" + std::to_string(F->d) + "]_frame[" + std::to_string(frame) + "].bgeo", buf, n);// IO::insert_job, :586-590
+	};
+	std::vector<std::thread> workers;
+	std::vector<int> steps(ndev, 0);
+	for(int d = 0; d < ndev; ++d)
+		workers.emplace_back([&, d] {
 			Dev& D = devs[d];
-			buf.resize(3 * D.n);
-			size_t n = D.n;
-			check(D, mpm_retrieve_positions(D.ctx, 0, buf.data(), &n));
-			std::printf("total number of particles %zu\n", n);
-			io.write_bgeo_async(out + "/model_dev[" + std::to_string(d) + "]_frame[" + std::to_string(frame) + "].bgeo", buf, n);// IO::insert_job, mgsp_benchmark.cuh:586-590
-		}
-		std::printf("frame %d done after %ld substeps\n", frame, steps);
-	}
+			if(!same && mpm_group_create(D.ctx, d, ndev, ident, &groups[d]) != MPM_OK) {
+				std::fprintf(stderr, "device %d: %s\n", d, mpm_last_error(D.ctx));
+				failed = 1;
+				return;
+			}
+			FrameCtx F {&D, d, &out, &io, &io_mutex};
+			int rc = mpm_group_initial_setup(groups[d]);
+			if(rc == MPM_OK) rc = mpm_group_main_loop(groups[d], frames, fps, 1e-4f, on_frame, &F, &steps[d]);
+			if(rc != MPM_OK) {
+				std::fprintf(stderr, "device %d: status %d: %s\n", d, rc, mpm_group_last_error(groups[d]));
+				failed = 1;
+			}
+		});
+	for(auto& w: workers) w.join();
+	if(failed) return 1;
+	std::printf("%d frames done after %d substeps\n", frames, steps[0]);
 	io.flush();
+	for(auto* g: groups) mpm_group_destroy(g);
 	for(auto& D: devs) mpm_destroy(D.ctx);
 	return 0;
 }
