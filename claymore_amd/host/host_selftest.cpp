@@ -7,6 +7,15 @@
 #include "particle_io.hpp"
 
 int main(int argc, char** argv) {
+	if(argc == 4 && !std::strcmp(argv[1], "--bgeo-from")) {// host_selftest --bgeo-from points.f32 out.bgeo: raw float32 xyz -> BGEO frame
+		std::ifstream in(argv[2], std::ios::binary | std::ios::ate);
+		if(!in) return 3;
+		const size_t bytes = (size_t) in.tellg();
+		std::vector<float> xyz(bytes / sizeof(float));
+		in.seekg(0);
+		in.read(reinterpret_cast<char*>(xyz.data()), (std::streamsize) bytes);
+		return pio::write_bgeo(argv[3], xyz.data(), xyz.size() / 3) ? 0 : 4;
+	}
 	const char* text = R"({"simulation": {"gpuid": 0, "fps": 1200, "frames": 2, "default_dt": 5e-6},
 	  "models": [{"type": "particle", "file": "two_dragons.sdf", "constitutive": "jfluid", "offset": [0.1, 0.1, 0.1],
 	              "span": [1.0, 1.0, 1.0], "velocity": [0.0, -1.0, 0.0], "nested": {"a": [true, false, null, "s\"q"]}},

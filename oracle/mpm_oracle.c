@@ -108,6 +108,12 @@ int mpmo_default_config(int domain_bits, mpm_config* cfg) {
 	return MPM_OK;
 }
 
+/* oracle-only experiment knob (tools/sand_drift_study.py): converged double-precision SVD instead of the reference's */
+int mpmo_set_exact_svd(int on) {
+	orc_exact_svd_enabled = on ? 1 : 0;
+	return MPM_OK;
+}
+
 /* oracle-only: OpenMP threads for G2P2G (bench.py cpu_baseline); 1 restores the deterministic serial order */
 int mpmo_set_threads(mpmo_ctx* c, int n) {
 	if(!c || n < 1) return MPM_ERR_INVALID;

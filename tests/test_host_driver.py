@@ -42,6 +42,24 @@ def test_host_selftest(tmp_path):
     assert np.array_equal(read_bgeo(str(tmp_path / "t.bgeo") + ".async7"), pts)
 
 
+def test_bgeo_writer_equals_partio_byte_for_byte(tmp_path):
+    """tests/golden/g10_partio.bgeo was written by the reference's own partio library (Externals/partio compiled from its
+    sources by tests/golden/gen/gen_bgeo.sh) through the calls of write_partio (Library/MnSystem/IO/ParticleIO.hpp:14-29);
+    the host drivers' writer must produce the same bytes from the same points."""
+    exe = tmp_path / "host_selftest"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-o", str(exe), os.path.join(HOST, "host_selftest.cpp")])
+    gold = os.path.join(ROOT, "tests", "golden")
+    out = tmp_path / "mine.bgeo"
+    subprocess.check_call([str(exe), "--bgeo-from", os.path.join(gold, "g10_points.f32"), str(out)])
+    want = open(os.path.join(gold, "g10_partio.bgeo"), "rb").read()
+    got = open(out, "rb").read()
+    assert len(got) == len(want) == 41 + 16 * 1000 + 2
+    assert got == want
+    # and the reader used by the other tests understands partio's file
+    pts = read_bgeo(os.path.join(gold, "g10_partio.bgeo"))
+    assert np.array_equal(pts, np.fromfile(os.path.join(gold, "g10_points.f32"), dtype=np.float32).reshape(-1, 3))
+
+
 @pytest.mark.gpu
 def test_gmpm_executable_matches_engine(tmp_path):
     import __graft_entry__ as g
@@ -75,6 +93,88 @@ def test_gmpm_executable_matches_engine(tmp_path):
             assert a.shape == b.shape
             idx, _ = match(a.astype(np.float64), b.astype(np.float64))
             assert np.abs(a - b[idx]).max() < 1e-6
+    eng.close()
+
+
+def _sample_sdf_numpy(sdf_path, bits, offset, span):
+    """Independent restatement of the level-set branch of sample_model (gmpm.cu:60-165, ParticleIO.hpp:32-70 as re-specified
+    in SURVEY f2): lattice particles (8 per node at +-0.25 dx) where the trilinear interpolation of phi is negative; the level
+    set box is scaled uniformly into `span` and moved to `offset`."""
+    tok = open(sdf_path).read().split()
+    n = [int(t) for t in tok[:3]]
+    mn = np.array([float(t) for t in tok[3:6]], dtype=np.float32)
+    sdx = np.float32(tok[6])
+    phi = np.array(tok[7:], dtype=np.float32).reshape(n[2], n[1], n[0]).transpose(2, 1, 0)
+    dx = np.float32(1.0 / (1 << bits))
+    offset, span = np.array(offset, dtype=np.float32), np.array(span, dtype=np.float32)
+    ext = np.array(n, dtype=np.float32) * sdx - mn
+    scale = np.float32((span / ext).min())
+    lo = np.floor(offset / dx).astype(int) - 1
+    hi = np.ceil((offset + span) / dx).astype(int) + 2
+    pts = scenes.lattice_box(bits, lo, hi)
+    q = (pts - offset) / scale + mn
+    g = (q - mn) / sdx
+    c = np.floor(g).astype(int)
+    t = g - c
+    ok = np.all((c >= 0) & (c + 1 < np.array(n)), axis=1)
+    cc = np.clip(c, 0, np.array(n) - 2)
+    r = np.zeros(len(pts), dtype=np.float32)
+    for a in (0, 1):
+        for b in (0, 1):
+            for e in (0, 1):
+                w = (t[:, 0] if a else 1 - t[:, 0]) * (t[:, 1] if b else 1 - t[:, 1]) * (t[:, 2] if e else 1 - t[:, 2])
+                r += w.astype(np.float32) * phi[cc[:, 0] + a, cc[:, 1] + b, cc[:, 2] + e]
+    return pts[ok & (r < 0)]
+
+
+@pytest.mark.gpu
+def test_gmpm_executable_matches_oracle_with_level_set_model(tmp_path):
+    """The `gmpm` executable end to end against the CPU ORACLE driven through the same scene: one analytic sphere
+    (fixed-corotated) and one model sampled from a text level set (tests/golden/g11_ball.sdf, the *.sdf branch of
+    sample_model), two output frames with adaptive dt."""
+    import shutil
+    import __graft_entry__ as g
+    g.build_host()
+    from claymore_amd import _ffi
+    from claymore_amd.engine import Engine
+    from oracle_ffi import oracle_api
+    from parity_util import match
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "g11_ball.sdf"), tmp_path / "ball.sdf")
+    vol = float(np.float32((1 / 64) ** 3 / 8))
+    scene = {
+        "simulation": {"gpuid": 0, "fps": 500, "frames": 2, "default_dt": 1e-4, "domain_bits": 6, "output_dir": str(tmp_path)},
+        "models": [
+            {"file": "sphere", "constitutive": "fixed_corotated", "rho": 1e3, "volume": vol, "youngs_modulus": 5e3, "poisson_ratio": 0.4,
+             "offset": [0.34375, 0.421875, 0.421875], "span": [0.15625] * 3, "velocity": [0.5, 0, 0]},
+            {"file": "ball.sdf", "constitutive": "fixed_corotated", "rho": 1e3, "volume": vol, "youngs_modulus": 5e3, "poisson_ratio": 0.4,
+             "offset": [0.53125, 0.40625, 0.40625], "span": [0.1875] * 3, "velocity": [-0.5, 0, 0]},
+        ],
+    }
+    fn = tmp_path / "scene.json"
+    fn.write_text(json.dumps(scene))
+    subprocess.check_output([os.path.join(HOST, "gmpm"), "-f", str(fn)], text=True)
+    p0 = read_bgeo(tmp_path / "model_id[0]_frame[0].bgeo")
+    p1 = read_bgeo(tmp_path / "model_id[1]_frame[0].bgeo")
+    # the level-set sampler against an independent numpy evaluation of the same rule
+    want = _sample_sdf_numpy(tmp_path / "ball.sdf", 6, scene["models"][1]["offset"], scene["models"][1]["span"])
+    assert p1.shape == want.shape and p1.shape[0] > 500
+    idx, _ = match(want.astype(np.float64), p1.astype(np.float64))
+    assert np.array_equal(p1[idx], want)
+    # the same scene through the oracle
+    eng = Engine(domain_bits=6, max_ppc=32, api=oracle_api())
+    prm = dict(volume=vol, rho=1e3, youngs_modulus=5e3, poisson_ratio=0.4)
+    eng.init_model(_ffi.FIXED_COROTATED, p0, (0.5, 0, 0), **prm)
+    eng.init_model(_ffi.FIXED_COROTATED, p1, (-0.5, 0, 0), **prm)
+    frames = {}
+    eng.main_loop(2, 500, 1e-4, on_frame=lambda f, e: frames.update({f: [e.retrieve_positions(0), e.retrieve_positions(1)]}))
+    for f in (1, 2):
+        for m in (0, 1):
+            a = read_bgeo(tmp_path / f"model_id[{m}]_frame[{f}].bgeo")
+            b = frames[f][m]
+            assert a.shape == b.shape
+            idx, _ = match(a.astype(np.float64), b.astype(np.float64))
+            rel = np.abs(a.astype(np.float64) - b[idx]).max(axis=1) / np.abs(a).max(axis=1)
+            assert rel.max() < 1e-5, rel.max()
     eng.close()
 
 

@@ -74,45 +74,95 @@ def test_device_svd_vs_reference_golden():
     assert (np.sign(Sg[big, 2]) == np.sign(det[big])).all()
 
 
+def _lame(p):
+    e, nu = np.float32(p.youngs_modulus), np.float32(p.poisson_ratio)
+    return float(e / (2 * (1 + nu))), float(e * nu / ((1 + nu) * (1 - 2 * nu)))
+
+
 def test_device_fixed_corotated_vs_reference_golden():
+    """P F^T of the fixed-corotated model against (1) the reference's golden output and (2) the float64 closed form.
+    The reference's float result carries the residual of its approximate 4-sweep SVD (up to 3.5e-4 of the stiffness scale
+    vol * E on these inputs); the device's symmetric eigen-decomposition converges, so the device must be (a) within 1e-5 of
+    vol * E of the exact stress on every well-conditioned input (classes 0-5) and (b) never further from the truth than
+    twice the reference itself."""
+    import exact_models as X
     hip = _ffi.load_hip()
     F = f32("g3_F_in.f32")
     n = F.size // 9
-    want = f32("g4_fc_out.f32").reshape(n, 9)
+    want = f32("g4_fc_out.f32").reshape(n, 9).astype(np.float64)
     got = np.empty((n, 19), dtype=np.float32)
-    assert hip.test_stress(_ffi.FIXED_COROTATED, C.byref(_params(_ffi.FIXED_COROTATED)), ptr(F), None, n, ptr(got), 0) == 0
-    scale = np.abs(want).max(axis=1, keepdims=True) + 1e-30
-    # stress of near-singular / reflected F amplifies the SVD's rounding; the physically relevant classes
-    # (0: near identity, 1: moderate strain, 2: rotation) must agree to 1e-4 of the stress magnitude
-    rel = (np.abs(got[:, 9:18] - want) / scale).max(axis=1)
+    p = _params(_ffi.FIXED_COROTATED)
+    assert hip.test_stress(_ffi.FIXED_COROTATED, C.byref(p), ptr(F), None, n, ptr(got), 0) == 0
+    mu, lam = _lame(p)
+    exact = X.fixed_corotated(F.reshape(n, 9), mu, lam, p.volume)
+    scale = p.volume * p.youngs_modulus
+    e_dev = np.abs(got[:, 9:18] - exact).max(axis=1) / scale
+    e_ref = np.abs(want - exact).max(axis=1) / scale
     cls = np.arange(n) % 8
-    # (the 4-sweep Jacobi SVD is approximate by design, so its residual - and with it the stress - moves by up
-    # to ~1e-3 under a different but equally valid rounding sequence; the bulk must agree much better)
-    assert np.quantile(rel[cls <= 2], 0.95) < 3e-4 and rel[cls <= 2].max() < 5e-3
-    assert np.median(rel) < 1e-5
+    ok = cls <= 5
+    assert e_dev[ok].max() < 1e-5, e_dev[ok].max()
+    assert (e_dev[ok] <= 2.0 * e_ref[ok] + 3e-6).all()
+    assert np.median(e_dev) < 1e-6
+    # near-singular / reflected inputs (classes 6, 7): same order as the reference
+    assert e_dev[~ok].max() <= max(2.0 * e_ref[~ok].max(), 1e-4)
 
 
-@pytest.mark.parametrize("material,fin,fout", [(_ffi.SAND, "g5_sand_logjp_in.f32", "g5_sand_out.f32"), (_ffi.NACC, "g6_nacc_logjp_in.f32", "g6_nacc_out.f32")])
-def test_device_plastic_models_vs_reference_golden(material, fin, fout):
+def test_device_sand_vs_reference_golden_and_closed_form():
+    """Drucker-Prager return mapping: projected F, P F^T and log Jp against the float64 closed form, with the reference's
+    own golden output as the yardstick (see the fixed-corotated test)."""
+    import exact_models as X
     hip = _ffi.load_hip()
     F = f32("g3_F_in.f32").reshape(-1, 9)
     n = F.shape[0]
-    lj = f32(fin)
-    want = f32(fout).reshape(n, 19)
+    lj = f32("g5_sand_logjp_in.f32")
+    want = f32("g5_sand_out.f32").reshape(n, 19).astype(np.float64)
     idx = np.arange(n)
-    # use the generator's default-parameter subset (cohesion 0 / volume_correction on / hardening on)
-    sel = np.where((idx % 5 != 4) & (idx % 7 != 6))[0]
-    p = _params(material)
+    sel = np.where((idx % 5 != 4) & (idx % 7 != 6))[0]      # the generator's default-parameter subset
+    p = _params(_ffi.SAND)
     Fi, li = np.ascontiguousarray(F[sel]), np.ascontiguousarray(lj[sel])
     got = np.empty((sel.size, 19), dtype=np.float32)
-    assert hip.test_stress(material, C.byref(p), ptr(Fi), ptr(li), sel.size, ptr(got), 0) == 0
+    assert hip.test_stress(_ffi.SAND, C.byref(p), ptr(Fi), ptr(li), sel.size, ptr(got), 0) == 0
+    mu, lam = _lame(p)
+    exF, exPF, exL = X.sand(Fi, li, mu, lam, p.volume, p.cohesion, p.beta, p.yield_surface, p.volume_correction)
+    w = want[sel]
+    scale = p.volume * p.youngs_modulus
+    cls = sel % 8
+    ok = (cls <= 5) & np.isfinite(w).all(axis=1)
+    e_dev = np.abs(got[:, 9:18] - exPF).max(axis=1) / scale
+    e_ref = np.abs(w[:, 9:18] - exPF).max(axis=1) / scale
+    assert e_dev[ok].max() < 1e-5, e_dev[ok].max()
+    assert (e_dev[ok] <= 2.0 * e_ref[ok] + 3e-6).all()
+    f_dev = np.abs(got[:, 0:9] - exF).max(axis=1)
+    f_ref = np.abs(w[:, 0:9] - exF).max(axis=1)
+    assert f_dev[ok].max() < 5e-6, f_dev[ok].max()
+    assert (f_dev[ok] <= 2.0 * f_ref[ok] + 2e-6).all()
+    assert np.abs(got[ok, 18] - exL[ok]).max() < 2e-6
+    assert np.abs(got[ok, 18] - w[ok, 18]).max() < 1e-5
+
+
+def test_device_nacc_vs_reference_golden():
+    """NACC (flagged unstable in the reference, constitutive_models.cuh:80): bulk agreement with the golden output."""
+    hip = _ffi.load_hip()
+    F = f32("g3_F_in.f32").reshape(-1, 9)
+    n = F.shape[0]
+    lj = f32("g6_nacc_logjp_in.f32")
+    want = f32("g6_nacc_out.f32").reshape(n, 19)
+    idx = np.arange(n)
+    sel = np.where((idx % 5 != 4) & (idx % 7 != 6))[0]
+    p = _params(_ffi.NACC)
+    Fi, li = np.ascontiguousarray(F[sel]), np.ascontiguousarray(lj[sel])
+    got = np.empty((sel.size, 19), dtype=np.float32)
+    assert hip.test_stress(_ffi.NACC, C.byref(p), ptr(Fi), ptr(li), sel.size, ptr(got), 0) == 0
     w = want[sel]
     fin_rows = np.isfinite(w).all(axis=1)
     cls = sel % 8
     good = fin_rows & (cls <= 5)
+    assert np.isfinite(got[good]).all()
     relF = np.abs(got[good, 0:9] - w[good, 0:9]).max(axis=1) / np.maximum(1.0, np.abs(w[good, 0:9]).max(axis=1))
-    assert np.median(relF) < 1e-5 and np.quantile(relF, 0.99) < 1e-3
-    assert np.median(np.abs(got[good, 18] - w[good, 18])) < 1e-5
+    assert np.median(relF) < 1e-6 and np.quantile(relF, 0.99) < 1e-4
+    assert np.median(np.abs(got[good, 18] - w[good, 18])) < 1e-6 and np.quantile(np.abs(got[good, 18] - w[good, 18]), 0.99) < 1e-4
+    eE = np.abs(got[good, 9:18] - w[good, 9:18]).max(axis=1) / (p.volume * p.youngs_modulus)
+    assert np.quantile(eE, 0.99) < 1e-4
 
 
 @pytest.mark.parametrize("nsteps", [1, 10, 100])
@@ -408,13 +458,13 @@ def test_single_particle_and_tiny_models_parity():
 
 
 def test_long_run_sand_stays_close_to_the_oracle():
-    """500 substeps of a 9.7 k-particle sand column.  Plastic flow amplifies rounding differences (yield branches flip for
-    particles on the cone surface), so the 1e-5 bound of the short runs is relaxed here: the error grows smoothly
-    (6e-7 after 100 substeps, 9e-6 after 300, 2e-5 after 500) - the same with libm logf/expf instead of v_log/v_exp, i.e.
-    it is the summation order / SVD rounding sequence, not an approximation, that separates the two trajectories."""
+    """500 substeps of a 9.7 k-particle sand column with plastic flow: north_star's 1e-5 holds here too.  (Round 1 needed
+    5e-5: its device SVD was the source.  With the eigen-decomposition of round 2 the engine stays within 3e-7 of the oracle,
+    the level at which two runs of the oracle itself separate when only the summation order of the grid accumulation is
+    permuted - tools/sand_drift_study.py, profiles/r02_sand_drift_study.txt.)"""
     sc = scenes.scaled_sand_column(7, 1.0 / 64)
     res = run_pair(sc, 500, sc["dt"])
     err = match_and_compare(res)
     assert err["n"] == scenes.total_particles(sc)
-    assert err["pos_rel"] < 5e-5, err
+    assert err["pos_rel"] < 2e-6, err
     assert err["grid_mass_rel"] < 1e-6, err
