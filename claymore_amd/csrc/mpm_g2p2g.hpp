@@ -5,15 +5,18 @@
 // instruction only every ~4.5-5 cycles (8.9 when it depends on the previous one) while the SIMD itself takes one every
 // ~1.6 (VOP2 / fma) to ~2.7 cycles (packed fp32, SGPR operands, min/max/cmp).  With two waves per SIMD - the round-1
 // kernel: 256 VGPRs, 17.8 KiB of LDS per wave - the SIMD idles most of the time no matter how the instructions are
-// ordered.  This kernel is therefore built to run FOUR waves per SIMD:
-//   * <= 128 VGPRs: the P2G scatter is no longer threaded through the next particle's arithmetic (that software pipeline
-//     cost ~40 live registers to hide the LDS latency inside one wave; with four waves the other waves hide it);
-//   * <= 9 KiB of LDS per wave: the advection records are read straight from global memory (prepare_blocks_kernel left
-//     them sorted), and BOTH arenas hold only nodes 1..6 of the 8^3 node cube around the block.  The gather never touches
-//     nodes 0 and 7; the scatter does only for particles that have just crossed into a neighbouring block (a few per cent
-//     in fast flows, none at rest): those lanes send the shell part of their stencil straight to the grid with global
-//     atomics (p2g_serial);
+// ordered.  This kernel is therefore built for three to four waves per SIMD:
+//   * 128-168 VGPRs: the P2G scatter chain of the previous particle is threaded through the material update only (the
+//     round-1 pipeline through the gather as well cost ~40 more live registers), the gather keeps one z-pencil of loads in
+//     flight, its results are pinned where they are produced;
+//   * 10.8 KiB of LDS per wave (15 workgroups per CU): the advection records are read straight from global memory
+//     (prepare_blocks_kernel left them sorted), the block's look-up row stays in a register (ds_bpermute), and ALL arenas
+//     hold only nodes 1..6 of the 8^3 node cube around the block.  The gather never touches nodes 0 and 7; the scatter
+//     does only for particles that have just crossed into a neighbouring block (2 % in a collapsing column, none at rest):
+//     those lanes go through p2g_serial, which sends the shell part of a stencil to the grid with global atomics;
 //   * the per-particle math needs only U and sigma (sym_eig3 in mpm_device_math.hpp), not a full SVD.
+// Measured on C3 (profiles/r02_*): three waves with the record prefetch a whole iteration ahead beat four waves with a late
+// prefetch by 5 %; two, three and four waves are within 3 % of each other - the kernel is no longer latency bound.
 // One workgroup = ONE wave = one particle block, as before: LDS operations of a single wave execute in order, which
 // is what makes the atomic-free read-modify-write scatter legal (lanes of an iteration hold distinct stencil bases:
 // prepare_blocks_kernel sorts the records into "k-th particle of every key" order; collisions left over are resolved
@@ -24,7 +27,7 @@
 namespace mpm {
 
 #ifndef MPM_G2P2G_WAVES
-#define MPM_G2P2G_WAVES 4// waves per SIMD the register allocation is held to
+#define MPM_G2P2G_WAVES 3// waves per SIMD the register allocation is held to (168 VGPRs)
 #endif
 
 // LDS arenas: nodes 1..6 per axis of the 8^3 cube spanned by the block's 2x2x2 grid blocks.
@@ -324,7 +327,6 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 	for(int i = lane; i < 2 * kP2GNodes; i += 64) p2g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 	__syncthreads();
 	// ---- round trip 3: the 8 grid blocks (lane = cell -> 256-B rows per channel, :699-727) and the first 64 particles
-	const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;// lane == cell of a 4x4x4 block
 	float4 gv[8];
 #pragma unroll
 	for(int lb = 0; lb < 8; ++lb) {
@@ -357,6 +359,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 	fetch(rec_cur, pf);
 #pragma unroll
 	for(int lb = 0; lb < 8; ++lb) {
+		const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;// lane == cell of a 4x4x4 block
 		const int ax = cx + ((lb & 4) ? 4 : 0) - 1, ay = cy + ((lb & 2) ? 4 : 0) - 1, az = cz + ((lb & 1) ? 4 : 0) - 1;
 		if(((unsigned) ax < 6u) & ((unsigned) ay < 6u) & ((unsigned) az < 6u)) g2p[ax * kG2PStrideX + ay * kG2PStrideY + az] = gv[lb];
 	}
@@ -397,12 +400,12 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 		const int slot_nn = idx0 + 128 < size ? idx0 + 128 : 0;
 		const int cnt_nn  = idx0 + 128 < size ? slice_records_at(size, idx0 + 128) : 1;
 		const int rec_nn  = list[slot_nn + min(lane, cnt_nn - 1)];
-#ifdef MPM_EARLY_FETCH
+		// the next iteration's particle record is requested a whole iteration ahead: record loads of 64 scattered 64-B sectors
+		// take long to return, and at three waves per SIMD the 16 registers are there
 		fetch(rec_next, pf);
 		rec_next = rec_nn;
-		cnt_cur	 = cnt_next;
-		cnt_next = cnt_nn;
-#endif
+		cnt_cur			   = cnt_next;
+		cnt_next		   = cnt_nn;
 		// ---- stencil base + weights (:774-797) for ALL lanes (idle lanes of a last partial iteration carry a dummy
 		//      position inside the block); offsets in cell units (exact: dx is a power of two)
 		int base[3], arena[3];
@@ -519,14 +522,6 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 			for(int d = 0; d < 9; ++d) pl.contrib[d] = A[d] * am - pl.contrib[d] * cs;
 		}
 		chain.template at<kSites - 1>();
-		// ---- the next iteration's particle data is requested here: in flight during the tail of this iteration and the
-		//      gather of the next one, without occupying 14 registers during the material update
-#ifndef MPM_EARLY_FETCH
-		fetch(rec_next, pf);
-		rec_next = rec_nn;
-		cnt_cur	 = cnt_next;
-		cnt_next = cnt_nn;
-#endif
 		ncode = in_arena ? (narena[0] | (narena[1] << 4) | (narena[2] << 8)) : -1;
 		// ---- list append: the atomics' results are in by now (and with them the next iteration's particle data)
 		{
@@ -557,7 +552,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 				st_losers += __popcll(__ballot(left && !code_edge(pv_code)));
 				st_edge += __popcll(__ballot(pv_in && code_edge(pv_code)));
 				st_retry_iters += __any(left) ? 1 : 0;
-				st_partial += 64 - cnt_cur;
+				st_partial += active ? 0 : 1;
 			}
 #endif
 			if(__any(left)) p2g_serial(p2g, left, pv_code, pv, mass, lane, info, next_grid);
@@ -583,16 +578,21 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 	}
 #endif
 	__syncthreads();
-	// ---- arena -> next grid: one hardware f32 atomic per touched node and channel (:907-936).  216 nodes, 4 rounds.
+	// ---- arena -> next grid: one hardware f32 atomic per touched node and channel (:907-936).  Lane = cell of one of the
+	//      eight grid blocks, like the staging above: every atomic instruction covers (27 cells of) ONE 256-B channel row.
+	//      (Walking the 216 arena nodes in arena order instead spreads each instruction over ~21 three-cell runs in up to
+	//      eight blocks: five times the L2 atomic requests.)
+	const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
 #pragma unroll
-	for(int r = 0; r < (kP2GNodes + 63) / 64; ++r) {// (uniform trip count: __shfl needs its source lanes 54..61 active)
-		const int n = min(r * 64 + lane, kP2GNodes - 1);
-		const int x = n / 36 + 1, y = (n / 6) % 6 + 1, z = n % 6 + 1;// cube coordinates 1..6
-		const int nb	= __shfl(info, 54 + (x >> 2) * 4 + (y >> 2) * 2 + (z >> 2));
+	for(int lb = 0; lb < 8; ++lb) {
+		const int nb = __shfl(info, 54 + lb);
+		const int ax = cx + ((lb & 4) ? 4 : 0) - 1, ay = cy + ((lb & 2) ? 4 : 0) - 1, az = cz + ((lb & 1) ? 4 : 0) - 1;
+		const bool in = ((unsigned) ax < 6u) & ((unsigned) ay < 6u) & ((unsigned) az < 6u);
+		const int n	  = in ? ax * kP2GStrideX + ay * kP2GStrideY + az : 0;
 		const float4 va = p2g[n], vb = p2g[kP2GNodes + n];
 		const float4 v	= make_float4(va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w);
-		if(nb >= 0 && r * 64 + lane < kP2GNodes) {
-			float* g = next_grid + (size_t) nb * 256 + (x & 3) * 16 + (y & 3) * 4 + (z & 3);
+		if(in && nb >= 0) {
+			float* g = next_grid + (size_t) nb * 256 + lane;
 			if(v.x != 0.f) unsafeAtomicAdd(g, v.x);
 			if(v.y != 0.f) unsafeAtomicAdd(g + 64, v.y);
 			if(v.z != 0.f) unsafeAtomicAdd(g + 128, v.z);

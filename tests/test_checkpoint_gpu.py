@@ -68,6 +68,43 @@ def test_checkpoint_rejects_a_different_setup():
     b.close()
 
 
+def test_checkpoint_rejects_other_physics_and_corrupt_headers():
+    """Same geometry, different material parameters or gravity: the parameter hash refuses the load; header counts that do
+    not fit together are refused before anything is copied."""
+    import struct
+    sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=3.0)
+    a = build_engine(sc)
+    a.initial_setup()
+    a.run_fixed(3, sc["dt"])
+    ckpt = a.save_checkpoint().copy()
+    a.close()
+    stiff = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=3.0, youngs=2e4)
+    b = build_engine(stiff)
+    b.initial_setup()
+    with pytest.raises(Exception):
+        b.load_checkpoint(ckpt)
+    b.close()
+    heavy = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=3.0)
+    heavy.setdefault("config", {})["gravity"] = -1.0
+    c = build_engine(heavy)
+    c.initial_setup()
+    with pytest.raises(Exception):
+        c.load_checkpoint(ckpt)
+    c.close()
+    d = build_engine(sc)
+    d.initial_setup()
+    raw = bytearray(ckpt.tobytes())
+    # header: magic u64, domain_bits/max_ppc/nmodels/rollid i32 x4, pbc/nbc/ebc/prev_count i32 x4
+    pbc, nbc, ebc, prev = struct.unpack_from("<4i", raw, 24)
+    for bad in ((nbc + 1, nbc, ebc, prev), (pbc, ebc + 1, ebc, prev), (pbc, nbc, 1 << 30, prev), (-1, nbc, ebc, prev)):
+        broken = bytearray(raw)
+        struct.pack_into("<4i", broken, 24, *bad)
+        with pytest.raises(Exception):
+            d.load_checkpoint(np.frombuffer(bytes(broken), dtype=np.uint8))
+    d.load_checkpoint(ckpt)      # the untouched checkpoint still loads into the same context
+    d.close()
+
+
 def test_checkpoint_into_a_smaller_capacity_grows_it():
     """The checkpoint needs more blocks than the loading context has: the load grows the capacity (check_capacity path)."""
     # a sphere centred on a block corner occupies 2^3 particle blocks; two cells further along the diagonal it straddles 3^3
