@@ -242,11 +242,11 @@ def main():
         if check is not None:
             out["config"]["self_check"] = check
         # measured HBM traffic of the same kernel on the same workload (PMC passes are separate runs, see profiles/)
-        tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
         if world == 1 and args.scene == "sand40m" and args.fraction >= 1.0 and os.path.exists(tf):
             t = json.load(open(tf))
             out["roofline"]["traffic"] = t["traffic_bytes"]
-            out["roofline"]["traffic_source"] = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated)"
+            out["roofline"]["traffic_source"] = "profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated)"
             out["roofline"]["algorithmic_bytes"] = n_rank * bpp
         if world == 1 and not args.no_cpu_baseline and not args.mgsp:
             out["cpu_baseline"] = cpu_baseline(args)

@@ -36,7 +36,8 @@ namespace mpm {
 // beyond the hardware's b128 pass structure (tools/valu_microbench3: 4.0 cycles per ds_read_b128 on the gather arena,
 // 8.8 per read-modify-write instruction on the scatter arena, against 4.0 / 8.3 for a linear address pattern).
 constexpr int kP2GStrideX = 36, kP2GStrideY = 6, kP2GNodes = 216;// scatter arenas (two): (x-1)*36 + (y-1)*6 + (z-1)
-constexpr int kG2PStrideX = 36, kG2PStrideY = 6, kG2PNodes = 216;// gather arena, same dense layout
+constexpr int kG2PStrideX = 36, kG2PStrideY = 6, kG2PNodes = 216;// gather arena, same dense layout (a padded y-major 52 / 8 layout reads
+																 // without bank conflicts in the micro-benchmark but gains < 1 % in the kernel)
 
 struct ModelView {
 	const float* bins_src;// [bin][64 records][nch floats], laid out by the previous block numbering
