@@ -26,6 +26,10 @@
 
 namespace mpm {
 
+#ifndef MPM_G2P2G_WAVES_FLUID
+#define MPM_G2P2G_WAVES_FLUID 4// J-fluid instantiation: 128 VGPRs suffice, and with a material update of a handful of instructions the
+								// scatter chain has little to hide behind - occupancy does it (same-box: 0.36 ms against 0.40 at three waves)
+#endif
 #ifndef MPM_G2P2G_WAVES
 #define MPM_G2P2G_WAVES 3// waves per SIMD the register allocation is held to (168 VGPRs)
 #endif
@@ -289,7 +293,7 @@ MPM_DEV int code_off(int c) {
 }
 
 template<int MAT>
-__global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_keys, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, float dt, float new_dt, int* __restrict__ status) {
+__global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : MPM_G2P2G_WAVES) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_keys, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, float dt, float new_dt, int* __restrict__ status) {
 	constexpr int NCH = MatTraits<MAT>::nch;
 	// 10.8 KB of LDS per wave: 15 single-wave workgroups per CU.
 	__shared__ float4 g2p[kG2PNodes];	   // node velocities {vx, vy, vz, vz} of cube nodes 1..6 per axis
@@ -426,6 +430,20 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 		// Every lane runs the whole body: the idle lanes of a last partial iteration carry a dummy particle and write it into
 		// the padding slots of the block's last bin (slot == pidib < 64 * ceil(size / 64), allocated but never read), which
 		// keeps the 13 stores out of divergent control flow (countable for s_waitcnt).
+		// ---- claim the stencil bases of the payload in flight: lanes whose base is unique in the wave (`win`) scatter in the
+		//      chain threaded through this iteration's register-only arithmetic - re-bucketing (kPreSites call sites) and the
+		//      material update - the others (and the edge lanes) afterwards
+#ifndef MPM_PRE_SITES
+#define MPM_PRE_SITES 3
+#endif
+		constexpr int kPreSites	   = MPM_PRE_SITES;
+		constexpr int kStressSites = MAT == 0 ? 1 : (MAT == 1 ? kFcSites : (MAT == 2 ? kSandSites : kNaccSites));
+		constexpr int kSites	   = kPreSites + kStressSites + 2;
+		const int pv_key = (pv_in ? code_key(pv_code) : 0) + (lane & 1) * 216;// even / odd lanes: separate arenas, separate claims
+		if(pv_in) s_owner[pv_key] = (unsigned char) lane;
+		__asm__ volatile("" ::: "memory");// another lane may have written the same byte: no store-to-load forwarding
+		win = pv_in && !code_edge(pv_code) && (int) s_owner[pv_key] == lane;
+		ScatterChain<kSites> chain(p2g + (win ? code_off(pv_code) + (lane & 1) * kP2GNodes : 0), pv, mass, win);
 		// ---- advect (:838)
 #pragma unroll
 		for(int d = 0; d < 3; ++d) pos[d] += vel[d] * dt;
@@ -443,6 +461,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 			narena[d]	  = arena[d] + (nbase[d] - base[d]);
 			in_arena &= (narena[d] >= 0) & (narena[d] <= 5);
 		}
+		if constexpr(kPreSites == 3) chain.template at<0>();
 		const bool dir_ok = ((unsigned) (dirv[0] + 1) < 3u) & ((unsigned) (dirv[1] + 1) < 3u) & ((unsigned) (dirv[2] + 1) < 3u);
 		const int ntag	  = dir_ok ? (dirv[0] + 1) * 9 + (dirv[1] + 1) * 3 + dirv[2] + 1 : kStay;
 		const int dno_raw = __shfl(info, 27 + ntag);
@@ -455,6 +474,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 			const int pb = (int) __builtin_rintf((pos[d] + vel[d] * new_dt) * dx_inv) - 1;// a prediction: ties do not matter
 			pk[d]		 = min(max(((nbase[d] - 1) & 3) + 1 + (pb - nbase[d]), 0), 5);
 		}
+		if constexpr(kPreSites == 3) chain.template at<1>();
 		const int pkey	= pk[1] * 36 + pk[0] * 6 + pk[2];
 		const int rec	= (ntag << tag_shift) | (pkey << key_shift) | pidib;
 		const bool stay = dno >= 0 && ntag == kStay;
@@ -472,24 +492,16 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 			if(dno < 0) atomicAdd(&status[ST_LOST], 1);// reference: particle silently lost (particle_buffer.cuh:105-113)
 			if(!in_arena) atomicAdd(&status[ST_ARENA], 1);// (:877-885) contribution discarded
 		}
-		// ---- claim the stencil bases of the payload in flight: lanes whose base is unique in the wave (`win`) scatter in the
-		//      chain threaded through this iteration's material update, the others (and the edge lanes) afterwards
-		constexpr int kStressSites = MAT == 0 ? 1 : (MAT == 1 ? kFcSites : (MAT == 2 ? kSandSites : kNaccSites));
-		constexpr int kSites	   = kStressSites + 2;
-		const int pv_key = (pv_in ? code_key(pv_code) : 0) + (lane & 1) * 216;// even / odd lanes: separate arenas, separate claims
-		if(pv_in) s_owner[pv_key] = (unsigned char) lane;
-		__asm__ volatile("" ::: "memory");// another lane may have written the same byte: no store-to-load forwarding
-		win = pv_in && !code_edge(pv_code) && (int) s_owner[pv_key] == lane;
-		ScatterChain<kSites> chain(p2g + (win ? code_off(pv_code) + (lane & 1) * kP2GNodes : 0), pv, mass, win);
+		if constexpr(kPreSites == 3) chain.template at<2>();
 		// ---- material update, store to the destination bin (slot == pidib: consecutive records) (:470-663)
 		float4* dst = reinterpret_cast<float4*>(mv.bins_dst + ((size_t) (binoff_dst + (pidib >> 6)) * kBin + (pidib & 63)) * NCH);
 		if constexpr(MAT == 0) {
 			float Aw[9];
 #pragma unroll
 			for(int d = 0; d < 9; ++d) Aw[d] = A[d] * cfg.dx;
-			chain.template at<0>();
+			chain.template at<kPreSites + 0>();
 			const float J = stress_jfluid(mv.mc, st[0], Aw, dt, cfg.d_inv, pl.contrib);
-			chain.template at<1>();
+			chain.template at<kPreSites + 1>();
 			dst[0] = make_float4(pos[0], pos[1], pos[2], J);
 		} else {
 			float dws[9], Fold[9], F[9];
@@ -499,16 +511,16 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_G2P2G_WAVES) void g2p2g_kernel(G
 				Fold[d] = st[d];
 			}
 			matmul3(dws, Fold, F);
-			chain.template at<0>();
+			chain.template at<kPreSites + 0>();
 			float lj = 0.f;
 			if constexpr(MAT == 1) {
-				stress_fixed_corotated<1>(mv.mc, F, pl.contrib, chain);
+				stress_fixed_corotated<kPreSites + 1>(mv.mc, F, pl.contrib, chain);
 			} else if constexpr(MAT == 2) {
 				lj = st[9];
-				stress_sand<1>(mv.mc, F, lj, pl.contrib, chain);
+				stress_sand<kPreSites + 1>(mv.mc, F, lj, pl.contrib, chain);
 			} else {
 				lj = st[9];
-				stress_nacc<1>(mv.mc, F, lj, pl.contrib, chain);
+				stress_nacc<kPreSites + 1>(mv.mc, F, lj, pl.contrib, chain);
 			}
 			dst[0] = make_float4(pos[0], pos[1], pos[2], F[0]);
 			dst[1] = make_float4(F[1], F[2], F[3], F[4]);

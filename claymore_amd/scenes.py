@@ -90,10 +90,14 @@ def scaled_sand_column(bits, fraction):
 
 
 def fluid_dam(bits=10, size_cells=(256, 192, 256), min_corner=(12, 12, 12)):
-    """C5: weakly compressible J-fluid dam break (reference defaults particle_buffer.cuh:148-153)."""
+    """C5: weakly compressible J-fluid dam break (reference defaults particle_buffer.cuh:148-153).  The fixed substep of the
+    bench / tests follows the acoustic CFL limit: sound speed sqrt(bulk * gamma / rho) = 16.9, dx / c = 2.3e-4 at bits 8 and
+    5.8e-5 at bits 10 - dt = 1e-4 is fine up to bits 8 and halves with every bit beyond (2.5e-5 at bits 10; at 1e-4 the
+    1024^3 run blows up within 2000 substeps, which bench.py's self-check reports as lost particles)."""
     lo = np.array(min_corner)
     hi = lo + np.array(size_cells)
-    return {"name": "fluid_dam", "bits": bits, "dt": 1e-4, "config": {"max_ppc": 32},
+    dt = 1e-4 if bits <= 8 else 1e-4 * 2.0 ** (8 - bits)
+    return {"name": "fluid_dam", "bits": bits, "dt": dt, "config": {"max_ppc": 32},
             "models": [{"material": J_FLUID, "xyz": lattice_box(bits, lo, hi), "v0": (0, 0, 0), "params": {}}]}
 
 
