@@ -595,35 +595,36 @@ MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, 
 	for(int i = 0; i < 3; i++) epsilon_hat[i] = epsilon[i] - (trace_epsilon * (1.0f / 3.0f));
 	const float epsilon_hat_norm = __builtin_amdgcn_sqrtf(epsilon_hat[0] * epsilon_hat[0] + epsilon_hat[1] * epsilon_hat[1] + epsilon_hat[2] * epsilon_hat[2]);
 	hk.template at<BASE + kEigSites>();
-	float dl[3] = {0.f, 0.f, 0.f};// ln S_new - ln sigma
-	bool rebuild = false, dead = false;
-	if(trace_epsilon >= 0.0f) {// case II: cone tip (:282-290)
+	// Return mapping without divergent branches (the three cases of :282-316 as selects; a wave of sand particles usually
+	// holds all of them): dl = ln S_new - ln sigma is -epsilon at the cone tip (case II), -r epsilon_hat with
+	// r = max(delta_gamma, 0) / |epsilon_hat| otherwise (case III; r = 0 is case I, inside the cone).
+	const bool tip	= trace_epsilon >= 0.0f;
+	const bool dead = !tip && mc.mu == 0.f;// reference: logf(0) when mu == 0 (:298-300): P is NaN, F is left as it is
+	const float delta_gamma = epsilon_hat_norm + (3.0f * mc.lambda + scaled_mu) * rcp_fast(scaled_mu) * trace_epsilon * mc.yield_surface;
+	const float r			= fmaxf(delta_gamma, 0.f) * rcp_fast(fmaxf(epsilon_hat_norm, 1e-30f));
+	float dl[3], lnS[3];
 #pragma unroll
-		for(int i = 0; i < 3; i++) dl[i] = -epsilon[i];
-		rebuild = true;
-		if(mc.volume_correction) log_jp = mc.beta * sum_epsilon + log_jp;
-	} else if(mc.mu != 0.f) {
-		log_jp					= 0.f;
-		const float delta_gamma = epsilon_hat_norm + (3.0f * mc.lambda + scaled_mu) * rcp_fast(scaled_mu) * trace_epsilon * mc.yield_surface;
-		if(delta_gamma > 0.f) {// case III: project to the cone surface (case I, inside the cone: dl = 0)
-			const float r = delta_gamma * rcp_fast(epsilon_hat_norm);
-#pragma unroll
-			for(int i = 0; i < 3; i++) dl[i] = -r * epsilon_hat[i];
-		}
-		rebuild = true;
-	} else {
-		dead = true;// reference: logf(0) when mu == 0 (:298-300): P is NaN, F is left as it is
+	for(int i = 0; i < 3; i++) {
+		dl[i]  = tip ? -epsilon[i] : -r * epsilon_hat[i];
+		lnS[i] = dead ? -__builtin_inff() : lns[i] + dl[i];
 	}
-	float lnS[3];
-#pragma unroll
-	for(int i = 0; i < 3; i++) lnS[i] = dead ? -__builtin_inff() : lns[i] + dl[i];
-	if(rebuild) {
-		if(!ill && det3(F) > 0.f) {
+	log_jp = tip ? (mc.volume_correction ? mc.beta * sum_epsilon + log_jp : log_jp) : (dead ? log_jp : 0.f);
+	// The projected F = U diag(exp(dl)) U^T F.  While every particle of the wave is inside the cone (dl = 0: elastic, the
+	// state of a column at rest) the factor is the identity and the rebuild is skipped for the whole wave; the reference
+	// rebuilds U S V^T there too, which only adds its rounding.  Reflected or collapsed F (rare) goes through V, as the
+	// reference's does, whether the strain changed or not (the rebuild removes the reflection).
+	const bool odd	   = !dead && (ill || !(det3(F) > 0.f));
+	const bool changed = !dead && !odd && (tip || r > 0.f);
+	if(__any(changed)) {
+		if(changed) {
 			float ratio[3];
 #pragma unroll
 			for(int i = 0; i < 3; i++) ratio[i] = exp_fast(dl[i]);
 			rescale_principal(F, U, ratio);
-		} else {// reflected or collapsed F (rare)
+		}
+	}
+	if(__any(odd)) {
+		if(odd) {
 			float Sn[3];
 #pragma unroll
 			for(int i = 0; i < 3; i++) Sn[i] = exp_fast(lnS[i]);

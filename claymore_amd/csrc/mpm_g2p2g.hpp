@@ -449,31 +449,31 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		for(int d = 0; d < 3; ++d) pos[d] += vel[d] * dt;
 		// ---- new base, re-bucket (:852-866, add_advection particle_buffer.cuh:100-135).  The list-append atomics are
 		//      issued BEFORE the stress computation, which hides their round trip to L2.
-		int nbase[3], narena[3], dirv[3];
+		int narena[3], dirv[3], pk[3];
 		in_arena = active;
+		const float pred = new_dt * dx_inv;
 #pragma unroll
 		for(int d = 0; d < 3; ++d) {
-			const float p = pos[d] * dx_inv;
-			nbase[d]	  = lround_pos(p) - 1;
-			pl.fd[d]	  = p - (float) nbase[d];
-			pl.mv[d]	  = mass * vel[d];
-			dirv[d]		  = ((base[d] - 1) >> 2) - ((nbase[d] - 1) >> 2);
-			narena[d]	  = arena[d] + (nbase[d] - base[d]);
+			const float p	= pos[d] * dx_inv;
+			const int nbase = lround_pos(p) - 1;
+			pl.fd[d]		= p - (float) nbase;
+			pl.mv[d]		= mass * vel[d];
+			narena[d]		= arena[d] + (nbase - base[d]);// new stencil base in the node cube of the block the particle came from
 			in_arena &= (narena[d] >= 0) & (narena[d] <= 5);
+			// the block the particle lands in: cube coordinates 1..4 belong to this block, 0 / 5.. to the neighbours
+			// (== ((base - 1) >> 2) - ((nbase - 1) >> 2), base - 1 and arena - 1 being congruent modulo 4)
+			dirv[d] = -((narena[d] - 1) >> 2);
+			// sort key for the NEXT step: the stencil base predicted after one more advection with the current velocity, in the
+			// cube of the block the particle is in after THIS step, clamped to 0..5 (a prediction: ties do not matter).
+			// rint((pos + vel new_dt) / dx) - 1 - nbase == rint(fd + vel new_dt / dx) - 1 because nbase is an integer.
+			const int step = (int) __builtin_rintf(fmaf(vel[d], pred, pl.fd[d]));
+			pk[d]		   = min(max(((narena[d] - 1) & 3) + step, 0), 5);
 		}
 		if constexpr(kPreSites == 3) chain.template at<0>();
 		const bool dir_ok = ((unsigned) (dirv[0] + 1) < 3u) & ((unsigned) (dirv[1] + 1) < 3u) & ((unsigned) (dirv[2] + 1) < 3u);
 		const int ntag	  = dir_ok ? (dirv[0] + 1) * 9 + (dirv[1] + 1) * 3 + dirv[2] + 1 : kStay;
 		const int dno_raw = __shfl(info, 27 + ntag);
 		const int dno	  = (active && dir_ok) ? dno_raw : -1;
-		// sort key for the NEXT step: predicted stencil base after one more advection with the current velocity,
-		// expressed in the cube of the block the particle is in after THIS step (clamped to the 6^3 range)
-		int pk[3];
-#pragma unroll
-		for(int d = 0; d < 3; ++d) {
-			const int pb = (int) __builtin_rintf((pos[d] + vel[d] * new_dt) * dx_inv) - 1;// a prediction: ties do not matter
-			pk[d]		 = min(max(((nbase[d] - 1) & 3) + 1 + (pb - nbase[d]), 0), 5);
-		}
 		if constexpr(kPreSites == 3) chain.template at<1>();
 		const int pkey	= pk[1] * 36 + pk[0] * 6 + pk[2];
 		const int rec	= (ntag << tag_shift) | (pkey << key_shift) | pidib;
