@@ -5,9 +5,11 @@
 
 A "step" is one MPM substep (grid update -> fused G2P2G -> sparse partition rebuild [-> halo exchange for
 N > 1]) over one synthetic scene.  N = 1 runs BASELINE config 3, the configuration the metric is quoted on:
-the 40.1 M-particle Drucker-Prager sand column on a 512^3 sparse grid (`configs[2]`); N > 1 keeps the total
-work fixed (strong scaling, MGSP static particle partition: equal-count slabs of the initial lattice, one
-rank per GPU over RCCL).  Inputs are resident in HBM before the timed region; value = particles * K / time.
+the 40.1 M-particle Drucker-Prager sand column on a 512^3 sparse grid (`configs[2]`).  N > 1 is MGSP (static particle
+partition, one rank per GPU, the substep loop and the halo exchange in the C++ driver on RCCL) and keeps the work PER GPU
+fixed by default (weak scaling): N touching C3 columns on the same 512^3 grid, one per rank, N x 40.1 M particles, every
+rank with halo blocks on the faces it shares; `--scaling strong` cuts the one C3 column into N equal-count slabs
+instead.  Inputs are resident in HBM before the timed region; value = particles of all ranks * K / time.
 
 Extra objects on the JSON line:
   roofline     - G2P2G (the dominant kernel): algorithmic bytes per launch (144 B/particle
@@ -114,6 +116,8 @@ def main():
     ap.add_argument("--fraction", type=float, default=1.0, help="debug: shrink the sand column")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mgsp", action="store_true", help="debug: drive the multi-GPU code path even with one rank")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = one C3 column per rank (N x 40.1 M particles), strong = the one C3 column cut N ways")
     args = ap.parse_args()
 
     import torch
@@ -142,8 +146,16 @@ def main():
         dist.barrier()
 
     from claymore_amd import scenes
-    sc, workload = make_scene(args)
-    n_total = scenes.total_particles(sc)
+    weak = world > 1 and args.scaling == "weak"
+    if weak:
+        if args.scene != "sand40m" or args.fraction < 1.0:
+            raise SystemExit("--scaling weak is defined for the default scene (one C3 column per rank)")
+        sc = scenes.sand_columns_rank(rank, world)          # this rank's column only
+        n_total = world * scenes.total_particles(sc)
+        workload = f"{world} touching C3 sand columns (Drucker-Prager), one per rank, 512^3 sparse grid"
+    else:
+        sc, workload = make_scene(args)
+        n_total = scenes.total_particles(sc)
     material = sc["models"][0]["material"]
     dt = sc["dt"]
 
@@ -186,7 +198,7 @@ def main():
             dist.broadcast_object_list(objs, src=0)
             return objs[0]
 
-        sim = MgspGroupRank(sc, rank, world, device=local_rank, bootstrap=bootstrap)
+        sim = MgspGroupRank(sc, rank, world, device=local_rank, bootstrap=bootstrap, prepartitioned=weak)
         sim.initial_setup()
         if args.start_step:
             sim.run_fixed(args.start_step, dt)
@@ -222,9 +234,10 @@ def main():
         out = {
             "metric": "particles*steps/sec", "value": value, "unit": "particles*steps/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "particles": n_total, "dt": dt,
-                       "parallelism": "single GPU" if not use_mgsp else f"mgsp static particle partition x{world}, C++ driver on RCCL",
+                       "parallelism": "single GPU" if not use_mgsp else
+                       f"mgsp static particle partition x{world} ({'one column per rank' if weak else 'equal-count slabs of the one column'}), C++ driver on RCCL",
                        "blocks": blocks, "phases_ms": phases},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

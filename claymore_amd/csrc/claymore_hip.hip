@@ -117,15 +117,30 @@ static hipError_t dalloc(T** p, size_t n) {
 	return hipMalloc((void**) p, sizeof(T) * (n ? n : 1));
 }
 
+// Scratch device array that is released on every exit path of the function that owns it.
+template<typename T>
+struct DevScratch {
+	T* p = nullptr;
+	DevScratch() = default;
+	DevScratch(const DevScratch&) = delete;
+	DevScratch& operator=(const DevScratch&) = delete;
+	~DevScratch() {
+		if(p) hipFree(p);
+	}
+	hipError_t alloc(size_t n) { return dalloc(&p, n); }
+};
+
 // Replace *p (old_n elements) by a zero-initialised array of new_n elements holding the old contents.
 template<typename T>
 static hipError_t regrow(T** p, size_t old_n, size_t new_n, hipStream_t s) {
 	T* q		 = nullptr;
 	hipError_t e = hipMalloc((void**) &q, sizeof(T) * new_n);
 	if(e != hipSuccess) return e;
-	if((e = hipMemsetAsync(q, 0, sizeof(T) * new_n, s)) != hipSuccess) return e;
-	if(*p && old_n && (e = hipMemcpyAsync(q, *p, sizeof(T) * old_n, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
-	if((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+	if((e = hipMemsetAsync(q, 0, sizeof(T) * new_n, s)) != hipSuccess || (*p && old_n && (e = hipMemcpyAsync(q, *p, sizeof(T) * old_n, hipMemcpyDeviceToDevice, s)) != hipSuccess)
+	   || (e = hipStreamSynchronize(s)) != hipSuccess) {
+		hipFree(q);// *p is untouched: the caller still owns a valid array of old_n elements
+		return e;
+	}
 	if(*p) hipFree(*p);
 	*p = q;
 	return hipSuccess;
@@ -242,12 +257,11 @@ int mpm_create(const mpm_config* cfg, int device, mpm_ctx** out) {
 		delete ctx;
 		return MPM_ERR_DEVICE;
 	}
-	hipEventCreate(&ctx->ev_a);
-	hipEventCreate(&ctx->ev_b);
-	hipEventCreate(&ctx->ev_g0);
-	hipEventCreate(&ctx->ev_g1);
-	hipEventCreateWithFlags(&ctx->ev_comm, hipEventDisableTiming);
-	hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming);
+	if(hipEventCreate(&ctx->ev_a) != hipSuccess || hipEventCreate(&ctx->ev_b) != hipSuccess || hipEventCreate(&ctx->ev_g0) != hipSuccess || hipEventCreate(&ctx->ev_g1) != hipSuccess
+	   || hipEventCreateWithFlags(&ctx->ev_comm, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming) != hipSuccess) {
+		mpm_destroy(ctx);// frees whatever was created (null handles are skipped)
+		return MPM_ERR_DEVICE;
+	}
 	*out = ctx;
 	return MPM_OK;
 }
@@ -286,15 +300,15 @@ void mpm_destroy(mpm_ctx* ctx) {
 	for(auto& p: ctx->d_send_ids) hipFree(p);
 	if(ctx->h_status) hipHostFree(ctx->h_status);
 	if(ctx->h_maxvel) hipHostFree(ctx->h_maxvel);
-	hipEventDestroy(ctx->ev_a);
-	hipEventDestroy(ctx->ev_b);
-	hipEventDestroy(ctx->ev_g0);
-	hipEventDestroy(ctx->ev_g1);
-	hipEventDestroy(ctx->ev_comm);
-	hipEventDestroy(ctx->ev_halo);
+	if(ctx->ev_a) hipEventDestroy(ctx->ev_a);
+	if(ctx->ev_b) hipEventDestroy(ctx->ev_b);
+	if(ctx->ev_g0) hipEventDestroy(ctx->ev_g0);
+	if(ctx->ev_g1) hipEventDestroy(ctx->ev_g1);
+	if(ctx->ev_comm) hipEventDestroy(ctx->ev_comm);
+	if(ctx->ev_halo) hipEventDestroy(ctx->ev_halo);
 	if(ctx->h_halo_counts) hipHostFree(ctx->h_halo_counts);
-	hipStreamDestroy(ctx->s_compute);
-	hipStreamDestroy(ctx->s_comm);
+	if(ctx->s_compute) hipStreamDestroy(ctx->s_compute);
+	if(ctx->s_comm) hipStreamDestroy(ctx->s_comm);
 	delete ctx;
 }
 
@@ -877,9 +891,11 @@ int mpm_retrieve_state(mpm_ctx* ctx, int model, float* xyz, float* state9, float
 	Model& m	  = ctx->models[model];
 	const int r = ctx->rollid, nn = r ^ 1;
 	const size_t cap = std::min(*n, m.n);
-	float *d_state = nullptr, *d_lj = nullptr;
-	if(state9) HIP_TRY(dalloc(&d_state, 9 * cap));
-	if(logjp) HIP_TRY(dalloc(&d_lj, cap));
+	// (an output call, once per frame at most: its two staging arrays are allocated here and released on every exit path)
+	DevScratch<float> b_state, b_lj;
+	if(state9) HIP_TRY(b_state.alloc(9 * cap));
+	if(logjp) HIP_TRY(b_lj.alloc(cap));
+	float *d_state = b_state.p, *d_lj = b_lj.p;
 	HIP_TRY(hipMemsetAsync(ctx->d_counter, 0, sizeof(unsigned long long), s));
 	if(ctx->pbc) retrieve_kernel<<<ctx->pbc, 256, 0, s>>>(ctx->g, m.nch, ctx->part[r].keys, ctx->part[nn].table, m.size, m.row_of, m.list[m.list_in], m.binoff[r], m.bins[r], m.d_xyz, d_state, d_lj, (unsigned long long) cap, ctx->d_counter);
 	unsigned long long count = 0;
@@ -889,8 +905,6 @@ int mpm_retrieve_state(mpm_ctx* ctx, int model, float* xyz, float* state9, float
 	HIP_TRY(hipMemcpy(xyz, m.d_xyz, sizeof(float) * 3 * got, hipMemcpyDeviceToHost));
 	if(state9) HIP_TRY(hipMemcpy(state9, d_state, sizeof(float) * 9 * got, hipMemcpyDeviceToHost));
 	if(logjp) HIP_TRY(hipMemcpy(logjp, d_lj, sizeof(float) * got, hipMemcpyDeviceToHost));
-	hipFree(d_state);
-	hipFree(d_lj);
 	*n = got;
 	if(count > cap) return fail(ctx, MPM_ERR_CAPACITY, "output array too small");
 	return MPM_OK;
@@ -930,33 +944,30 @@ int mpm_dump_grid(mpm_ctx* ctx, int* keys, float* blocks, size_t* nblocks) {
 
 int mpm_test_svd(const float* F, size_t n, float* out21, int device) {
 	HIP_TRY0(hipSetDevice(device));
-	float *dF = nullptr, *dO = nullptr;
-	HIP_TRY0(dalloc(&dF, 9 * n));
-	HIP_TRY0(dalloc(&dO, 21 * n));
-	HIP_TRY0(hipMemcpy(dF, F, sizeof(float) * 9 * n, hipMemcpyHostToDevice));
-	test_svd_kernel<<<cdiv(n, 256), 256>>>(n, dF, dO);
-	HIP_TRY0(hipMemcpy(out21, dO, sizeof(float) * 21 * n, hipMemcpyDeviceToHost));
-	hipFree(dF);
-	hipFree(dO);
+	DevScratch<float> dF, dO;
+	HIP_TRY0(dF.alloc(9 * n));
+	HIP_TRY0(dO.alloc(21 * n));
+	HIP_TRY0(hipMemcpy(dF.p, F, sizeof(float) * 9 * n, hipMemcpyHostToDevice));
+	test_svd_kernel<<<cdiv(n, 256), 256>>>(n, dF.p, dO.p);
+	HIP_TRY0(hipGetLastError());
+	HIP_TRY0(hipMemcpy(out21, dO.p, sizeof(float) * 21 * n, hipMemcpyDeviceToHost));
 	return MPM_OK;
 }
 
 int mpm_test_stress(int material, const mpm_material_params* p, const float* F, const float* logjp, size_t n, float* out19, int device) {
 	if(material < 1 || material > 3 || !p) return MPM_ERR_INVALID;
 	HIP_TRY0(hipSetDevice(device));
-	float *dF = nullptr, *dL = nullptr, *dO = nullptr;
-	HIP_TRY0(dalloc(&dF, 9 * n));
-	HIP_TRY0(dalloc(&dO, 19 * n));
-	HIP_TRY0(hipMemcpy(dF, F, sizeof(float) * 9 * n, hipMemcpyHostToDevice));
+	DevScratch<float> dF, dL, dO;
+	HIP_TRY0(dF.alloc(9 * n));
+	HIP_TRY0(dO.alloc(19 * n));
+	HIP_TRY0(hipMemcpy(dF.p, F, sizeof(float) * 9 * n, hipMemcpyHostToDevice));
 	if(logjp) {
-		HIP_TRY0(dalloc(&dL, n));
-		HIP_TRY0(hipMemcpy(dL, logjp, sizeof(float) * n, hipMemcpyHostToDevice));
+		HIP_TRY0(dL.alloc(n));
+		HIP_TRY0(hipMemcpy(dL.p, logjp, sizeof(float) * n, hipMemcpyHostToDevice));
 	}
-	test_stress_kernel<<<cdiv(n, 256), 256>>>(material, make_material_const(*p), n, dF, dL, dO);
-	HIP_TRY0(hipMemcpy(out19, dO, sizeof(float) * 19 * n, hipMemcpyDeviceToHost));
-	hipFree(dF);
-	hipFree(dL);
-	hipFree(dO);
+	test_stress_kernel<<<cdiv(n, 256), 256>>>(material, make_material_const(*p), n, dF.p, dL.p, dO.p);
+	HIP_TRY0(hipGetLastError());
+	HIP_TRY0(hipMemcpy(out19, dO.p, sizeof(float) * 19 * n, hipMemcpyDeviceToHost));
 	return MPM_OK;
 }
 

@@ -89,6 +89,25 @@ def scaled_sand_column(bits, fraction):
     return sand_column(bits, tuple(int(x) for x in size))
 
 
+def sand_columns_layout(world, bits=9, size_cells=(128, 306, 128)):
+    """Min corners of `world` adjacent sand columns on the floor of the domain, ceil(sqrt(world)) per row along x, rows
+    along z, centred and block-aligned: the weak-scaling workload of bench.py (one C3 column per rank; touching columns
+    share a face, so every rank has halo blocks from the first substep)."""
+    n = 1 << bits
+    cols = int(np.ceil(np.sqrt(world)))
+    rows = (world + cols - 1) // cols
+    x0 = ((n - size_cells[0] * cols) // 2) & ~3
+    z0 = ((n - size_cells[2] * rows) // 2) & ~3
+    if x0 < 12 or z0 < 12 or 12 + size_cells[1] > n - 12:
+        raise ValueError(f"{world} columns of {size_cells} cells do not fit a {n}^3 grid")
+    return [(x0 + size_cells[0] * (r % cols), 12, z0 + size_cells[2] * (r // cols)) for r in range(world)]
+
+
+def sand_columns_rank(rank, world, bits=9, size_cells=(128, 306, 128)):
+    """The particles of ONE rank of the weak-scaling workload (a rank never builds the other ranks' columns)."""
+    return sand_column(bits, size_cells, sand_columns_layout(world, bits, size_cells)[rank])
+
+
 def fluid_dam(bits=10, size_cells=(256, 192, 256), min_corner=(12, 12, 12)):
     """C5: weakly compressible J-fluid dam break (reference defaults particle_buffer.cuh:148-153).  The fixed substep of the
     bench / tests follows the acoustic CFL limit: sound speed sqrt(bulk * gamma / rho) = 16.9, dx / c = 2.3e-4 at bits 8 and

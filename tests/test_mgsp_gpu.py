@@ -117,11 +117,15 @@ def test_multi_context_equals_oracle(world, kind, phased):
 
 
 # ---- the C++ group driver (claymore_amd/csrc/mpm_group.inc) -----------------------------------------------------------
-def _run_group_threads(scene, world, nsteps, dt, adaptive=None):
+def _run_group_threads(scene, world, nsteps, dt, adaptive=None, local_scenes=None):
     """`world` engine contexts on one GPU, one thread per rank, every substep inside mpm_group_substep (in-process
-    transport: device-to-device copies; the RCCL transport needs one GPU per rank)."""
+    transport: device-to-device copies; the RCCL transport needs one GPU per rank).  local_scenes: a partition made by
+    the caller (one scene per rank) instead of the equal-count slabs of `scene`."""
     lg = LocalGroup(world)
-    ranks = [MgspGroupRank(scene, r, world, device=0, local_group=lg) for r in range(world)]
+    if local_scenes is not None:
+        ranks = [MgspGroupRank(local_scenes[r], r, world, device=0, local_group=lg, prepartitioned=True) for r in range(world)]
+    else:
+        ranks = [MgspGroupRank(scene, r, world, device=0, local_group=lg) for r in range(world)]
     lg.create()
     results, errors = [None] * world, []
 
@@ -188,6 +192,19 @@ def test_cpp_group_c5_shaped_fluid_dam_8_ranks():
     res = _run_group_threads(sc, 8, nsteps, 1e-4)
     assert sum(r[1] for r in res) > 0 and max(r[2] for r in res) > 0
     _compare_with_oracle(sc, res, nsteps, 1e-4)
+
+
+def test_cpp_group_weak_scaling_layout_one_column_per_rank():
+    """bench.py's weak-scaling workload in miniature: 4 touching sand columns (2 x 2 on the floor), one per rank, each rank
+    building only its own column; the union must evolve like the single-engine oracle run of all four columns."""
+    size, world = (8, 14, 8), 4
+    parts = [scenes.sand_columns_rank(r, world, bits=6, size_cells=size) for r in range(world)]
+    whole = dict(parts[0])
+    whole["models"] = [dict(parts[0]["models"][0], xyz=np.concatenate([p["models"][0]["xyz"] for p in parts]))]
+    nsteps = 30
+    res = _run_group_threads(None, world, nsteps, 1e-4, local_scenes=parts)
+    assert min(r[1] for r in res) > 0 and min(r[2] for r in res) > 0  # every rank shares faces: halo blocks everywhere
+    _compare_with_oracle(whole, res, nsteps, 1e-4)
 
 
 def test_rccl_transport_single_rank_equals_plain_engine():

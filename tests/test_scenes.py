@@ -23,3 +23,27 @@ def test_config_sizes():
     parts = scenes.split_slabs(c1["models"][0]["xyz"], 4)
     assert sum(p.shape[0] for p in parts) == c1["models"][0]["xyz"].shape[0]
     assert max(p.shape[0] for p in parts) - min(p.shape[0] for p in parts) <= 1
+
+
+def test_weak_scaling_columns_layout():
+    """bench.py --gpus N (weak scaling): N touching, block-aligned C3 columns that fit the 512^3 grid, one per rank."""
+    assert scenes.sand_columns_layout(1) == [tuple(int(v) for v in ((512 - 128) // 2, 12, (512 - 128) // 2))]  # N = 1 is C3 itself
+    for world in (2, 4, 8):
+        lay = scenes.sand_columns_layout(world)
+        assert len(set(lay)) == world
+        for (x, y, z) in lay:
+            assert x % 4 == 0 and z % 4 == 0 and y == 12
+            assert 12 <= x and x + 128 <= 500 and 12 <= z and z + 128 <= 500   # inside the walls
+        # every column shares a face with another one (halo blocks from the first substep)
+        for a in lay:
+            assert any((abs(a[0] - b[0]) == 128 and a[2] == b[2]) or (abs(a[2] - b[2]) == 128 and a[0] == b[0]) for b in lay if b != a)
+    # small instance: the ranks' particle sets are disjoint and each equals a plain column
+    parts = [scenes.sand_columns_rank(r, 4, bits=6, size_cells=(8, 14, 8)) for r in range(4)]
+    allp = np.concatenate([p["models"][0]["xyz"] for p in parts])
+    assert all(p["models"][0]["xyz"].shape[0] == 8 * 14 * 8 * 8 for p in parts)
+    assert np.unique(allp, axis=0).shape[0] == allp.shape[0]
+    try:
+        scenes.sand_columns_layout(10)
+        assert False
+    except ValueError:
+        pass
