@@ -228,8 +228,10 @@ struct ScatterChain {
 	float mass;
 	int win;// (int, not bool: a 1-byte member makes the compiler slice its neighbours into bytes)
 	float pw[3][3];
-	float b0, wij;
-	v2f_ b12, c12;
+	float b0, wij, bx0;
+	v2f_ b12, bx12;
+	float cp6[3];// contrib[6] * (k - fd_z) and {contrib[7], contrib[8]} * (k - fd_z): the z part of the affine momentum term,
+	v2f_ cp12[3];// the same for the nine pencils (computed once, 9 registers, instead of per node)
 	float4 acc;
 	MPM_DEV ScatterChain(float4* n0, const P2GPayload& p, float m, bool w)
 		: node0(n0)
@@ -244,21 +246,31 @@ struct ScatterChain {
 		for(int d = 0; d < 9; ++d) pp.contrib[d] = p.contrib[d];
 #pragma unroll
 		for(int d = 0; d < 3; ++d) bspline_weight_cells(pp.fd[d], pw[d]);
-		c12 = (v2f_) {pp.contrib[7], pp.contrib[8]};
+		const v2f_ c12 = {pp.contrib[7], pp.contrib[8]};
+#pragma unroll
+		for(int k = 0; k < 3; ++k) {
+			const float pz = (float) k - pp.fd[2];
+			cp6[k]		   = pp.contrib[6] * pz;
+			cp12[k]		   = c12 * pz;
+		}
 		if(win) acc = node0[0];
 	}
 	MPM_DEV void step(int o) {// o is a compile-time constant after unrolling
 		const int i = o / 9, j = (o / 3) % 3, k = o % 3;
 		if(k == 0) {
-			const float px = (float) i - pp.fd[0], py = (float) j - pp.fd[1];
-			b0	= pp.mv[0] + pp.contrib[0] * px + pp.contrib[3] * py;
-			b12 = (v2f_) {pp.mv[1] + pp.contrib[1] * px + pp.contrib[4] * py, pp.mv[2] + pp.contrib[2] * px + pp.contrib[5] * py};
-			wij = pw[0][i] * pw[1][j];
+			if(j == 0) {// x part of the affine term: once per slab of nine nodes
+				const float px = (float) i - pp.fd[0];
+				bx0			   = pp.mv[0] + pp.contrib[0] * px;
+				bx12		   = (v2f_) {pp.mv[1], pp.mv[2]} + (v2f_) {pp.contrib[1], pp.contrib[2]} * px;
+			}
+			const float py = (float) j - pp.fd[1];
+			b0			   = bx0 + pp.contrib[3] * py;
+			b12			   = bx12 + (v2f_) {pp.contrib[4], pp.contrib[5]} * py;
+			wij			   = pw[0][i] * pw[1][j];
 		}
-		const float pz = (float) k - pp.fd[2];
 		const float W  = wij * pw[2][k];
-		const v2f_ m0  = {mass, b0 + pp.contrib[6] * pz};
-		const v2f_ t12 = c12 * pz + b12;
+		const v2f_ m0  = {mass, b0 + cp6[k]};
+		const v2f_ t12 = b12 + cp12[k];
 		if(win) {// (letting the other lanes run the steps on a scratch stencil instead removes 81 exec-mask instructions per iteration and is slower: +1-4 % sand, +11 % J-fluid)
 			v2f_ a01 = {acc.x, acc.y};
 			v2f_ a23 = {acc.z, acc.w};
@@ -385,6 +397,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		bool in_arena = false;
 		int ncode	  = -1;
 		if(!drain) {
+		MPM_MARK("L_top");
 		const bool active = lane < cnt_cur;
 #ifdef MPM_G2P2G_STATS
 		st_partial += __popcll(__ballot(!active));
@@ -414,6 +427,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		rec_next = rec_nn;
 		cnt_cur			   = cnt_next;
 		cnt_next		   = cnt_nn;
+		MPM_MARK("L_gather");
 		// ---- stencil base + weights (:774-797) for ALL lanes (idle lanes of a last partial iteration carry a dummy
 		//      position inside the block); offsets in cell units (exact: dx is a power of two)
 		int base[3], arena[3];
@@ -439,6 +453,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 #ifndef MPM_PRE_SITES
 #define MPM_PRE_SITES 3
 #endif
+		MPM_MARK("L_claim");
 		constexpr int kPreSites	   = MPM_PRE_SITES;
 		constexpr int kStressSites = MAT == 0 ? 1 : (MAT == 1 ? kFcSites : (MAT == 2 ? kSandSites : kNaccSites));
 		constexpr int kSites	   = kPreSites + kStressSites + 2;
@@ -447,6 +462,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		__asm__ volatile("" ::: "memory");// another lane may have written the same byte: no store-to-load forwarding
 		win = pv_in && !code_edge(pv_code) && (int) s_owner[pv_key] == lane;
 		ScatterChain<kSites> chain(p2g + (win ? code_off(pv_code) + (lane & 1) * kP2GNodes : 0), pv, mass, win);
+		MPM_MARK("L_rebucket");
 		// ---- advect (:838)
 #pragma unroll
 		for(int d = 0; d < 3; ++d) pos[d] += vel[d] * dt;
@@ -496,6 +512,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 			if(!in_arena) atomicAdd(&status[ST_ARENA], 1);// (:877-885) contribution discarded
 		}
 		if constexpr(kPreSites == 3) chain.template at<2>();
+		MPM_MARK("L_material");
 		// ---- material update, store to the destination bin (slot == pidib: consecutive records) (:470-663)
 		float4* dst = reinterpret_cast<float4*>(mv.bins_dst + ((size_t) (binoff_dst + (pidib >> 6)) * kBin + (pidib & 63)) * NCH);
 		if constexpr(MAT == 0) {
@@ -530,6 +547,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 			dst[2] = make_float4(F[5], F[6], F[7], F[8]);
 			if constexpr(NCH == 16) dst[3] = make_float4(lj, 0.f, 0.f, 0.f);
 		}
+		MPM_MARK("L_contrib");
 		// (:850) contrib = (A m - contrib new_dt) D^-1, pre-multiplied by dx so that P2G can stay in cell units
 		{
 			const float am = mass * cfg.dx * cfg.dx * cfg.d_inv;
@@ -539,6 +557,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		}
 		chain.template at<kSites - 1>();
 		ncode = in_arena ? (narena[0] | (narena[1] << 4) | (narena[2] << 8)) : -1;
+		MPM_MARK("L_append");
 		// ---- list append: the atomics' results are in by now (and with them the next iteration's particle data)
 		{
 			const int basev = __shfl(raw_stay, stay_leader);
@@ -559,6 +578,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 			ScatterChain<1> chain(p2g + (win ? code_off(pv_code) + (lane & 1) * kP2GNodes : 0), pv, mass, win);
 			chain.template at<0>();
 		}
+		MPM_MARK("L_serial");
 		// ---- the lanes that lost the claim and the edge lanes scatter now (rare); in the draining pass: every lane
 		{
 			const bool left = pv_in && !win;
@@ -573,6 +593,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 			if(__any(left)) p2g_serial(p2g, left, pv_code, pv, mass, lane, info, next_grid);
 		}
 		if(drain) break;
+		MPM_MARK("L_handoff");
 		// ---- hand the payload to the next iteration (:887-905)
 #pragma unroll
 		for(int d = 0; d < 3; ++d) {
