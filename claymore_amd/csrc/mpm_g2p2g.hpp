@@ -313,6 +313,10 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 										   // copy, odd lanes the second: the sort puts two particles of one key that share a slice
 										   // into neighbouring lanes, so both scatter in the same pass (summed in the write-back)
 	__shared__ unsigned char s_owner[2 * 216];
+#ifdef MPM_LDS_PAD
+	__shared__ float s_pad[MPM_LDS_PAD / 4];// experiment: lower the occupancy without touching the code
+	if(size_t(grid) == 1) s_pad[threadIdx.x] = 0.f;
+#endif
 
 	const int lane = threadIdx.x;
 	// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Consecutive block numbers are spatial
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		// particles that stay in this block share one wave-aggregated atomic
 		const unsigned long long stay_m = __ballot(stay);
 		const int stay_leader			= stay_m ? __ffsll((long long) stay_m) - 1 : 0;
-		const int stay_rank				= __popcll(stay_m & ((1ull << lane) - 1ull));
+		const int stay_rank				= (int) __builtin_amdgcn_mbcnt_hi((unsigned) (stay_m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) stay_m, 0u));// set bits below this lane
 		int raw_stay = 0, raw_move = 0;
 		int b_opaque = b;
 		__asm__("" : "+v"(b_opaque));// hide the uniform address: the compiler's atomic optimiser would broadcast the
