@@ -1,26 +1,25 @@
 // mpm_g2p2g.hpp — the fused G2P + particle update + P2G kernel (g2p2g, Projects/GMPM/mgmpm_kernels.cuh:665-937 with the
-// per-material bodies :422-663), round-2 design: OCCUPANCY first.
+// per-material bodies :422-663), round-2 design.
 //
-// What the cost model says (tools/valu_microbench2/3, profiles/r02_cost_model.txt): one gfx950 wave can issue a VALU
-// instruction only every ~4.5-5 cycles (8.9 when it depends on the previous one) while the SIMD itself takes one every
-// ~1.6 (VOP2 / fma) to ~2.7 cycles (packed fp32, SGPR operands, min/max/cmp).  With two waves per SIMD - the round-1
-// kernel: 256 VGPRs, 17.8 KiB of LDS per wave - the SIMD idles most of the time no matter how the instructions are
-// ordered.  This kernel is therefore built for three to four waves per SIMD:
-//   * 128-168 VGPRs: the P2G scatter chain of the previous particle is threaded through the material update only (the
-//     round-1 pipeline through the gather as well cost ~40 more live registers), the gather keeps one z-pencil of loads in
-//     flight, its results are pinned where they are produced;
-//   * 10.8 KiB of LDS per wave (15 workgroups per CU): the advection records are read straight from global memory
-//     (prepare_blocks_kernel left them sorted), the block's look-up row stays in a register (ds_bpermute), and ALL arenas
-//     hold only nodes 1..6 of the 8^3 node cube around the block.  The gather never touches nodes 0 and 7; the scatter
-//     does only for particles that have just crossed into a neighbouring block (2 % in a collapsing column, none at rest):
-//     those lanes go through p2g_serial, which sends the shell part of a stencil to the grid with global atomics;
+// Cost model (tools/valu_rate.hip, profiles/r02_valu_rate.txt): with the whole chip busy a SIMD issues one VALU
+// instruction of this kernel's mix every ~3.9 periods of the nominal clock (VOP2 2.75, three-source VOP3 4-5, packed fp32 5.5,
+// transcendentals 8.6) and reaches that rate with two waves; a single wave gets one in only every 8-10.  The kernel is
+// bound by that issue rate (vector ALUs ~60 % busy), so the design minimises instructions per particle and keeps three
+// waves per SIMD for the LDS / memory latencies in between:
+//   * <= 168 VGPRs: the P2G scatter chain of the previous particle is threaded through the re-bucketing and the material
+//     update only (the round-1 pipeline through the gather as well cost ~40 more live registers), the gather keeps one
+//     z-pencil of loads in flight, its results are pinned where they are produced;
+//   * 10.8 KiB of LDS per wave: the advection records are read straight from global memory (prepare_blocks_kernel left them
+//     sorted), the block's look-up row stays in a register (ds_bpermute), and ALL arenas hold only nodes 1..6 of the 8^3
+//     node cube around the block.  The gather never touches nodes 0 and 7; the scatter does only for particles that have
+//     just crossed into a neighbouring block (2 % in a collapsing column, none at rest): those lanes go through
+//     p2g_serial, which sends the shell part of a stencil to the grid with global atomics;
 //   * the per-particle math needs only U and sigma (sym_eig3 in mpm_device_math.hpp), not a full SVD.
-// Measured on C3 (profiles/r02_*): three waves with the record prefetch a whole iteration ahead beat four waves with a late
-// prefetch by 5 %; two, three and four waves are within 3 % of each other - the kernel is no longer latency bound.
-// One workgroup = ONE wave = one particle block, as before: LDS operations of a single wave execute in order, which
-// is what makes the atomic-free read-modify-write scatter legal (lanes of an iteration hold distinct stencil bases:
-// prepare_blocks_kernel sorts the records into "k-th particle of every key" order; collisions left over are resolved
-// through an owner table and a retry).
+// One workgroup = ONE wave = one particle block: LDS operations of a single wave execute in order, which is what makes the
+// atomic-free read-modify-write scatter legal.  Lanes of an iteration hold distinct stencil bases: prepare_blocks_kernel
+// sorts the records by predicted base and deals them to the block's slices round-robin (a key's particles land in
+// consecutive slices); the two particles of a key that still share a slice sit in neighbouring lanes and scatter into
+// separate arenas (lane parity); what is left is decided by an owner table and goes through p2g_serial.
 #pragma once
 #include "mpm_device_math.hpp"
 

@@ -1,18 +1,15 @@
 // mpm_kernels.hpp — hand-written gfx950 kernels of the MPM substep hot path.
 //
 // Design (MI355X-first, not a translation of the reference's CUDA):
-//   * wave64 everywhere: one wave == one 4x4x4 grid block (64 cells) in the grid kernels, one wave == one
-//     64-slot AoSoA particle bin in G2P2G, so every bin-stride load/store is a full 256-B row;
-//   * G2P2G workgroup = ONE wave = one particle block.  The 8 neighbouring grid blocks are staged through LDS
-//     once (float4 {vx,vy,vz,-} per node -> one ds_read_b96 per stencil node).  The P2G scatter is atomic-free:
-//     gfx950 serialises ds_add_f32 (193 cycles per wave-instruction, profiles/r01_lds_microbench.txt), so the
-//     advection records of a block are counting-sorted (prepare_blocks_kernel, once per substep) into "k-th
-//     particle of every key" order, key = predicted stencil base; the 64 lanes of an iteration therefore hold 64
-//     distinct bases, and each lane read-modify-writes its 27 float4 nodes {m, px, py, pz} with plain
-//     ds_read_b128/ds_write_b128 - a chain of 27 ordered LDS round trips that ScatterChain threads through the
-//     NEXT particle's gather / SVD / stress arithmetic (lanes that collide with another lane's stencil base are
-//     detected through an LDS owner table and retried).  The arena is written back with one hardware f32 atomic
-//     per touched node and channel;
+//   * wave64 everywhere: one wave == one 4x4x4 grid block (64 cells) in the grid kernels (every channel a 256-B row), one
+//     wave == one particle block in G2P2G (mpm_g2p2g.hpp); particles live in 64-slot bins of 16 / 48 / 64-B records, one
+//     record = one particle = one to four 16-B accesses of its lane;
+//   * the P2G scatter is atomic-free: gfx950 serialises ds_add_f32 (193 cycles per wave-instruction,
+//     profiles/r01_lds_microbench.txt), so the advection records of a block are counting-sorted by predicted stencil base
+//     and dealt to 64-record slices round-robin (prepare_blocks_kernel, once per substep): the 64 lanes of an iteration
+//     hold distinct bases, and each lane read-modify-writes its 27 float4 nodes {m, px, py, pz} with plain
+//     ds_read_b128 / ds_write_b128 (mpm_g2p2g.hpp); the arena is written back with one hardware f32 atomic per touched
+//     node and channel;
 //   * block-level advection lists instead of the reference's cell buckets + compaction passes: a particle
 //     appends ONE 4-byte record {direction tag, predicted stencil base, slot} to the list of the block it lands in
 //     (wave-aggregated atomic for the particles that stay), and next step's G2P2G consumes that list
@@ -37,7 +34,7 @@
 
 namespace mpm {
 
-constexpr int kBin		  = 64; // particles per AoSoA bin == wavefront width
+constexpr int kBin		  = 64; // particle records per bin == wavefront width
 constexpr int kG2P2GThreads = 64; // ONE wave per particle block: no cross-wave LDS hazards, no barriers that wait
 constexpr int kMaxModels  = 8;
 constexpr int kSortKeys		= 216; // sort key = PREDICTED stencil base of the particle in the arena of its block (6^3 values)
