@@ -55,6 +55,10 @@ struct mpm_ctx {
 	int device = 0;
 	hipStream_t s_compute = nullptr, s_comm = nullptr;
 	hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_g0 = nullptr, ev_g1 = nullptr, ev_comm = nullptr, ev_halo = nullptr;
+	// grid[0] already holds the velocities of the coming substep (the rebuild's carry-over applied the grid update for this dt):
+	// only inside mpm_run_fixed, never when a call returns
+	bool grid_preupdated = false;
+	float preupdate_dt	 = 0.f;
 	Partition part[2];
 	float* grid[2] = {nullptr, nullptr};
 	int rollid	   = 0;
@@ -487,6 +491,11 @@ int mpm_initial_setup(mpm_ctx* ctx) {
 // grid-update phase, gmpm_simulator.cuh:326-347
 static int launch_grid_update(mpm_ctx* ctx, float dt) {
 	hipStream_t s = ctx->s_compute;
+	if(ctx->grid_preupdated) {
+		ctx->grid_preupdated = false;
+		if(dt != ctx->preupdate_dt) return fail(ctx, MPM_ERR_INVALID, "grid was updated for another dt");
+		return MPM_OK;
+	}
 	HIP_TRY(hipMemsetAsync(ctx->d_maxvel, 0, sizeof(unsigned) * kMaxVelSlots * kMaxVelStride, s));
 	if(ctx->nbc) {
 		if(ctx->has_collision)
@@ -602,7 +611,8 @@ static int launch_prepare(mpm_ctx* ctx, int cur, int prev, bool list_is_out, int
 }
 
 // partition rebuild, gmpm_simulator.cuh:415-579 (launches only; no host round trip inside)
-static int launch_rebuild(mpm_ctx* ctx) {
+// fuse_dt > 0: the carry-over applies the grid update of the next substep (dt = fuse_dt) as well
+static int launch_rebuild(mpm_ctx* ctx, float fuse_dt = 0.f) {
 	hipStream_t s = ctx->s_compute;
 	GridCfg& g	  = ctx->g;
 	const int r = ctx->rollid, n = r ^ 1;
@@ -626,7 +636,13 @@ static int launch_rebuild(mpm_ctx* ctx) {
 	const unsigned rg8 = std::max(1u, std::min(4096u, cdiv((size_t) ctx->ebc * 8, 256))), rg32 = std::max(1u, std::min(8192u, cdiv((size_t) ctx->ebc * 32, 256)));
 	register_blocks_kernel<0, 1><<<rg8, 256, 0, s>>>(g, &ctx->d_status[ST_PBC], Pn.table, Pn.keys, Pn.count, ctx->d_status);
 	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_NBC], Pn.count, sizeof(int), hipMemcpyDeviceToDevice, s));
-	carry_grid_kernel<<<2048, 256, 0, s>>>(g, &ctx->d_status[ST_NBC], Pn.keys, Pr.table, ctx->nbc, ctx->grid[1], ctx->grid[0]);
+	if(fuse_dt > 0.f && !ctx->has_collision) {
+		HIP_TRY(hipMemsetAsync(ctx->d_maxvel, 0, sizeof(unsigned) * kMaxVelSlots * kMaxVelStride, s));
+		carry_grid_kernel<true><<<2048, 256, 0, s>>>(g, &ctx->d_status[ST_NBC], Pn.keys, Pr.table, ctx->nbc, ctx->grid[1], ctx->grid[0], fuse_dt, ctx->d_maxvel);
+		ctx->grid_preupdated = true;
+		ctx->preupdate_dt	 = fuse_dt;
+	} else
+		carry_grid_kernel<false><<<2048, 256, 0, s>>>(g, &ctx->d_status[ST_NBC], Pn.keys, Pr.table, ctx->nbc, ctx->grid[1], ctx->grid[0], 0.f, nullptr);
 	register_blocks_kernel<-1, 1><<<rg32, 256, 0, s>>>(g, &ctx->d_status[ST_PBC], Pn.table, Pn.keys, Pn.count, ctx->d_status);
 	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_EBC], Pn.count, sizeof(int), hipMemcpyDeviceToDevice, s));
 	// the next G2P2G runs in the new numbering n with the particle data laid out in r: sort its lists (the ones the last
@@ -760,7 +776,7 @@ int mpm_run_fixed(mpm_ctx* ctx, int nsteps, float dt) {
 		if(rc) return rc;
 		rc = launch_g2p2g(ctx, dt, dt);// records ev_g0 / ev_g1 around the G2P2G kernel(s)
 		if(rc) return rc;
-		rc = launch_rebuild(ctx);
+		rc = launch_rebuild(ctx, it + 1 < nsteps ? dt : 0.f);// the last substep leaves the canonical state behind
 		if(rc) return rc;
 		HIP_TRY(hipEventRecord(ctx->ev_b, s));
 		HIP_TRY(hipMemcpyAsync(ctx->h_maxvel, ctx->d_maxvel, sizeof(float) * kMaxVelSlots * kMaxVelStride, hipMemcpyDeviceToHost, s));

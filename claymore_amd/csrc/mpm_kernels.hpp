@@ -478,21 +478,53 @@ __global__ __launch_bounds__(256) void register_blocks_kernel(GridCfg cfg, const
 // Carry the P2G result (old numbering) into the current grid (new numbering): every NEW neighbour block is written
 // exactly once - copied from its old block if it existed, zero otherwise.  Replaces clear_grid +
 // mark_active_grid_blocks + copy_selected_grid_blocks (gmpm_simulator.cuh:436-446, :536-541).  One wave per block.
-__global__ __launch_bounds__(256) void carry_grid_kernel(GridCfg cfg, const int* __restrict__ new_nbc_ptr, const int* __restrict__ new_keys, const int* __restrict__ old_table, int old_nbc, const float* __restrict__ p2g_grid, float* __restrict__ grid) {
+// UPDATE: the grid update of the NEXT substep (update_grid_velocity_query_max, :325-420; same arithmetic as grid_update_kernel)
+// is applied on the way - momentum -> velocity, gravity, slip walls, max |v|^2 - which saves that kernel's own pass over the
+// grid.  Used between the substeps of mpm_run_fixed, where the next dt is known and nobody looks at the grid in between.
+template<bool UPDATE>
+__global__ __launch_bounds__(256) void carry_grid_kernel(GridCfg cfg, const int* __restrict__ new_nbc_ptr, const int* __restrict__ new_keys, const int* __restrict__ old_table, int old_nbc, const float* __restrict__ p2g_grid, float* __restrict__ grid, float dt, unsigned* __restrict__ max_vel_bits) {
 	const int nbc  = min(*new_nbc_ptr, cfg.cap);
 	const int lane = threadIdx.x & 63;
+	float vel_sqr  = 0.f;
 	for(int nb = blockIdx.x * 4 + (threadIdx.x >> 6); nb < nbc; nb += gridDim.x * 4) {
-		const int old = table_query(cfg, old_table, new_keys[3 * nb], new_keys[3 * nb + 1], new_keys[3 * nb + 2]);
+		const int kx = new_keys[3 * nb], ky = new_keys[3 * nb + 1], kz = new_keys[3 * nb + 2];
+		const int old = table_query(cfg, old_table, kx, ky, kz);
 		float4 v	  = {0.f, 0.f, 0.f, 0.f};
 		if(old >= 0 && old < old_nbc) {
 			const float* s = p2g_grid + (size_t) old * 256;
 			v			   = {s[lane], s[64 + lane], s[128 + lane], s[192 + lane]};
+		}
+		if constexpr(UPDATE) {
+			if(v.x > 0.0f) {
+				const bool wx = kx < cfg.boundary || kx >= cfg.G - cfg.boundary;
+				const bool wy = ky < cfg.boundary || ky >= cfg.G - cfg.boundary;
+				const bool wz = kz < cfg.boundary || kz >= cfg.G - cfg.boundary;
+				const float mass_inv = 1.f / v.x;
+				const float v0		 = wx ? 0.0f : v.y * mass_inv;
+				const float v1		 = (wy ? 0.0f : v.z * mass_inv) + cfg.gravity * dt;
+				const float v2		 = wz ? 0.0f : v.w * mass_inv;
+				v.y					 = v0;
+				v.z					 = v1;
+				v.w					 = v2;
+				float q				 = v0 * v0 + v1 * v1 + v2 * v2;
+				if(q != q) q = __builtin_inff();
+				vel_sqr = fmaxf(vel_sqr, q);
+			}
 		}
 		float* d	  = grid + (size_t) nb * 256;
 		d[lane]		  = v.x;
 		d[64 + lane]  = v.y;
 		d[128 + lane] = v.z;
 		d[192 + lane] = v.w;
+	}
+	if constexpr(UPDATE) {
+#pragma unroll
+		for(int off = 32; off > 0; off >>= 1) vel_sqr = fmaxf(vel_sqr, __shfl_xor(vel_sqr, off));
+		if(lane == 0 && vel_sqr > 0.f) {
+			const unsigned bits = __float_as_uint(vel_sqr);
+			unsigned* slot		= max_vel_bits + (blockIdx.x & (kMaxVelSlots - 1)) * kMaxVelStride;
+			if(bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+		}
 	}
 }
 
