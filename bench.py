@@ -120,6 +120,12 @@ def main():
                     help="N > 1: weak = one C3 column per rank (N x 40.1 M particles), strong = the one C3 column cut N ways")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON record: libraries that print banners there (gloo's "connected to N peer ranks",
+    # RCCL's version block) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -263,7 +269,8 @@ def main():
             out["roofline"]["algorithmic_bytes"] = n_rank * bpp
         if world == 1 and not args.no_cpu_baseline and not args.mgsp:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_mgsp:
         dist.destroy_process_group()
 

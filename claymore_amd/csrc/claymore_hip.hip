@@ -59,6 +59,7 @@ struct mpm_ctx {
 	// only inside mpm_run_fixed, never when a call returns
 	bool grid_preupdated = false;
 	float preupdate_dt	 = 0.f;
+	float fuse_dt_once	 = 0.f;// set by a driver that knows the next substep's dt (mpm_group_run_fixed): consumed by the next rebuild
 	Partition part[2];
 	float* grid[2] = {nullptr, nullptr};
 	int rollid	   = 0;
@@ -613,6 +614,8 @@ static int launch_prepare(mpm_ctx* ctx, int cur, int prev, bool list_is_out, int
 // partition rebuild, gmpm_simulator.cuh:415-579 (launches only; no host round trip inside)
 // fuse_dt > 0: the carry-over applies the grid update of the next substep (dt = fuse_dt) as well
 static int launch_rebuild(mpm_ctx* ctx, float fuse_dt = 0.f) {
+	if(fuse_dt == 0.f) fuse_dt = ctx->fuse_dt_once;
+	ctx->fuse_dt_once = 0.f;
 	hipStream_t s = ctx->s_compute;
 	GridCfg& g	  = ctx->g;
 	const int r = ctx->rollid, n = r ^ 1;

@@ -117,7 +117,7 @@ def test_multi_context_equals_oracle(world, kind, phased):
 
 
 # ---- the C++ group driver (claymore_amd/csrc/mpm_group.inc) -----------------------------------------------------------
-def _run_group_threads(scene, world, nsteps, dt, adaptive=None, local_scenes=None):
+def _run_group_threads(scene, world, nsteps, dt, adaptive=None, local_scenes=None, fixed=False):
     """`world` engine contexts on one GPU, one thread per rank, every substep inside mpm_group_substep (in-process
     transport: device-to-device copies; the RCCL transport needs one GPU per rank).  local_scenes: a partition made by
     the caller (one scene per rank) instead of the equal-count slabs of `scene`."""
@@ -134,7 +134,10 @@ def _run_group_threads(scene, world, nsteps, dt, adaptive=None, local_scenes=Non
             sim = ranks[rank]
             sim.initial_setup()
             shared = 0
-            if adaptive is None:
+            if adaptive is None and fixed:      # mpm_group_run_fixed: the whole loop inside the library
+                sim.run_fixed(nsteps, dt)
+                shared, steps = sum(sim.send_counts), nsteps
+            elif adaptive is None:
                 for _ in range(nsteps):
                     sim.substep(dt, dt)
                     shared = max(shared, sum(sim.send_counts))
@@ -202,7 +205,7 @@ def test_cpp_group_weak_scaling_layout_one_column_per_rank():
     whole = dict(parts[0])
     whole["models"] = [dict(parts[0]["models"][0], xyz=np.concatenate([p["models"][0]["xyz"] for p in parts]))]
     nsteps = 30
-    res = _run_group_threads(None, world, nsteps, 1e-4, local_scenes=parts)
+    res = _run_group_threads(None, world, nsteps, 1e-4, local_scenes=parts, fixed=True)
     assert min(r[1] for r in res) > 0 and min(r[2] for r in res) > 0  # every rank shares faces: halo blocks everywhere
     _compare_with_oracle(whole, res, nsteps, 1e-4)
 
