@@ -634,7 +634,7 @@ static int launch_rebuild(mpm_ctx* ctx, float fuse_dt = 0.f) {
 		rm.row_of[mi]	 = m.row_of;
 		rm.binoff[mi]	 = m.binoff[r];// becomes the destination offsets after the roll
 	}
-	if(ctx->ebc) compact_blocks_kernel<<<cdiv(ctx->ebc, 256), 256, 0, s>>>(g, ctx->ebc, rm, Pr.keys, Pn.keys, Pn.table, Pn.count, ctx->d_status);
+	if(ctx->ebc) compact_blocks_kernel<<<cdiv(ctx->ebc, 1024), 1024, 0, s>>>(g, ctx->ebc, rm, Pr.keys, Pn.keys, Pn.table, Pn.count, ctx->d_status);
 	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_PBC], Pn.count, sizeof(int), hipMemcpyDeviceToDevice, s));
 	const unsigned rg8 = std::max(1u, std::min(4096u, cdiv((size_t) ctx->ebc * 8, 256))), rg32 = std::max(1u, std::min(8192u, cdiv((size_t) ctx->ebc * 32, 256)));
 	register_blocks_kernel<0, 1><<<rg8, 256, 0, s>>>(g, &ctx->d_status[ST_PBC], Pn.table, Pn.keys, Pn.count, ctx->d_status);

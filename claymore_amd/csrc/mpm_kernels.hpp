@@ -96,6 +96,34 @@ __device__ __forceinline__ int wave_append(int* counter, bool pred) {
 }
 
 
+// The same for a whole workgroup (every thread must call it; blockDim.x a multiple of 64, at most 1024): `amount` items per
+// thread, ONE global atomic per workgroup.  Returns the thread's first slot (meaningless for amount == 0).
+__device__ __forceinline__ int block_append(int* counter, int amount) {
+	__shared__ int s_wave[16];
+	__shared__ int s_base;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
+	int incl = amount;// inclusive scan over the wave
+#pragma unroll
+	for(int off = 1; off < 64; off <<= 1) {
+		const int v = __shfl_up(incl, off);
+		if(lane >= off) incl += v;
+	}
+	__syncthreads();// (s_wave / s_base may still be read by a previous call)
+	if(lane == 63) s_wave[wave] = incl;
+	__syncthreads();
+	if(threadIdx.x == 0) {
+		int total = 0;
+		for(int w = 0; w < nwaves; ++w) {
+			const int c = s_wave[w];
+			s_wave[w]	= total;
+			total += c;
+		}
+		s_base = total ? atomicAdd(counter, total) : 0;
+	}
+	__syncthreads();
+	return s_base + s_wave[wave] + incl - amount;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Layout of a block's advection list after prepare_blocks_kernel.  The list is cut into chunks of kListChunk slots
 // (records [512 c, 512 c + n) of the block); a chunk with n records is laid out as S = ceil(n / 64) slices of 64 slots
@@ -405,7 +433,10 @@ struct RebuildModels {
 // update_buckets + compute_bin_capacity + exclusive_scan (gmpm_simulator.cuh:436-505): blocks that received
 // particles get a new number (wave-aggregated atomic), their key goes into the new table, their bins are
 // allocated.  Order of the new numbering is arbitrary (as it is in the reference: insert order of atomics).
-__global__ __launch_bounds__(256) void compact_blocks_kernel(GridCfg cfg, int ebc, RebuildModels rm, const int* __restrict__ old_keys, int* __restrict__ new_keys, int* __restrict__ new_table, int* __restrict__ new_count, int* __restrict__ status) {
+__global__ __launch_bounds__(1024) void compact_blocks_kernel(GridCfg cfg, int ebc, RebuildModels rm, const int* __restrict__ old_keys, int* __restrict__ new_keys, int* __restrict__ new_table, int* __restrict__ new_count, int* __restrict__ status) {
+	// The three counters of this kernel (new block numbers, bins, particle totals) share a cache line: same-line atomics
+	// serialise in L2 at ~11 ns each, so they are issued once per 1024-thread workgroup (3 x 95 at C3), not once per wave
+	// (3 x 1516 = 33 us, which was the kernel's whole run time).
 	const int b = blockIdx.x * blockDim.x + threadIdx.x;
 	int c[kMaxModels];
 	bool any = false;
@@ -413,31 +444,41 @@ __global__ __launch_bounds__(256) void compact_blocks_kernel(GridCfg cfg, int eb
 		c[m] = b < ebc ? rm.out_count[m][b] : 0;
 		any |= c[m] > 0;
 	}
-	// particles per model (the reference's "total number of particles" check, gmpm_simulator.cuh:617): one atomic per wave
+	// particles per model (the reference's "total number of particles" check, gmpm_simulator.cuh:617)
+	__shared__ int s_part[kMaxModels];
+	if(threadIdx.x < kMaxModels) s_part[threadIdx.x] = 0;
+	__syncthreads();
 	for(int m = 0; m < rm.n; ++m) {
 		int t = c[m];
 #pragma unroll
 		for(int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
-		if((threadIdx.x & 63) == 0 && t) atomicAdd(&status[ST_PART0 + m], t);
+		if((threadIdx.x & 63) == 0 && t) atomicAdd(&s_part[m], t);
 	}
-	if(!any) return;
-	const int nb = atomicAdd(new_count, 1);// the compiler turns this into one atomic per wave
-	const int kx = old_keys[3 * b], ky = old_keys[3 * b + 1], kz = old_keys[3 * b + 2];
-	new_keys[3 * nb]					  = kx;
-	new_keys[3 * nb + 1]				  = ky;
-	new_keys[3 * nb + 2]				  = kz;
-	new_table[key_index(cfg, kx, ky, kz)] = nb;
+	__syncthreads();
+	if((int) threadIdx.x < rm.n && s_part[threadIdx.x]) atomicAdd(&status[ST_PART0 + threadIdx.x], s_part[threadIdx.x]);
+	const int nb = block_append(new_count, any ? 1 : 0);
+	int kx = 0, ky = 0, kz = 0;
+	if(any) {
+		kx = old_keys[3 * b], ky = old_keys[3 * b + 1], kz = old_keys[3 * b + 2];
+		new_keys[3 * nb]					  = kx;
+		new_keys[3 * nb + 1]				  = ky;
+		new_keys[3 * nb + 2]				  = kz;
+		new_table[key_index(cfg, kx, ky, kz)] = nb;
+	}
 	for(int m = 0; m < rm.n; ++m) {
-		rm.size[m][nb]	 = c[m];
-		rm.row_of[m][nb] = b;
-		const int nbins	 = (c[m] + kBin - 1) / kBin;
-		rm.binoff[m][nb] = nbins ? atomicAdd(&status[ST_BINS0 + m], nbins) : 0;
+		const int nbins = any ? (c[m] + kBin - 1) / kBin : 0;
+		const int first = block_append(&status[ST_BINS0 + m], nbins);
+		if(any) {
+			rm.size[m][nb]	 = c[m];
+			rm.row_of[m][nb] = b;
+			rm.binoff[m][nb] = nbins ? first : 0;
+		}
 	}
 }
 
 // register_neighbor_blocks / register_exterior_blocks (mgmpm_kernels.cuh:117-151); pbc is read from device memory.
 // One LANE per (particle block, offset): the (HI-LO+1)^3 look-ups of a block are independent loads instead of a chain of
-// dependent ones in one thread (27 x ~1 us), and the few lanes that really insert share one counter atomic per wave.
+// dependent ones in one thread (27 x ~1 us), and the few lanes that really insert share one counter atomic per workgroup.
 template<int LO, int HI>
 __global__ __launch_bounds__(256) void register_blocks_kernel(GridCfg cfg, const int* __restrict__ pbc_ptr, int* table, int* keys, int* count, int* status) {
 	constexpr int W	   = HI - LO + 1;
@@ -445,7 +486,8 @@ __global__ __launch_bounds__(256) void register_blocks_kernel(GridCfg cfg, const
 	constexpr int LPB  = NOFF <= 8 ? 8 : 32;// lanes per block (27 padded to 32)
 	const int pbc	   = *pbc_ptr;
 	const long long total = (long long) pbc * LPB;
-	for(long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x; t < ((total + 63) & ~63ll); t += (long long) gridDim.x * blockDim.x) {
+	const long long bound = (total + blockDim.x - 1) / blockDim.x * blockDim.x;// whole workgroups stay in the loop together (block_append has barriers)
+	for(long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x; t < bound; t += (long long) gridDim.x * blockDim.x) {
 		const int b = (int) (t / LPB), o = (int) (t % LPB);
 		bool claim	= false;
 		int x = 0, y = 0, z = 0;
@@ -460,7 +502,7 @@ __global__ __launch_bounds__(256) void register_blocks_kernel(GridCfg cfg, const
 				if(table[i] == -1) claim = atomicCAS(&table[i], -1, -2) == -1;
 			}
 		}
-		const int idx = wave_append(count, claim);// whole waves reach this point together (the loop bound is wave-aligned)
+		const int idx = block_append(count, claim ? 1 : 0);// one counter atomic per workgroup (same-address atomics serialise in L2)
 		if(claim) {
 			if(idx < cfg.cap) {
 				table[i]		  = idx;
