@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--fraction", type=float, default=1.0, help="debug: shrink the sand column")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mgsp", action="store_true", help="debug: drive the multi-GPU code path even with one rank")
+    ap.add_argument("--max-ppc", type=int, default=0, help="debug: override the scene's particles-per-cell capacity (reference: 128)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = one C3 column per rank (N x 40.1 M particles), strong = the one C3 column cut N ways")
     args = ap.parse_args()
@@ -162,6 +163,8 @@ def main():
     else:
         sc, workload = make_scene(args)
         n_total = scenes.total_particles(sc)
+    if args.max_ppc:
+        sc["config"]["max_ppc"] = args.max_ppc
     material = sc["models"][0]["material"]
     dt = sc["dt"]
 

@@ -137,7 +137,7 @@ int main(int argc, char** argv) {
 
 	mpm_config cfg;
 	if(mpm_default_config(bits, &cfg)) die(nullptr, MPM_ERR_INVALID);
-	cfg.max_ppc = (int) num(sim, "max_ppc", 32);
+	cfg.max_ppc = (int) num(sim, "max_ppc", 128);
 	cfg.gravity = num(sim, "gravity", cfg.gravity);
 	mpm_ctx* ctx = nullptr;
 	int rc		 = mpm_create(&cfg, gpuid, &ctx);

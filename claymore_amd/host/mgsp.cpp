@@ -85,7 +85,7 @@ int main(int argc, char** argv) {
 		mpm_default_config(bits, &cfg);
 		cfg.gravity = -9.8f * 0.5f;// Projects/MGSP/settings.h:108
 		cfg.cfl		= 0.3f;
-		cfg.max_ppc = 32;
+		cfg.max_ppc = 128;// settings.h:75
 		check(D, mpm_create(&cfg, D.gpu, &D.ctx));
 		int lo[3], hi[3];
 		if(scenario == 3) {

@@ -54,7 +54,7 @@ def two_spheres(bits=7, radius_cells=9.0, gap_cells=None, speed=0.5, material=FI
     prm = {"volume": _vol(bits), "youngs_modulus": youngs, "poisson_ratio": 0.4, "rho": 1e3}
     return {
         "name": "two_spheres", "bits": bits, "dt": 1e-4,
-        "config": {"max_ppc": 32},
+        "config": {"max_ppc": 128},
         "models": [
             {"material": material, "xyz": lattice_sphere(bits, c0, radius_cells), "v0": (speed, 0.0, 0.0), "params": dict(prm)},
             {"material": material, "xyz": lattice_sphere(bits, c1, radius_cells), "v0": (-speed, 0.0, 0.0), "params": dict(prm)},
@@ -65,7 +65,7 @@ def two_spheres(bits=7, radius_cells=9.0, gap_cells=None, speed=0.5, material=FI
 def sphere_drop(bits=8, radius_cells=53.0, center=(0.5, 0.6, 0.5), material=FIXED_COROTATED):
     """C2: one elastic sphere dropped under gravity (~5.0 M particles at bits 8, R = 53 dx)."""
     prm = {"volume": _vol(bits)} if material != SAND else {}
-    return {"name": "sphere_drop", "bits": bits, "dt": 1e-4, "config": {"max_ppc": 32},
+    return {"name": "sphere_drop", "bits": bits, "dt": 1e-4, "config": {"max_ppc": 128},
             "models": [{"material": material, "xyz": lattice_sphere(bits, center, radius_cells), "v0": (0, 0, 0), "params": prm}]}
 
 
@@ -77,7 +77,7 @@ def sand_column(bits=9, size_cells=(128, 306, 128), min_corner=None):
         min_corner = ((n - size_cells[0]) // 2, 12, (n - size_cells[2]) // 2)
     lo = np.array(min_corner)
     hi = lo + np.array(size_cells)
-    return {"name": "sand_column", "bits": bits, "dt": 1e-4, "config": {"max_ppc": 32},
+    return {"name": "sand_column", "bits": bits, "dt": 1e-4, "config": {"max_ppc": 128},
             "models": [{"material": SAND, "xyz": lattice_box(bits, lo, hi), "v0": (0, 0, 0), "params": {}}]}
 
 
@@ -116,7 +116,7 @@ def fluid_dam(bits=10, size_cells=(256, 192, 256), min_corner=(12, 12, 12)):
     lo = np.array(min_corner)
     hi = lo + np.array(size_cells)
     dt = 1e-4 if bits <= 8 else 1e-4 * 2.0 ** (8 - bits)
-    return {"name": "fluid_dam", "bits": bits, "dt": dt, "config": {"max_ppc": 32},
+    return {"name": "fluid_dam", "bits": bits, "dt": dt, "config": {"max_ppc": 128},
             "models": [{"material": J_FLUID, "xyz": lattice_box(bits, lo, hi), "v0": (0, 0, 0), "params": {}}]}
 
 
