@@ -396,7 +396,8 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		const bool drain = idx0 >= size;
 		bool win		 = false;
 		const bool pv_in = pv_code >= 0;
-		P2GPayload pl;
+		P2GPayload pl;// (only pl.contrib is used inside the iteration: the stress P F^T vol; the payload itself is formed at the hand-over)
+		float vel[3], A[9], nfd[3];
 		bool in_arena = false;
 		int ncode	  = -1;
 		if(!drain) {
@@ -434,7 +435,6 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		// ---- stencil base + weights (:774-797) for ALL lanes (idle lanes of a last partial iteration carry a dummy
 		//      position inside the block); offsets in cell units (exact: dx is a power of two)
 		int base[3], arena[3];
-		float vel[3], A[9];
 		{
 			float fd[3], w[3][3];
 #pragma unroll
@@ -478,8 +478,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		for(int d = 0; d < 3; ++d) {
 			const float p	= pos[d] * dx_inv;
 			const int nbase = lround_pos(p) - 1;
-			pl.fd[d]		= p - (float) nbase;
-			pl.mv[d]		= mass * vel[d];
+			nfd[d]			= p - (float) nbase;
 			narena[d]		= arena[d] + (nbase - base[d]);// new stencil base in the node cube of the block the particle came from
 			in_arena &= (narena[d] >= 0) & (narena[d] <= 5);
 			// the block the particle lands in: cube coordinates 1..4 belong to this block, 0 / 5.. to the neighbours
@@ -488,7 +487,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 			// sort key for the NEXT step: the stencil base predicted after one more advection with the current velocity, in the
 			// cube of the block the particle is in after THIS step, clamped to 0..5 (a prediction: ties do not matter).
 			// rint((pos + vel new_dt) / dx) - 1 - nbase == rint(fd + vel new_dt / dx) - 1 because nbase is an integer.
-			const int step = (int) __builtin_rintf(fmaf(vel[d], pred, pl.fd[d]));
+			const int step = (int) __builtin_rintf(fmaf(vel[d], pred, nfd[d]));
 			pk[d]		   = min(max(((narena[d] - 1) & 3) + step, 0), 5);
 		}
 		if constexpr(kPreSites == 3) chain.template at<0>();
@@ -551,13 +550,6 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 			if constexpr(NCH == 16) dst[3] = make_float4(lj, 0.f, 0.f, 0.f);
 		}
 		MPM_MARK("L_contrib");
-		// (:850) contrib = (A m - contrib new_dt) D^-1, pre-multiplied by dx so that P2G can stay in cell units
-		{
-			const float am = mass * cfg.dx * cfg.dx * cfg.d_inv;
-			const float cs = new_dt * cfg.d_inv * cfg.dx;
-#pragma unroll
-			for(int d = 0; d < 9; ++d) pl.contrib[d] = A[d] * am - pl.contrib[d] * cs;
-		}
 		chain.template at<kSites - 1>();
 		ncode = in_arena ? (narena[0] | (narena[1] << 4) | (narena[2] << 8)) : -1;
 		MPM_MARK("L_append");
@@ -597,14 +589,20 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		}
 		if(drain) break;
 		MPM_MARK("L_handoff");
-		// ---- hand the payload to the next iteration (:887-905)
+		// ---- hand the payload to the next iteration (:887-905).  It is formed here, after the last reader of the previous
+		//      payload (chain, p2g_serial), so that it can be computed straight into the loop-carried registers (no copies).
+		//      (:850) contrib = (A m - stress new_dt) D^-1, pre-multiplied by dx so that P2G can stay in cell units
+		{
+			const float am = mass * cfg.dx * cfg.dx * cfg.d_inv;
+			const float cs = new_dt * cfg.d_inv * cfg.dx;
 #pragma unroll
-		for(int d = 0; d < 3; ++d) {
-			pv.fd[d] = pl.fd[d];
-			pv.mv[d] = pl.mv[d];
+			for(int d = 0; d < 3; ++d) {
+				pv.fd[d] = nfd[d];
+				pv.mv[d] = mass * vel[d];
+			}
+#pragma unroll
+			for(int d = 0; d < 9; ++d) pv.contrib[d] = A[d] * am - pl.contrib[d] * cs;
 		}
-#pragma unroll
-		for(int d = 0; d < 9; ++d) pv.contrib[d] = pl.contrib[d];
 		pv_code = ncode;
 	}
 #ifdef MPM_G2P2G_STATS
