@@ -15,7 +15,7 @@ MATERIAL_NAMES = {"jfluid": J_FLUID, "fixed_corotated": FIXED_COROTATED, "sand":
 class Config(C.Structure):
     _fields_ = [("domain_bits", C.c_int), ("max_ppc", C.c_int), ("boundary_blocks", C.c_int),
                 ("gravity", C.c_float), ("cfl", C.c_float), ("max_blocks", C.c_int64),
-                ("grow", C.c_int), ("reserved", C.c_int * 5)]
+                ("grow", C.c_int), ("drop_overflow", C.c_int), ("reserved", C.c_int * 4)]
 
 
 class MaterialParams(C.Structure):
@@ -40,7 +40,7 @@ class Counts(C.Structure):
 
 class Diagnostics(C.Structure):
     _fields_ = [("lost_particles", C.c_int64), ("discarded_p2g", C.c_int64), ("overflow_flags", C.c_int),
-                ("reserved", C.c_int * 5)]
+                ("dropped_particles", C.c_int), ("reserved", C.c_int * 4)]
 
 
 class Timers(C.Structure):

@@ -355,7 +355,7 @@ static int read_status(mpm_ctx* ctx) {
 static int check_status(mpm_ctx* ctx) {
 	const int* st = ctx->h_status;
 	if(st[ST_OVERFLOW] & 1) return fail(ctx, MPM_ERR_CAPACITY, "Too much active blocks: block capacity " + std::to_string(ctx->g.cap) + " exceeded");
-	if(st[ST_OVERFLOW] & 2) return fail(ctx, MPM_ERR_CAPACITY, "particles-per-block capacity exceeded (max_ppc*64 = " + std::to_string(ctx->g.ppb) + ")");
+	if((st[ST_OVERFLOW] & 2) && !ctx->cfg.drop_overflow) return fail(ctx, MPM_ERR_CAPACITY, "particles-per-block capacity exceeded (max_ppc*64 = " + std::to_string(ctx->g.ppb) + ")");
 	return MPM_OK;
 }
 
@@ -890,8 +890,9 @@ int mpm_get_diagnostics(mpm_ctx* ctx, mpm_diagnostics* d) {
 	d->lost_particles = ctx->h_status[ST_LOST];
 	d->discarded_p2g  = ctx->h_status[ST_ARENA];
 	d->overflow_flags = ctx->h_status[ST_OVERFLOW];
+	d->dropped_particles = ctx->h_status[ST_DROPPED];
 #ifdef MPM_G2P2G_STATS
-	for(int i = 0; i < 5; ++i) d->reserved[i] = ctx->h_status[24 + i];// cumulative: iterations, loser lanes, edge lanes, iterations with a retry, idle lanes
+	for(int i = 0; i < 4; ++i) d->reserved[i] = ctx->h_status[24 + i];// cumulative: iterations, loser lanes, edge lanes, iterations with a retry
 #endif
 	return MPM_OK;
 }

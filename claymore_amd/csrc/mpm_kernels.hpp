@@ -42,7 +42,7 @@ constexpr int kKeyBits		= 8;
 constexpr int kStay		  = 13; // dir_offset(0,0,0), utility_funcs.hpp:25-27
 
 // status block indices (device ints, read back once per substep)
-enum { ST_PBC = 0, ST_NBC = 1, ST_EBC = 2, ST_OVERFLOW = 3, ST_LOST = 4, ST_ARENA = 5, ST_BINS0 = 8, ST_PART0 = 16, ST_WORDS = 32 };
+enum { ST_PBC = 0, ST_NBC = 1, ST_EBC = 2, ST_OVERFLOW = 3, ST_LOST = 4, ST_ARENA = 5, ST_DROPPED = 6, ST_BINS0 = 8, ST_PART0 = 16, ST_WORDS = 32 };
 
 struct GridCfg {
 	int G;		  // blocks per axis
@@ -442,6 +442,11 @@ __global__ __launch_bounds__(1024) void compact_blocks_kernel(GridCfg cfg, int e
 	bool any = false;
 	for(int m = 0; m < rm.n; ++m) {
 		c[m] = b < ebc ? rm.out_count[m][b] : 0;
+		if(c[m] > cfg.ppb) {// more arrivals than list slots: G2P2G has set the overflow flag and left the surplus records out (drop policy:
+							// the block goes on with the ppb particles it has slots for; otherwise the host reports MPM_ERR_CAPACITY)
+			atomicAdd(&status[ST_DROPPED], c[m] - cfg.ppb);
+			c[m] = cfg.ppb;
+		}
 		any |= c[m] > 0;
 	}
 	// particles per model (the reference's "total number of particles" check, gmpm_simulator.cuh:617)

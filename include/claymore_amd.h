@@ -59,7 +59,10 @@ typedef struct mpm_config {
 	int64_t max_blocks;	 /* (initial) capacity in (exterior) blocks; settings.h:89 G_MAX_ACTIVE_BLOCK; 0 = size from the models */
 	int grow;			 /* 1 (default): block / bin capacities grow by 3/2 once 3/4 full, like check_capacity()
 							(gmpm_simulator.cuh:283-300); 0: fixed capacities, MPM_ERR_CAPACITY when exceeded */
-	int reserved[5];
+	int drop_overflow;	 /* 0 (default): a block receiving more than max_ppc * 64 particles is MPM_ERR_CAPACITY; 1: the particles beyond the
+							capacity are dropped and counted (mpm_diagnostics.dropped_particles) - what the reference does, silently and
+							per cell (particle_buffer.cuh:122-130) */
+	int reserved[4];
 } mpm_config;
 
 /* Material parameter block (Projects/GMPM/particle_buffer.cuh:141-264).  Unused fields are ignored. */
@@ -193,8 +196,9 @@ int mpm_get_timers(mpm_ctx* ctx, mpm_timers* t);
 typedef struct mpm_diagnostics {
 	int64_t lost_particles;
 	int64_t discarded_p2g;
-	int overflow_flags; /* bit 0: block capacity, bit 1: particles per block (both also raise MPM_ERR_CAPACITY) */
-	int reserved[5];
+	int overflow_flags; /* bit 0: block capacity, bit 1: particles per block (MPM_ERR_CAPACITY, unless bit 1 with drop_overflow) */
+	int dropped_particles; /* cumulative; only with mpm_config.drop_overflow */
+	int reserved[4];
 } mpm_diagnostics;
 int mpm_get_diagnostics(mpm_ctx* ctx, mpm_diagnostics* d);
 /* Sum over the current grid of {mass, momentum x, y, z} (the reference's sum_grid_mass debug kernel,

@@ -337,6 +337,37 @@ def test_capacity_overflow_reports_error():
     eng.close()
 
 
+def test_runtime_overflow_error_or_drop():
+    """A block that receives more particles than it has list slots (max_ppc * 64): MPM_ERR_CAPACITY by default; with
+    mpm_config.drop_overflow the surplus is dropped and counted - what the reference does silently and per cell
+    (particle_buffer.cuh:122-130) - and the run goes on with a consistent particle count."""
+    def scene():
+        sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=0.5, speed=3.0, youngs=2e3)
+        sc["config"]["max_ppc"] = 8      # 512 per block: the lattice fills interior blocks exactly, any compression overflows
+        return sc
+    sc = scene()
+    n = scenes.total_particles(sc)
+    eng = build_engine(sc)
+    eng.initial_setup()
+    with pytest.raises(Exception):
+        eng.run_fixed(400, 1e-4)
+    eng.close()
+    sc = scene()
+    sc["config"]["drop_overflow"] = 1
+    eng = build_engine(sc)
+    eng.initial_setup()
+    eng.run_fixed(400, 1e-4)
+    c, d = eng.counts(), eng.diagnostics()
+    assert d.dropped_particles > 0 and (d.overflow_flags & 2)
+    assert c.particles[0] + c.particles[1] == n - d.dropped_particles
+    x = np.concatenate([eng.retrieve_positions(0), eng.retrieve_positions(1)])
+    assert x.shape[0] == n - d.dropped_particles and np.isfinite(x).all()
+    tot = eng.grid_totals()
+    mass = sum(eng.model_mass(i) * (c.particles[i]) for i in range(2))
+    assert abs(tot[0] - mass) / mass < 1e-4
+    eng.close()
+
+
 def test_block_capacity_grows_like_check_capacity():
     """gmpm_simulator.cuh:283-300: capacities grow by 3/2 once 3/4 full.  A run that starts with a block capacity just above
     its exterior block count grows at the first rebuild and must then follow the same trajectory as a generously sized run."""
