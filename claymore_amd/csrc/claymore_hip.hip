@@ -550,11 +550,17 @@ static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, in
 	const int r = ctx->rollid, n = r ^ 1;
 	ModelView v = make_view(ctx, m);
 	const int* cur_keys	  = ctx->part[r].keys;
+	const GridCfg& g = ctx->g;
+	StepConst sk;
+	sk.dts	= dt * (4.f * g.dx_inv);
+	sk.pred = next_dt * g.dx_inv;
+	sk.am	= m.mc.mass * g.dx * g.dx * g.d_inv;
+	sk.cs	= next_dt * g.d_inv * g.dx;
 	switch(m.material) {
-		case MPM_J_FLUID: g2p2g_kernel<0><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
-		case MPM_FIXED_COROTATED: g2p2g_kernel<1><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
-		case MPM_SAND: g2p2g_kernel<2><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
-		default: g2p2g_kernel<3><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, ctx->d_status); break;
+		case MPM_J_FLUID: g2p2g_kernel<0><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, sk, ctx->d_status); break;
+		case MPM_FIXED_COROTATED: g2p2g_kernel<1><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, sk, ctx->d_status); break;
+		case MPM_SAND: g2p2g_kernel<2><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, sk, ctx->d_status); break;
+		default: g2p2g_kernel<3><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, sk, ctx->d_status); break;
 	}
 }
 

@@ -291,6 +291,15 @@ struct ScatterChain {
 	}
 };
 
+// Uniform per-launch factors, formed on the host: gfx950 has no scalar float ALU, so a uniform product computed in the kernel lives in
+// a vector register for the whole particle loop.
+struct StepConst {
+	float dts; // dt * dx * D^-1 = dt * 4 / dx: A (cell units) -> dt grad v
+	float pred;// new_dt / dx
+	float am;  // mass dx^2 D^-1
+	float cs;  // new_dt D^-1 dx
+};
+
 // packed stencil base in the node cube (x | y << 4 | z << 8), -1 = outside (contribution discarded, :877-885)
 MPM_DEV int code_key(int c) {
 	return ((c >> 4) & 15) * 36 + (c & 15) * 6 + (c >> 8);
@@ -304,7 +313,7 @@ MPM_DEV int code_off(int c) {
 }
 
 template<int MAT>
-__global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : MPM_G2P2G_WAVES) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_keys, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, float dt, float new_dt, int* __restrict__ status) {
+__global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : MPM_G2P2G_WAVES) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_keys, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, float dt, float new_dt, StepConst sk, int* __restrict__ status) {
 	constexpr int NCH = MatTraits<MAT>::nch;
 	// 10.8 KB of LDS per wave: 15 single-wave workgroups per CU.
 	__shared__ float4 g2p[kG2PNodes];	   // node velocities {vx, vy, vz, vz} of cube nodes 1..6 per axis
@@ -331,7 +340,6 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 	if(size == 0) return;// (:692-697)
 	const int* list		= mv.list_in + (size_t) row * cfg.ppb;
 	const float dx_inv	= cfg.dx_inv;
-	const float scale	= 4.f * cfg.dx_inv;// dx * D^-1 (settings.h:66): A is accumulated in cell units
 	const float mass	= mv.mc.mass;
 	const int key_shift = cfg.pid_bits;
 	const int tag_shift = cfg.pid_bits + kKeyBits;
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		//      issued BEFORE the stress computation, which hides their round trip to L2.
 		int narena[3], dirv[3], pk[3];
 		in_arena = active;
-		const float pred = new_dt * dx_inv;
+		const float pred = sk.pred;
 #pragma unroll
 		for(int d = 0; d < 3; ++d) {
 			const float p	= pos[d] * dx_inv;
@@ -529,7 +537,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 			float dws[9], Fold[9], F[9];
 #pragma unroll
 			for(int d = 0; d < 9; ++d) {
-				dws[d]	= (A[d] * dt) * scale + ((d & 0x3) != 0 ? 0.f : 1.f);
+				dws[d]	= A[d] * sk.dts + ((d & 0x3) != 0 ? 0.f : 1.f);// I + dt grad v (A is accumulated in cell units: dx * D^-1 = 4 / dx, settings.h:66)
 				Fold[d] = st[d];
 			}
 			matmul3(dws, Fold, F);
@@ -593,8 +601,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		//      payload (chain, p2g_serial), so that it can be computed straight into the loop-carried registers (no copies).
 		//      (:850) contrib = (A m - stress new_dt) D^-1, pre-multiplied by dx so that P2G can stay in cell units
 		{
-			const float am = mass * cfg.dx * cfg.dx * cfg.d_inv;
-			const float cs = new_dt * cfg.d_inv * cfg.dx;
+			const float am = sk.am, cs = sk.cs;
 #pragma unroll
 			for(int d = 0; d < 3; ++d) {
 				pv.fd[d] = nfd[d];
@@ -619,17 +626,21 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 	//      eight grid blocks, like the staging above: every atomic instruction covers (27 cells of) ONE 256-B channel row.
 	//      (Walking the 216 arena nodes in arena order instead spreads each instruction over ~21 three-cell runs in up to
 	//      eight blocks: five times the L2 atomic requests.)
-	const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
+	int lane_wb = lane;
+	__asm__ volatile("" : "+v"(lane_wb));// (the cell coordinates and look-up lanes of the write-back are formed here: shared with the set-up's they would sit in ~15 registers through the particle loop)
+	const int cx = lane_wb >> 4, cy = (lane_wb >> 2) & 3, cz = lane_wb & 3;
 #pragma unroll
 	for(int lb = 0; lb < 8; ++lb) {
-		const int nb = __shfl(info, 54 + lb);
+		int sel = 54 + lb;
+		__asm__ volatile("" : "+s"(sel));
+		const int nb = __shfl(info, sel);
 		const int ax = cx + ((lb & 4) ? 4 : 0) - 1, ay = cy + ((lb & 2) ? 4 : 0) - 1, az = cz + ((lb & 1) ? 4 : 0) - 1;
 		const bool in = ((unsigned) ax < 6u) & ((unsigned) ay < 6u) & ((unsigned) az < 6u);
 		const int n	  = in ? ax * kP2GStrideX + ay * kP2GStrideY + az : 0;
 		const float4 va = p2g[n], vb = p2g[kP2GNodes + n];
 		const float4 v	= make_float4(va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w);
 		if(in && nb >= 0) {
-			float* g = next_grid + (size_t) nb * 256 + lane;
+			float* g = next_grid + (size_t) nb * 256 + lane_wb;
 			if(v.x != 0.f) unsafeAtomicAdd(g, v.x);
 			if(v.y != 0.f) unsafeAtomicAdd(g + 64, v.y);
 			if(v.z != 0.f) unsafeAtomicAdd(g + 128, v.z);
