@@ -337,6 +337,23 @@ def test_capacity_overflow_reports_error():
     eng.close()
 
 
+def test_fuzz_parity():
+    """Random small scenes (tests/fuzz_scenes.py: 1-3 bodies, J-fluid / fixed-corotated / sand, random sizes, positions - some next
+    to a wall -, velocities up to 3 m/s, 20-120 substeps): positions within 1e-5 relative of the oracle's, block counts equal.
+    (NACC, which the reference itself flags unstable, constitutive_models.cuh:80, has its own test; tools/fuzz_parity.py runs
+    the long / fast / all-material variant.)"""
+    from fuzz_scenes import random_scene
+    rng = np.random.default_rng(2024)
+    for case in range(12):
+        sc, nsteps = random_scene(rng, case, 3.0, 120, (_ffi.J_FLUID, _ffi.FIXED_COROTATED, _ffi.SAND))
+        res = run_pair(sc, nsteps)
+        co, ch = res["oracle"]["counts"], res["hip"]["counts"]
+        assert [co.particles[i] for i in range(len(sc["models"]))] == [m["xyz"].shape[0] for m in sc["models"]]
+        w = match_and_compare(res)
+        assert w["pos_rel"] < 1e-5, (case, w)
+        assert (ch.particle_blocks, ch.neighbor_blocks, ch.exterior_blocks) == (co.particle_blocks, co.neighbor_blocks, co.exterior_blocks), case
+
+
 def test_runtime_overflow_error_or_drop():
     """A block that receives more particles than it has list slots (max_ppc * 64): MPM_ERR_CAPACITY by default; with
     mpm_config.drop_overflow the surplus is dropped and counted - what the reference does silently and per cell
