@@ -403,6 +403,12 @@ MPM_DEV void jacobi_rot(float& spp, float& spq, float& sqq, float& srp, float& s
 	uq[2] = s * pz + c * qz;
 }
 
+#ifndef MPM_EIG_TOL
+#define MPM_EIG_TOL 1e-6f// sweeps stop once every off-diagonal entry of every lane is below this fraction of the smallest diagonal entry
+#endif
+#ifndef MPM_EIG_PRECHECK
+#define MPM_EIG_PRECHECK 1// A/B switch: 0 = always run the first sweep (round 2)
+#endif
 constexpr int kEigSites = 13;
 template<int BASE, class Hook>
 MPM_DEV void sym_eig3(const float (&F)[9], float (&lam)[3], float (&U)[9], Hook& hk) {
@@ -417,24 +423,36 @@ MPM_DEV void sym_eig3(const float (&F)[9], float (&lam)[3], float (&U)[9], Hook&
 	float u1[3] = {1.f, 0.f, 0.f}, u2[3] = {0.f, 1.f, 0.f}, u3[3] = {0.f, 0.f, 1.f};
 	MPM_MARK("eig_jacobi");
 	hk.template at<BASE + 0>();
-	bool done = false;
-#define MPM_SWEEP(IT)                                                          \
+	// The convergence test runs BEFORE every sweep (the first one included: a particle in free fall or rigid translation
+	// has b diagonal already, and a whole wave of them skips the rotations altogether), not after the last one.
+	bool done;
+#define MPM_CONVERGED()                                                                 \
+	{                                                                                   \
+		const float off = fmaxf(fmaxf(fabsf(s21), fabsf(s31)), fabsf(s32));             \
+		const float dia = fminf(fminf(fabsf(s11), fabsf(s22)), fabsf(s33));             \
+		done			= __all(off <= MPM_EIG_TOL * dia);                               \
+	}
+#define MPM_SWEEP(IT, LAST)                                                    \
 	if(!done) jacobi_rot(s11, s21, s22, s31, s32, u1, u2);                     \
 	hk.template at<BASE + 1 + 3 * IT>();                                       \
 	if(!done) jacobi_rot(s22, s32, s33, s21, s31, u2, u3);                     \
 	hk.template at<BASE + 2 + 3 * IT>();                                       \
 	if(!done) {                                                                \
 		jacobi_rot(s33, s31, s11, s32, s21, u3, u1);                           \
-		const float off = fmaxf(fabsf(s21), fabsf(s32));                       \
-		const float dia = fminf(fminf(fabsf(s11), fabsf(s22)), fabsf(s33));    \
-		done			= __all(off <= 1e-6f * dia);                           \
+		if(!(LAST)) MPM_CONVERGED()                                            \
 	}                                                                          \
 	hk.template at<BASE + 3 + 3 * IT>();
-	MPM_SWEEP(0)
-	MPM_SWEEP(1)
-	MPM_SWEEP(2)
-	MPM_SWEEP(3)
+#if MPM_EIG_PRECHECK
+	MPM_CONVERGED()
+#else
+	done = false;
+#endif
+	MPM_SWEEP(0, false)
+	MPM_SWEEP(1, false)
+	MPM_SWEEP(2, false)
+	MPM_SWEEP(3, true)
 #undef MPM_SWEEP
+#undef MPM_CONVERGED
 	MPM_MARK("eig_end");
 	lam[0] = s11;
 	lam[1] = s22;
@@ -614,7 +632,8 @@ MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, 
 	// rebuilds U S V^T there too, which only adds its rounding.  Reflected or collapsed F (rare) goes through V, as the
 	// reference's does, whether the strain changed or not (the rebuild removes the reflection).
 	const bool odd	   = !dead && (ill || !(det3(F) > 0.f));
-	const bool changed = !dead && !odd && (tip || r > 0.f);
+	// (dl == 0 exactly: inside the cone, or at the tip with zero strain - free fall; exp(0) = 1 would only add the rounding of U U^T)
+	const bool changed = !dead && !odd && ((dl[0] != 0.f) | (dl[1] != 0.f) | (dl[2] != 0.f));
 	if(__any(changed)) {
 		if(changed) {
 			float ratio[3];

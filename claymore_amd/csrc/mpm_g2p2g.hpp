@@ -156,28 +156,37 @@ MPM_DEV void gather_apic(const float4* __restrict__ gbase, const float (&w)[3][3
 
 // P2G of the particles the chain cannot take - lanes that lost the claim of their stencil base (another lane of the
 // iteration holds the same base) and edge lanes, whose stencil reaches cube nodes 0 or 7 (cells of the 2x2x2 grid blocks
-// outside the LDS arena; the particle has just crossed into a neighbouring block).  They are served ONE PARTICLE AT A TIME
-// with the 27 stencil nodes spread over 27 lanes: the particle's payload is broadcast (v_readlane), lane o computes the
-// contribution to node o and adds it - a plain read-modify-write for arena nodes (the 27 nodes of one particle are
-// distinct, and a single wave's LDS operations execute in order), a global float atomic per channel for shell nodes.
-// One LDS round trip per particle whatever the multiplicity of its base, no claim rounds, no second 27-step pass.
+// outside the LDS arena; the particle has just crossed into a neighbouring block).  They are served TWO PARTICLES AT A TIME,
+// each with its 27 stencil nodes spread over 27 lanes of one half of the wave (lanes 0..26 and 32..58): the payloads are
+// broadcast with ds_bpermute (the LDS crossbar, no VALU: one instruction serves both halves, where v_readlane would take
+// 2 x 17 plus the selects), lane o of a half computes the contribution to node o and adds it - a plain read-modify-write
+// for arena nodes (the 27 nodes of one particle are distinct, the two halves use separate arenas, and a single wave's LDS
+// operations execute in order), a global float atomic per channel for shell nodes.
+// One LDS round trip per PAIR whatever the multiplicity of the bases, no claim rounds, no second 27-step pass.
 MPM_DEV void p2g_serial(float4* __restrict__ arena, bool pending, int code, const P2GPayload& pl, float mass, int lane, int info, float* __restrict__ next_grid) {
 	__asm__ volatile("" : "+v"(lane));// (recomputed here every time: hoisted out of the main loop these would hold six registers)
-	const int oi = lane / 9, oj = (lane / 3) % 3, ok = lane % 3;// this lane's stencil offset (lanes 0..26)
+	const int l	   = lane & 31;
+	const int half = lane >> 5;
+	const int oi = l / 9, oj = (l / 3) % 3, ok = l % 3;// this lane's stencil offset (lanes 0..26 of each half)
 	const float fi = (float) oi, fj = (float) oj, fk = (float) ok;
+	float4* const my_arena = arena + half * kP2GNodes;
 	unsigned long long todo = __ballot(pending);
 	while(todo) {
-		const int src = __ffsll((long long) todo) - 1;
+		const int src_a = __ffsll((long long) todo) - 1;
 		todo &= todo - 1;
+		const bool two	= todo != 0ull;
+		const int src_b = two ? __ffsll((long long) todo) - 1 : src_a;
+		todo &= todo - 1;// (no-op on zero)
+		const int src = half ? src_b : src_a;
 		float fd[3], mvv[3], c[9];
 #pragma unroll
 		for(int d = 0; d < 3; ++d) {
-			fd[d]  = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pl.fd[d]), src));
-			mvv[d] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pl.mv[d]), src));
+			fd[d]  = __shfl(pl.fd[d], src);
+			mvv[d] = __shfl(pl.mv[d], src);
 		}
 #pragma unroll
-		for(int d = 0; d < 9; ++d) c[d] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pl.contrib[d]), src));
-		const int cd = __builtin_amdgcn_readlane(code, src);
+		for(int d = 0; d < 9; ++d) c[d] = __shfl(pl.contrib[d], src);
+		const int cd = __shfl(code, src);
 		const int nx = cd & 15, ny = (cd >> 4) & 15, nz = cd >> 8;
 		float w[3][3];
 #pragma unroll
@@ -194,9 +203,9 @@ MPM_DEV void p2g_serial(float4* __restrict__ arena, bool pending, int code, cons
 		const int gx = nx + oi, gy = ny + oj, gz = nz + ok;// cube coordinates 0..7
 		const bool inside = ((unsigned) (gx - 1) < 6u) & ((unsigned) (gy - 1) < 6u) & ((unsigned) (gz - 1) < 6u);
 		const int nb	  = __shfl(info, 54 + ((gx >> 2) & 1) * 4 + ((gy >> 2) & 1) * 2 + ((gz >> 2) & 1));// grid block of the node (all lanes active here)
-		if(lane < 27) {
+		if(l < 27 && (half == 0 || two)) {
 			if(inside) {
-				float4* node	 = arena + (gx - 1) * kP2GStrideX + (gy - 1) * kP2GStrideY + (gz - 1);
+				float4* node	 = my_arena + (gx - 1) * kP2GStrideX + (gy - 1) * kP2GStrideY + (gz - 1);
 				const float4 acc = *node;
 				*node			 = make_float4(acc.x + v0, acc.y + v1, acc.z + v2, acc.w + v3);
 			} else {
@@ -209,7 +218,7 @@ MPM_DEV void p2g_serial(float4* __restrict__ arena, bool pending, int code, cons
 				}
 			}
 		}
-		__asm__ volatile("" ::: "memory");// the next particle may hit the same nodes: keep the LDS operations in program order
+		__asm__ volatile("" ::: "memory");// the next pair may hit the same nodes: keep the LDS operations in program order
 	}
 }
 
