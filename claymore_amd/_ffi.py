@@ -15,7 +15,7 @@ MATERIAL_NAMES = {"jfluid": J_FLUID, "fixed_corotated": FIXED_COROTATED, "sand":
 class Config(C.Structure):
     _fields_ = [("domain_bits", C.c_int), ("max_ppc", C.c_int), ("boundary_blocks", C.c_int),
                 ("gravity", C.c_float), ("cfl", C.c_float), ("max_blocks", C.c_int64),
-                ("grow", C.c_int), ("drop_overflow", C.c_int), ("reserved", C.c_int * 4)]
+                ("grow", C.c_int), ("drop_overflow", C.c_int), ("sync_interval", C.c_int), ("reserved", C.c_int * 3)]
 
 
 class MaterialParams(C.Structure):

@@ -60,10 +60,15 @@ struct mpm_ctx {
 	bool grid_preupdated = false;
 	float preupdate_dt	 = 0.f;
 	float fuse_dt_once	 = 0.f;// set by a driver that knows the next substep's dt (mpm_group_run_fixed): consumed by the next rebuild
+	// Between two host synchronisations of mpm_run_fixed the block counts below are ESTIMATES (the values of the last
+	// synchronisation): launches are sized by them with a margin, every kernel reads the true counts from the status block.
+	bool rebuild_cleared = false;// the rebuild's part of substep_clear_kernel has been issued together with the P2G part
+	std::vector<hipEvent_t> ev_ring;// 4 events per substep of a window (substep start, G2P2G start / end, substep end)
 	Partition part[2];
 	float* grid[2] = {nullptr, nullptr};
 	int rollid	   = 0;
 	int pbc = 0, nbc = 0, ebc = 0;
+	int pbc_prev = 0;// particle blocks of the previous numbering (the one the particle data is laid out in)
 	std::vector<Model> models;
 	int* d_status		  = nullptr;// ST_WORDS ints
 	int* h_status		  = nullptr;// pinned
@@ -110,7 +115,7 @@ static float host_maxvel(const mpm_ctx* ctx) {
 	return m;
 }
 
-static int launch_prepare(mpm_ctx* ctx, int cur, int prev, bool list_is_out, int binoff_sel, const int* pbc_ptr, int nblocks_max, bool sort);
+static int launch_prepare(mpm_ctx* ctx, int cur, int prev, bool list_is_out, int binoff_sel, const int* pbc_ptr, int nblocks_est, bool sort, bool publish);
 
 static int fail(mpm_ctx* ctx, int code, const std::string& msg) {
 	ctx->err = msg;
@@ -311,6 +316,7 @@ void mpm_destroy(mpm_ctx* ctx) {
 	if(ctx->ev_g1) hipEventDestroy(ctx->ev_g1);
 	if(ctx->ev_comm) hipEventDestroy(ctx->ev_comm);
 	if(ctx->ev_halo) hipEventDestroy(ctx->ev_halo);
+	for(hipEvent_t e: ctx->ev_ring) hipEventDestroy(e);
 	if(ctx->h_halo_counts) hipHostFree(ctx->h_halo_counts);
 	if(ctx->s_compute) hipStreamDestroy(ctx->s_compute);
 	if(ctx->s_comm) hipStreamDestroy(ctx->s_comm);
@@ -356,6 +362,7 @@ static int check_status(mpm_ctx* ctx) {
 	const int* st = ctx->h_status;
 	if(st[ST_OVERFLOW] & 1) return fail(ctx, MPM_ERR_CAPACITY, "Too much active blocks: block capacity " + std::to_string(ctx->g.cap) + " exceeded");
 	if((st[ST_OVERFLOW] & 2) && !ctx->cfg.drop_overflow) return fail(ctx, MPM_ERR_CAPACITY, "particles-per-block capacity exceeded (max_ppc*64 = " + std::to_string(ctx->g.ppb) + ")");
+	if(st[ST_OVERFLOW] & 4) return fail(ctx, MPM_ERR_CAPACITY, "bin capacity exceeded");
 	return MPM_OK;
 }
 
@@ -409,16 +416,22 @@ int mpm_initial_setup(mpm_ctx* ctx) {
 		prov   = need;
 		g.cap  = (int) prov;
 	}
-	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_PBC], P.count, sizeof(int), hipMemcpyDeviceToDevice, s));
-	register_blocks_kernel<0, 1><<<std::max(1u, std::min(4096u, cdiv((size_t) pbc * 8, 256))), 256, 0, s>>>(g, &ctx->d_status[ST_PBC], P.table, P.keys, P.count, ctx->d_status);
-	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_NBC], P.count, sizeof(int), hipMemcpyDeviceToDevice, s));
-	register_blocks_kernel<-1, 1><<<std::max(1u, std::min(8192u, cdiv((size_t) pbc * 32, 256))), 256, 0, s>>>(g, &ctx->d_status[ST_PBC], P.table, P.keys, P.count, ctx->d_status);
-	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_EBC], P.count, sizeof(int), hipMemcpyDeviceToDevice, s));
+	// (one-time set-up: the phase counters start from the activation's count; the published counts are formed on the host below)
+	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_CNT_P], P.count, sizeof(int), hipMemcpyDeviceToDevice, s));
+	register_blocks_kernel<0, 1><<<std::max(1u, std::min(4096u, cdiv((size_t) pbc * 8, 256))), 256, 0, s>>>(g, &ctx->d_status[ST_CNT_P], nullptr, &ctx->d_status[ST_CNT_N], &ctx->d_status[ST_PBC], P.table, P.keys, ctx->d_status);
+	register_blocks_kernel<-1, 1><<<std::max(1u, std::min(8192u, cdiv((size_t) pbc * 32, 256))), 256, 0, s>>>(g, &ctx->d_status[ST_CNT_P], &ctx->d_status[ST_CNT_N], &ctx->d_status[ST_CNT_E], &ctx->d_status[ST_NBC], P.table, P.keys, ctx->d_status);
 	{
 		int rc0 = read_status(ctx);
 		if(rc0) return rc0;
 		rc0 = check_status(ctx);
 		if(rc0) return rc0;
+		const int ebc0 = ctx->h_status[ST_CNT_P] + ctx->h_status[ST_CNT_N] + ctx->h_status[ST_CNT_E];
+		ctx->h_status[ST_EBC] = ebc0;
+		ctx->pbc_prev		  = pbc;
+		HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_EBC], &ctx->h_status[ST_EBC], sizeof(int), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_PBCPREV], &ctx->pbc_prev, sizeof(int), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(P.count, &ctx->h_status[ST_EBC], sizeof(int), hipMemcpyHostToDevice, s));
+		HIP_TRY(hipStreamSynchronize(s));
 	}
 	ctx->nbc = ctx->h_status[ST_NBC];
 	ctx->ebc = ctx->h_status[ST_EBC];
@@ -465,6 +478,9 @@ int mpm_initial_setup(mpm_ctx* ctx) {
 	if(rc) return rc;
 	rc = check_status(ctx);
 	if(rc) return rc;
+	// a block that STARTS with more particles than it has list slots is a configuration error whatever the overflow policy (the drop
+	// policy covers particles that arrive at run time: a dropped particle must not have been rasterised)
+	if(ctx->h_status[ST_OVERFLOW] & 2) return fail(ctx, MPM_ERR_CAPACITY, "a block holds more than max_ppc*64 = " + std::to_string(g.ppb) + " particles at set-up");
 	if(ctx->h_status[ST_LOST]) return fail(ctx, MPM_ERR_INVALID, "particles outside the domain at setup");
 	for(size_t mi = 0; mi < ctx->models.size(); ++mi) {
 		ctx->models[mi].bincount = ctx->h_status[ST_BINS0 + mi];
@@ -481,7 +497,7 @@ int mpm_initial_setup(mpm_ctx* ctx) {
 	for(auto& m: ctx->models)
 		if(m.n) rasterize_kernel<<<cdiv(m.n, 256), 256, 0, s>>>(g, m.n, m.d_xyz, ctx->part[r].table, ctx->grid[0], m.mc.mass, m.v0[0], m.v0[1], m.v0[2]);
 	// the first G2P2G: current == previous numbering (roll r), lists as filled above
-	rc = launch_prepare(ctx, r, n, false, r, &ctx->d_status[ST_PBC], ctx->pbc, true);
+	rc = launch_prepare(ctx, r, n, false, r, &ctx->d_status[ST_PBC], ctx->pbc, true, false);
 	if(rc) return rc;
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(s));
@@ -499,10 +515,11 @@ static int launch_grid_update(mpm_ctx* ctx, float dt) {
 	}
 	HIP_TRY(hipMemsetAsync(ctx->d_maxvel, 0, sizeof(unsigned) * kMaxVelSlots * kMaxVelStride, s));
 	if(ctx->nbc) {
+		const int est = std::min(ctx->g.cap, ctx->nbc + ctx->nbc / 16 + 64);// (an estimate between two synchronisations of mpm_run_fixed)
 		if(ctx->has_collision)
-			grid_update_collision_kernel<<<cdiv(ctx->nbc, 4), 256, 0, s>>>(ctx->g, ctx->nbc, ctx->grid[0], ctx->part[ctx->rollid].keys, dt, ctx->collision, ctx->d_maxvel);
+			grid_update_collision_kernel<<<cdiv(est, 4), 256, 0, s>>>(ctx->g, &ctx->d_status[ST_NBC], ctx->grid[0], ctx->part[ctx->rollid].keys, dt, ctx->collision, ctx->d_maxvel);
 		else
-			grid_update_kernel<<<cdiv(ctx->nbc, 16), 256, 0, s>>>(ctx->g, ctx->nbc, ctx->grid[0], ctx->part[ctx->rollid].keys, dt, ctx->d_maxvel);
+			grid_update_kernel<<<cdiv(est, 16), 256, 0, s>>>(ctx->g, &ctx->d_status[ST_NBC], ctx->grid[0], ctx->part[ctx->rollid].keys, dt, ctx->d_maxvel);
 	}
 	return MPM_OK;
 }
@@ -546,8 +563,16 @@ static ModelView make_view(mpm_ctx* ctx, Model& m) {
 	return v;
 }
 
-static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, int nblocks, float dt, float next_dt, hipStream_t s) {
-	const int r = ctx->rollid, n = r ^ 1;
+// a launch size for `n` (an estimate that may be a few substeps old) particle blocks: margin for growth, a multiple of 8 (XCDs)
+static inline int hint_blocks(const mpm_ctx* ctx, int n) {
+	const long long h = (long long) n + n / 16 + 64;
+	return (int) ((std::min<long long>(h, std::max(ctx->g.cap, 8)) + 7) & ~7ll);
+}
+
+// nblocks_ptr != nullptr: the block count is read from device memory, `nblocks` is the host's estimate of it (launch size);
+// otherwise `nblocks` is exact (the halo / interior lists of the MGSP path, whose lengths the host has read back)
+static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, const int* nblocks_ptr, int nblocks, float dt, float next_dt, hipStream_t s) {
+	const int r = ctx->rollid;
 	ModelView v = make_view(ctx, m);
 	const int* cur_keys	  = ctx->part[r].keys;
 	const GridCfg& g = ctx->g;
@@ -556,37 +581,62 @@ static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, in
 	sk.pred = next_dt * g.dx_inv;
 	sk.am	= m.mc.mass * g.dx * g.dx * g.d_inv;
 	sk.cs	= next_dt * g.d_inv * g.dx;
+#ifdef MPM_G2P2G_NOLOOP
+	const int nwg = nblocks;
+#else
+	const int nwg = nblocks_ptr ? hint_blocks(ctx, nblocks) : nblocks;
+#endif
 	switch(m.material) {
-		case MPM_J_FLUID: g2p2g_kernel<0><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, sk, ctx->d_status); break;
-		case MPM_FIXED_COROTATED: g2p2g_kernel<1><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, sk, ctx->d_status); break;
-		case MPM_SAND: g2p2g_kernel<2><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, sk, ctx->d_status); break;
-		default: g2p2g_kernel<3><<<nblocks, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, dt, next_dt, sk, ctx->d_status); break;
+		case MPM_J_FLUID: g2p2g_kernel<0><<<nwg, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, nblocks_ptr, nblocks, dt, next_dt, sk, ctx->d_status); break;
+		case MPM_FIXED_COROTATED: g2p2g_kernel<1><<<nwg, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, nblocks_ptr, nblocks, dt, next_dt, sk, ctx->d_status); break;
+		case MPM_SAND: g2p2g_kernel<2><<<nwg, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, nblocks_ptr, nblocks, dt, next_dt, sk, ctx->d_status); break;
+		default: g2p2g_kernel<3><<<nwg, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, nblocks_ptr, nblocks, dt, next_dt, sk, ctx->d_status); break;
 	}
 }
 
-// clears that precede g2p2g (gmpm_simulator.cuh:383,:389)
-static int launch_g2p2g_prologue(mpm_ctx* ctx) {
-	hipStream_t s = ctx->s_compute;
-	HIP_TRY(hipMemsetAsync(ctx->grid[1], 0, sizeof(float) * 256 * (size_t) ctx->nbc, s));
-	for(auto& m: ctx->models) HIP_TRY(hipMemsetAsync(m.out_count, 0, sizeof(int) * ((size_t) ctx->ebc + 1), s));
+// substep_clear_kernel: the P2G part precedes G2P2G (clear_grid + the bucket counters, gmpm_simulator.cuh:383,:389), the rebuild
+// part precedes the rebuild (reset_table + the counters, :436-446); with_rebuild issues both in one launch
+static int launch_clear(mpm_ctx* ctx, int flags) {
+	if(flags & kClearRebuild) {
+		if(ctx->rebuild_cleared) flags &= ~kClearRebuild;// (already issued with this substep's P2G part)
+		ctx->rebuild_cleared = false;
+	}
+	if(!flags) return MPM_OK;
+	ClearArgs a {};
+	a.flags	  = flags;
+	a.nmodels = (int) ctx->models.size();
+	for(int mi = 0; mi < a.nmodels; ++mi) a.out_count[mi] = ctx->models[mi].out_count;
+	a.p2g_grid	   = ctx->grid[1];
+	a.status	   = ctx->d_status;
+	a.max_vel_bits = ctx->d_maxvel;
+	Partition& Pn  = ctx->part[ctx->rollid ^ 1];
+	a.old_table	   = Pn.table;
+	a.old_keys	   = Pn.keys;
+	a.old_count	   = Pn.count;
+	substep_clear_kernel<<<1024, 256, 0, ctx->s_compute>>>(ctx->g, a);
 	return MPM_OK;
 }
+static int launch_g2p2g_prologue(mpm_ctx* ctx, bool with_rebuild = false) {
+	int rc = launch_clear(ctx, with_rebuild ? (kClearP2G | kClearRebuild) : kClearP2G);
+	if(rc == MPM_OK && with_rebuild) ctx->rebuild_cleared = true;
+	return rc;
+}
 
-static int launch_g2p2g(mpm_ctx* ctx, float dt, float next_dt) {
+static int launch_g2p2g(mpm_ctx* ctx, float dt, float next_dt, hipEvent_t e0, hipEvent_t e1, bool with_rebuild_clear = false) {
 	hipStream_t s = ctx->s_compute;
-	int rc		  = launch_g2p2g_prologue(ctx);
+	int rc		  = launch_g2p2g_prologue(ctx, with_rebuild_clear);
 	if(rc) return rc;
-	HIP_TRY(hipEventRecord(ctx->ev_g0, s));
+	HIP_TRY(hipEventRecord(e0, s));
 	if(ctx->pbc)
-		for(auto& m: ctx->models) launch_g2p2g_model(ctx, m, nullptr, ctx->pbc, dt, next_dt, s);
-	HIP_TRY(hipEventRecord(ctx->ev_g1, s));
+		for(auto& m: ctx->models) launch_g2p2g_model(ctx, m, nullptr, &ctx->d_status[ST_PBC], ctx->pbc, dt, next_dt, s);
+	HIP_TRY(hipEventRecord(e1, s));
 	return MPM_OK;
 }
 
 int mpm_g2p2g(mpm_ctx* ctx, float dt, float next_dt) {
 	if(!ctx || !ctx->ready) return MPM_ERR_NOT_READY;
 	HIP_TRY(hipSetDevice(ctx->device));
-	int rc = launch_g2p2g(ctx, dt, next_dt);
+	int rc = launch_g2p2g(ctx, dt, next_dt, ctx->ev_g0, ctx->ev_g1);
 	if(rc) return rc;
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(ctx->s_compute));
@@ -597,9 +647,11 @@ int mpm_g2p2g(mpm_ctx* ctx, float dt, float next_dt) {
 
 // Per-block preparation of the next G2P2G (prepare_blocks_kernel): `cur` is the numbering that G2P2G will run in, `prev`
 // the numbering the particle data is laid out in; `list_sel` / `binoff_sel` select the list and bin-offset buffers that
-// G2P2G will read (they differ before and after the roll).  nblocks_max bounds the particle block count (*pbc_ptr).
-static int launch_prepare(mpm_ctx* ctx, int cur, int prev, bool list_is_out, int binoff_sel, const int* pbc_ptr, int nblocks_max, bool sort) {
-	if(nblocks_max <= 0) return MPM_OK;
+// G2P2G will read (they differ before and after the roll).  nblocks_est: the host's estimate of the particle block count
+// *pbc_ptr (the launch size; the kernel walks over what is beyond it).  publish: the rebuild's last kernel publishes the
+// exterior block count.
+static int launch_prepare(mpm_ctx* ctx, int cur, int prev, bool list_is_out, int binoff_sel, const int* pbc_ptr, int nblocks_est, bool sort, bool publish) {
+	if(nblocks_est <= 0 && !publish) return MPM_OK;
 	PrepareModels pm {};
 	pm.n = (int) ctx->models.size();
 	for(int mi = 0; mi < pm.n; ++mi) {
@@ -610,14 +662,17 @@ static int launch_prepare(mpm_ctx* ctx, int cur, int prev, bool list_is_out, int
 		pm.binoff_src[mi] = m.binoff[binoff_sel];
 		pm.blockinfo[mi]  = m.blockinfo;
 	}
+	const int nwg = std::max(1, std::min(ctx->g.cap, nblocks_est + nblocks_est / 16 + 64));
+	int* pub	  = publish ? ctx->d_status : nullptr;
 	if(sort)
-		prepare_blocks_kernel<true><<<nblocks_max, 64, 0, ctx->s_compute>>>(ctx->g, pm, pbc_ptr, ctx->part[cur].table, ctx->part[cur].keys, ctx->part[prev].table);
+		prepare_blocks_kernel<true><<<nwg, 64, 0, ctx->s_compute>>>(ctx->g, pm, pbc_ptr, ctx->part[cur].table, ctx->part[cur].keys, ctx->part[prev].table, pub, ctx->part[cur].count);
 	else
-		prepare_blocks_kernel<false><<<nblocks_max, 64, 0, ctx->s_compute>>>(ctx->g, pm, pbc_ptr, ctx->part[cur].table, ctx->part[cur].keys, ctx->part[prev].table);
+		prepare_blocks_kernel<false><<<nwg, 64, 0, ctx->s_compute>>>(ctx->g, pm, pbc_ptr, ctx->part[cur].table, ctx->part[cur].keys, ctx->part[prev].table, pub, ctx->part[cur].count);
 	return MPM_OK;
 }
 
-// partition rebuild, gmpm_simulator.cuh:415-579 (launches only; no host round trip inside)
+// partition rebuild, gmpm_simulator.cuh:415-579 (launches only: no host round trip, no runtime fill / copy commands; launch sizes
+// from the host's estimates of the block counts, true counts from the status block)
 // fuse_dt > 0: the carry-over applies the grid update of the next substep (dt = fuse_dt) as well
 static int launch_rebuild(mpm_ctx* ctx, float fuse_dt = 0.f) {
 	if(fuse_dt == 0.f) fuse_dt = ctx->fuse_dt_once;
@@ -627,10 +682,8 @@ static int launch_rebuild(mpm_ctx* ctx, float fuse_dt = 0.f) {
 	const int r = ctx->rollid, n = r ^ 1;
 	Partition& Pn = ctx->part[n];
 	Partition& Pr = ctx->part[r];
-	const size_t table = (size_t) g.G * g.G * g.G;
-	HIP_TRY(hipMemsetAsync(Pn.table, 0xff, sizeof(int) * table, s));// reset_table, hash_table.cuh:110-112
-	HIP_TRY(hipMemsetAsync(Pn.count, 0, sizeof(int), s));
-	HIP_TRY(hipMemsetAsync(&ctx->d_status[ST_BINS0], 0, sizeof(int) * 2 * kMaxModels, s));// bin totals + particle totals
+	int rc		  = launch_clear(ctx, kClearRebuild);// un-insert the old keys of Pn (reset_table, hash_table.cuh:110-112), counters, totals
+	if(rc) return rc;
 	RebuildModels rm {};
 	rm.n = (int) ctx->models.size();
 	for(int mi = 0; mi < rm.n; ++mi) {
@@ -639,28 +692,27 @@ static int launch_rebuild(mpm_ctx* ctx, float fuse_dt = 0.f) {
 		rm.size[mi]		 = m.size;
 		rm.row_of[mi]	 = m.row_of;
 		rm.binoff[mi]	 = m.binoff[r];// becomes the destination offsets after the roll
+		rm.bin_cap[mi]	 = (long long) m.bin_cap;
 	}
-	if(ctx->ebc) compact_blocks_kernel<<<cdiv(ctx->ebc, 1024), 1024, 0, s>>>(g, ctx->ebc, rm, Pr.keys, Pn.keys, Pn.table, Pn.count, ctx->d_status);
-	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_PBC], Pn.count, sizeof(int), hipMemcpyDeviceToDevice, s));
-	const unsigned rg8 = std::max(1u, std::min(4096u, cdiv((size_t) ctx->ebc * 8, 256))), rg32 = std::max(1u, std::min(8192u, cdiv((size_t) ctx->ebc * 32, 256)));
-	register_blocks_kernel<0, 1><<<rg8, 256, 0, s>>>(g, &ctx->d_status[ST_PBC], Pn.table, Pn.keys, Pn.count, ctx->d_status);
-	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_NBC], Pn.count, sizeof(int), hipMemcpyDeviceToDevice, s));
+	int* st			  = ctx->d_status;
+	const int ebc_est = std::min(g.cap, ctx->ebc + ctx->ebc / 16 + 1024);
+	compact_blocks_kernel<<<std::max(1u, cdiv(ebc_est, 1024)), 1024, 0, s>>>(g, rm, Pr.keys, Pn.keys, Pn.table, st);
+	const unsigned rg8 = std::max(1u, std::min(4096u, cdiv((size_t) ebc_est * 8, 256))), rg32 = std::max(1u, std::min(8192u, cdiv((size_t) ebc_est * 32, 256)));
+	register_blocks_kernel<0, 1><<<rg8, 256, 0, s>>>(g, &st[ST_CNT_P], nullptr, &st[ST_CNT_N], &st[ST_PBC], Pn.table, Pn.keys, st);
 	if(fuse_dt > 0.f && !ctx->has_collision) {
-		HIP_TRY(hipMemsetAsync(ctx->d_maxvel, 0, sizeof(unsigned) * kMaxVelSlots * kMaxVelStride, s));
-		carry_grid_kernel<true><<<2048, 256, 0, s>>>(g, &ctx->d_status[ST_NBC], Pn.keys, Pr.table, ctx->nbc, ctx->grid[1], ctx->grid[0], fuse_dt, ctx->d_maxvel);
+		carry_grid_kernel<true><<<2048, 256, 0, s>>>(g, st, Pn.keys, Pr.table, ctx->grid[1], ctx->grid[0], fuse_dt, ctx->d_maxvel);
 		ctx->grid_preupdated = true;
 		ctx->preupdate_dt	 = fuse_dt;
 	} else
-		carry_grid_kernel<false><<<2048, 256, 0, s>>>(g, &ctx->d_status[ST_NBC], Pn.keys, Pr.table, ctx->nbc, ctx->grid[1], ctx->grid[0], 0.f, nullptr);
-	register_blocks_kernel<-1, 1><<<rg32, 256, 0, s>>>(g, &ctx->d_status[ST_PBC], Pn.table, Pn.keys, Pn.count, ctx->d_status);
-	HIP_TRY(hipMemcpyAsync(&ctx->d_status[ST_EBC], Pn.count, sizeof(int), hipMemcpyDeviceToDevice, s));
+		carry_grid_kernel<false><<<2048, 256, 0, s>>>(g, st, Pn.keys, Pr.table, ctx->grid[1], ctx->grid[0], 0.f, nullptr);
+	register_blocks_kernel<-1, 1><<<rg32, 256, 0, s>>>(g, &st[ST_CNT_P], &st[ST_CNT_N], &st[ST_CNT_E], &st[ST_NBC], Pn.table, Pn.keys, st);
 	// the next G2P2G runs in the new numbering n with the particle data laid out in r: sort its lists (the ones the last
-	// G2P2G appended to), look up its blocks' neighbours.  The old exterior count bounds the new particle block count.
-	return launch_prepare(ctx, n, r, true, n, &ctx->d_status[ST_PBC], ctx->ebc, true);
+	// G2P2G appended to), look up its blocks' neighbours; this last kernel also publishes the exterior block count
+	return launch_prepare(ctx, n, r, true, n, &st[ST_CNT_P], ebc_est, true, true);
 }
 
 // check_capacity() (gmpm_simulator.cuh:283-300): once the exterior block count / a model's bin count passes 3/4 of its
-// capacity the capacity grows by 3/2.  Runs at the one host synchronisation of a substep, after the rebuild; every
+// capacity the capacity grows by 3/2.  Runs at a host synchronisation, after a rebuild; every
 // array indexed by block number (keys, grids, lists, sizes, bin offsets, halo lists) or by bin is reallocated and
 // copied.  The dense table is sized by the domain, not by the capacity.
 static int grow_capacity(mpm_ctx* ctx) {
@@ -709,7 +761,15 @@ static int grow_capacity(mpm_ctx* ctx) {
 	return MPM_OK;
 }
 
-static int finish_rebuild(mpm_ctx* ctx, mpm_counts* counts) {
+// the host's half of a rebuild that needs no device data: the roll (gmpm_simulator.cuh:578)
+static void roll_partition(mpm_ctx* ctx) {
+	for(auto& m: ctx->models) m.list_in ^= 1;
+	ctx->rollid ^= 1;
+}
+
+// Host synchronisation after one or more enqueued substeps (every one already rolled on the host): read the status block,
+// report what went wrong in the meantime (flags are sticky), take over the counts, grow capacities.
+static int sync_counts(mpm_ctx* ctx, mpm_counts* counts) {
 	int rc = read_status(ctx);
 	if(rc) return rc;
 	rc = check_status(ctx);
@@ -717,20 +777,24 @@ static int finish_rebuild(mpm_ctx* ctx, mpm_counts* counts) {
 	ctx->pbc = ctx->h_status[ST_PBC];
 	ctx->nbc = ctx->h_status[ST_NBC];
 	ctx->ebc = ctx->h_status[ST_EBC];
+	ctx->pbc_prev = ctx->h_status[ST_PBCPREV];
 	if(ctx->ebc > ctx->g.cap) return fail(ctx, MPM_ERR_CAPACITY, "Too much exterior blocks: " + std::to_string(ctx->ebc));
 	for(size_t mi = 0; mi < ctx->models.size(); ++mi) {
-		Model& m   = ctx->models[mi];
-		m.bincount_src = m.bincount;
-		m.bincount = ctx->h_status[ST_BINS0 + mi];
-		m.bucketed = ctx->h_status[ST_PART0 + mi];
+		Model& m	   = ctx->models[mi];
+		m.bincount_src = ctx->h_status[ST_BINSPREV + mi];
+		m.bincount	   = ctx->h_status[ST_BINS0 + mi];
+		m.bucketed	   = ctx->h_status[ST_PART0 + mi];
 		if((size_t) m.bincount > m.bin_cap) return fail(ctx, MPM_ERR_CAPACITY, "bin capacity exceeded");
-		m.list_in ^= 1;
 	}
-	ctx->rollid ^= 1;// gmpm_simulator.cuh:578
+	if(ctx->h_status[ST_NONFINITE]) return fail(ctx, MPM_ERR_NONFINITE, "Maximum velocity is infinity");// gmpm_simulator.cuh:355-358
 	rc = grow_capacity(ctx);
 	if(rc) return rc;
 	if(counts) return mpm_get_counts(ctx, counts);
 	return MPM_OK;
+}
+static int finish_rebuild(mpm_ctx* ctx, mpm_counts* counts) {
+	roll_partition(ctx);
+	return sync_counts(ctx, counts);
 }
 
 int mpm_rebuild_partition(mpm_ctx* ctx, mpm_counts* counts) {
@@ -757,7 +821,7 @@ int mpm_substep(mpm_ctx* ctx, float dt, float step_time, float frame_time, float
 	const float nd = mpm_compute_dt(ctx, mv, step_time, frame_time, dt_default);
 	if(max_vel) *max_vel = mv;
 	if(next_dt) *next_dt = nd;
-	rc = launch_g2p2g(ctx, dt, nd);
+	rc = launch_g2p2g(ctx, dt, nd, ctx->ev_g0, ctx->ev_g1, true);
 	if(rc) return rc;
 	hipStream_t s = ctx->s_compute;
 	HIP_TRY(hipEventRecord(ctx->ev_a, s));
@@ -774,35 +838,69 @@ int mpm_substep(mpm_ctx* ctx, float dt, float step_time, float frame_time, float
 	return MPM_OK;
 }
 
+// The substep loop with fixed dt.  The host enqueues up to mpm_config.sync_interval substeps (default 8) back to back and only
+// then synchronises: every kernel reads its block counts from the status block, launches are sized by the counts of the last
+// synchronisation plus a margin (a kernel walks over what is beyond its launch), errors raised in between are sticky flags.
+// The reference synchronises the host six times per substep (gmpm_simulator.cuh:398,:470,:503,:518,:541,:564).
+static int run_fixed_fail(mpm_ctx* ctx, int rc) {
+	ctx->grid_preupdated = false;// an interrupted run leaves no promise about the grid behind (a checkpoint load restores a canonical one)
+	ctx->fuse_dt_once	 = 0.f;
+	ctx->rebuild_cleared = false;
+	return rc;
+}
 int mpm_run_fixed(mpm_ctx* ctx, int nsteps, float dt) {
 	if(!ctx || !ctx->ready) return MPM_ERR_NOT_READY;
 	HIP_TRY(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->s_compute;
+#ifdef MPM_G2P2G_NOLOOP
+	const int K = 1;
+#else
+	const int K = ctx->cfg.sync_interval > 0 ? std::min(ctx->cfg.sync_interval, 64) : 8;
+#endif
+	while((int) ctx->ev_ring.size() < 4 * K) {
+		hipEvent_t e = nullptr;
+		HIP_TRY(hipEventCreate(&e));
+		ctx->ev_ring.push_back(e);
+	}
+	{// the counts are exact here: a context that starts a run above the 3/4 mark grows before its first window, not after it
+		int rc = grow_capacity(ctx);
+		if(rc) return rc;
+	}
 	double acc_grid = 0, acc_g2p2g = 0, acc_part = 0, acc_total = 0;
+	int in_window = 0;
 	for(int it = 0; it < nsteps; ++it) {
-		HIP_TRY(hipEventRecord(ctx->ev_a, s));
+		hipEvent_t* ev = &ctx->ev_ring[4 * in_window];
+		HIP_TRY(hipEventRecord(ev[0], s));
 		int rc = launch_grid_update(ctx, dt);
-		if(rc) return rc;
-		rc = launch_g2p2g(ctx, dt, dt);// records ev_g0 / ev_g1 around the G2P2G kernel(s)
-		if(rc) return rc;
+		if(rc) return run_fixed_fail(ctx, rc);
+		rc = launch_g2p2g(ctx, dt, dt, ev[1], ev[2], true);
+		if(rc) return run_fixed_fail(ctx, rc);
 		rc = launch_rebuild(ctx, it + 1 < nsteps ? dt : 0.f);// the last substep leaves the canonical state behind
-		if(rc) return rc;
-		HIP_TRY(hipEventRecord(ctx->ev_b, s));
-		HIP_TRY(hipMemcpyAsync(ctx->h_maxvel, ctx->d_maxvel, sizeof(float) * kMaxVelSlots * kMaxVelStride, hipMemcpyDeviceToHost, s));
-		HIP_TRY(hipGetLastError());
-		rc = finish_rebuild(ctx, nullptr);
-		if(rc) return rc;
-		if(std::isinf(host_maxvel(ctx))) return fail(ctx, MPM_ERR_NONFINITE, "Maximum velocity is infinity");
-		float t_grid = 0, t_g = 0, t_part = 0, t_tot = 0;
-		HIP_TRY(hipEventElapsedTime(&t_grid, ctx->ev_a, ctx->ev_g0));
-		HIP_TRY(hipEventElapsedTime(&t_g, ctx->ev_g0, ctx->ev_g1));
-		HIP_TRY(hipEventElapsedTime(&t_part, ctx->ev_g1, ctx->ev_b));
-		HIP_TRY(hipEventElapsedTime(&t_tot, ctx->ev_a, ctx->ev_b));
-		acc_grid += t_grid;
-		acc_g2p2g += t_g;
-		acc_part += t_part;
-		acc_total += t_tot;
-		ctx->last_g2p2g_ms = t_g;
+		if(rc) return run_fixed_fail(ctx, rc);
+		HIP_TRY(hipEventRecord(ev[3], s));
+		roll_partition(ctx);
+		++in_window;
+		if(in_window == K || it + 1 == nsteps) {
+			HIP_TRY(hipMemcpyAsync(ctx->h_maxvel, ctx->d_maxvel, sizeof(float) * kMaxVelSlots * kMaxVelStride, hipMemcpyDeviceToHost, s));
+			HIP_TRY(hipGetLastError());
+			rc = sync_counts(ctx, nullptr);
+			if(rc) return run_fixed_fail(ctx, rc);
+			if(std::isinf(host_maxvel(ctx))) return run_fixed_fail(ctx, fail(ctx, MPM_ERR_NONFINITE, "Maximum velocity is infinity"));
+			for(int w = 0; w < in_window; ++w) {
+				hipEvent_t* e = &ctx->ev_ring[4 * w];
+				float t_grid = 0, t_g = 0, t_part = 0, t_tot = 0;
+				HIP_TRY(hipEventElapsedTime(&t_grid, e[0], e[1]));
+				HIP_TRY(hipEventElapsedTime(&t_g, e[1], e[2]));
+				HIP_TRY(hipEventElapsedTime(&t_part, e[2], e[3]));
+				HIP_TRY(hipEventElapsedTime(&t_tot, e[0], e[3]));
+				acc_grid += t_grid;
+				acc_g2p2g += t_g;
+				acc_part += t_part;
+				acc_total += t_tot;
+				ctx->last_g2p2g_ms = t_g;
+			}
+			in_window = 0;
+		}
 	}
 	if(nsteps > 0) {// per-substep averages over this call, HIP events on the compute stream
 		ctx->timers.grid_update_ms = (float) (acc_grid / nsteps);

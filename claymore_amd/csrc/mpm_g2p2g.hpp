@@ -322,7 +322,7 @@ MPM_DEV int code_off(int c) {
 }
 
 template<int MAT>
-__global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : MPM_G2P2G_WAVES) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_keys, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, float dt, float new_dt, StepConst sk, int* __restrict__ status) {
+__global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : MPM_G2P2G_WAVES) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_keys, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, const int* __restrict__ nblocks_ptr, int nblocks, float dt, float new_dt, StepConst sk, int* __restrict__ status) {
 	constexpr int NCH = MatTraits<MAT>::nch;
 	// 10.8 KB of LDS per wave: 15 single-wave workgroups per CU.
 	__shared__ float4 g2p[kG2PNodes];	   // node velocities {vx, vy, vz, vz} of cube nodes 1..6 per axis
@@ -335,18 +335,32 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 	if(size_t(grid) == 1) s_pad[threadIdx.x] = 0.f;
 #endif
 
-	const int lane = threadIdx.x;
+	const int lane0 = threadIdx.x;
 	// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Consecutive block numbers are spatial
 	// neighbours (they share grid blocks: reads in the set-up, atomics in the write-back), so every XCD gets one contiguous
 	// eighth of the block range instead of every eighth block.
-	const int nwg = (int) gridDim.x, xcd = (int) (blockIdx.x & 7u), q = (int) (blockIdx.x >> 3);
-	const int bid = xcd * (nwg >> 3) + min(xcd, nwg & 7) + q;// XCD r owns (nwg / 8) + (r < nwg % 8) consecutive numbers
+	// The number of blocks is read from device memory when nblocks_ptr is given (the launch is then sized by the host's ESTIMATE
+	// of it - mpm_run_fixed does not wait for the rebuild's counts -, a multiple of 8): workgroup (xcd, q) takes the blocks
+	// q, q + gridDim.x / 8, ... of its XCD's range; one trip when the estimate holds.
+#ifdef MPM_G2P2G_NOLOOP// A/B switch: exact launch sizes from the host (needs sync_interval = 1), one block per workgroup
+	const int total = nblocks;
+	const int xcd = (int) (blockIdx.x & 7u), nq = 0x40000000;
+#else
+	const int total = nblocks_ptr ? min(*nblocks_ptr, cfg.cap) : nblocks;
+	const int xcd = (int) (blockIdx.x & 7u), nq = nblocks_ptr ? (int) (gridDim.x >> 3) : 0x40000000;
+#endif
+	const int share = (total >> 3) + (xcd < (total & 7) ? 1 : 0);// XCD r owns (total / 8) + (r < total % 8) consecutive numbers
+	const int first = xcd * (total >> 3) + min(xcd, total & 7);
+	for(int q = (int) (blockIdx.x >> 3); q < share; q += nq) {
+	int lane = lane0;
+	__asm__ volatile("" : "+v"(lane));// (what a block derives from the lane number is formed per block: hoisted out of this loop it would sit in registers through the particle loop)
+	const int bid = first + q;
 	const int b	  = block_list ? block_list[bid] : bid;
 	// ---- round trip 1: everything addressed by the block number alone (scalar loads)
 	const int size		 = mv.size[b];
 	const int row		 = mv.row_of[b];
 	const int binoff_dst = mv.binoff_dst[b];
-	if(size == 0) return;// (:692-697)
+	if(size == 0) continue;// (:692-697)
 	const int* list		= mv.list_in + (size_t) row * cfg.ppb;
 	const float dx_inv	= cfg.dx_inv;
 	const float mass	= mv.mc.mass;
@@ -655,6 +669,8 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 			if(v.z != 0.f) unsafeAtomicAdd(g + 128, v.z);
 			if(v.w != 0.f) unsafeAtomicAdd(g + 192, v.w);
 		}
+	}
+	__syncthreads();// (a further block of this workgroup starts by clearing the arenas)
 	}
 }
 

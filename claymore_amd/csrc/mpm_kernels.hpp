@@ -41,8 +41,15 @@ constexpr int kSortKeys		= 216; // sort key = PREDICTED stencil base of the part
 constexpr int kKeyBits		= 8;
 constexpr int kStay		  = 13; // dir_offset(0,0,0), utility_funcs.hpp:25-27
 
-// status block indices (device ints, read back once per substep)
-enum { ST_PBC = 0, ST_NBC = 1, ST_EBC = 2, ST_OVERFLOW = 3, ST_LOST = 4, ST_ARENA = 5, ST_DROPPED = 6, ST_BINS0 = 8, ST_PART0 = 16, ST_WORDS = 32 };
+// status block indices (device ints; read back once per host synchronisation, i.e. once per window of substeps in mpm_run_fixed).
+// ST_PBC / ST_NBC / ST_EBC are the PUBLISHED counts of the current partition; during a rebuild the new partition is counted in the
+// three phase counters ST_CNT_P (particle blocks), ST_CNT_N (further neighbour blocks), ST_CNT_E (further exterior blocks) - a block
+// registered in a later phase gets the number base + counter, so no phase needs a snapshot of a running counter (the rebuild used to
+// take three 4-byte device-to-device copies for that) - and each count is published by the first kernel that runs after its phase.
+enum {
+	ST_PBC = 0, ST_NBC = 1, ST_EBC = 2, ST_OVERFLOW = 3, ST_LOST = 4, ST_ARENA = 5, ST_DROPPED = 6, ST_NONFINITE = 7, ST_BINS0 = 8, ST_PART0 = 16,
+	/* 24..28: MPM_G2P2G_STATS */ ST_CNT_P = 29, ST_CNT_N = 30, ST_CNT_E = 31, ST_BINSPREV = 32, ST_PBCPREV = 40, ST_WORDS = 64
+};
 
 struct GridCfg {
 	int G;		  // blocks per axis
@@ -167,12 +174,13 @@ constexpr int kMaxVelStride = 32;// ... one slot per 128-B line: the filtering l
 // Grid update: momentum -> velocity, gravity, slip walls, max |v|^2.   One wave per grid block, lane = cell.
 // (update_grid_velocity_query_max, mgmpm_kernels.cuh:325-420)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void grid_update_kernel(GridCfg cfg, int nblocks, float* __restrict__ grid, const int* __restrict__ keys, float dt, unsigned* __restrict__ max_vel_bits) {
-	// 16 lanes per grid block, 4 cells (one float4) per lane and channel: 16-B accesses, 4 blocks per wave
+__global__ __launch_bounds__(256) void grid_update_kernel(GridCfg cfg, const int* __restrict__ nbc_ptr, float* __restrict__ grid, const int* __restrict__ keys, float dt, unsigned* __restrict__ max_vel_bits) {
+	// 16 lanes per grid block, 4 cells (one float4) per lane and channel: 16-B accesses, 4 blocks per wave; the neighbour block
+	// count is read from device memory (the launch is sized by the host's estimate of it)
 	const int sub	  = threadIdx.x & 15;
-	const int blockno = (blockIdx.x * 256 + threadIdx.x) >> 4;
+	const int nblocks = min(*nbc_ptr, cfg.cap);
 	float vel_sqr	  = 0.f;
-	if(blockno < nblocks) {
+	for(int blockno = (blockIdx.x * 256 + threadIdx.x) >> 4; blockno < nblocks; blockno += gridDim.x * 16) {
 		const int kx = keys[3 * blockno], ky = keys[3 * blockno + 1], kz = keys[3 * blockno + 2];
 		const bool wx = kx < cfg.boundary || kx >= cfg.G - cfg.boundary;
 		const bool wy = ky < cfg.boundary || ky >= cfg.G - cfg.boundary;
@@ -217,11 +225,11 @@ __global__ __launch_bounds__(256) void grid_update_kernel(GridCfg cfg, int nbloc
 // Grid update with a level-set collision object (second update_grid_velocity_query_max overload,
 // Projects/MGSP/mgmpm_kernels.cuh:323-399): one wave per grid block, lane = cell.  Reports the reference's doubled
 // |v|^2 (vel.dot(vel) followed by the three += of the plain overload, :365-373).
-__global__ __launch_bounds__(256) void grid_update_collision_kernel(GridCfg cfg, int nblocks, float* __restrict__ grid, const int* __restrict__ keys, float dt, CollisionObject obj, unsigned* __restrict__ max_vel_bits) {
+__global__ __launch_bounds__(256) void grid_update_collision_kernel(GridCfg cfg, const int* __restrict__ nbc_ptr, float* __restrict__ grid, const int* __restrict__ keys, float dt, CollisionObject obj, unsigned* __restrict__ max_vel_bits) {
 	const int cell	  = threadIdx.x & 63;
-	const int blockno = (blockIdx.x * 256 + threadIdx.x) >> 6;
+	const int nblocks = min(*nbc_ptr, cfg.cap);
 	float vel_sqr	  = 0.f;
-	if(blockno < nblocks) {
+	for(int blockno = (blockIdx.x * 256 + threadIdx.x) >> 6; blockno < nblocks; blockno += gridDim.x * 4) {
 		const int kx = keys[3 * blockno], ky = keys[3 * blockno + 1], kz = keys[3 * blockno + 2];
 		const bool wx = kx < cfg.boundary || kx >= cfg.G - cfg.boundary;
 		const bool wy = ky < cfg.boundary || ky >= cfg.G - cfg.boundary;
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(256) void grid_update_collision_kernel(GridCfg cfg,
 			q += vel[1] * vel[1];
 			q += vel[2] * vel[2];
 			if(q != q) q = __builtin_inff();
-			vel_sqr = q;
+			vel_sqr = fmaxf(vel_sqr, q);
 		}
 	}
 #pragma unroll
@@ -316,15 +324,24 @@ struct PrepareModels {
 	const int* binoff_src[kMaxModels];	// bin offsets in the numbering the particle data is laid out in (previous partition)
 	int* blockinfo[kMaxModels];
 };
+// The launch is sized by a host-side ESTIMATE of the particle block count (the host does not wait for the rebuild's counts,
+// mpm_run_fixed); the true count is read from device memory and a workgroup walks over blocks b, b + gridDim.x, ... (one trip
+// when the estimate holds).  publish (the status block, or null): the rebuild's exterior phase is over by now - workgroup 0
+// publishes the exterior block count (status[ST_EBC], *part_count).
 template<bool SORT>
-__global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, PrepareModels pm, const int* __restrict__ pbc_ptr, const int* __restrict__ cur_table, const int* __restrict__ cur_keys, const int* __restrict__ prev_table) {
+__global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, PrepareModels pm, const int* __restrict__ pbc_ptr, const int* __restrict__ cur_table, const int* __restrict__ cur_keys, const int* __restrict__ prev_table, int* __restrict__ publish, int* __restrict__ part_count) {
 	// records are sorted in chunks of 512 (8 per lane): every 64-slot slice of a chunk is one G2P2G iteration
 	constexpr int kPrepChunk = kListChunk;
 	__shared__ int s_sorted[kPrepChunk];
 	__shared__ int s_cnt[256];// per key (216 used): count, then first position of the key in key-major order
 	const int lane = threadIdx.x;
-	const int b	   = blockIdx.x;
-	if(b >= *pbc_ptr) return;
+	if(publish && blockIdx.x == 0 && lane == 0) {
+		const int ebc	 = publish[ST_CNT_P] + publish[ST_CNT_N] + publish[ST_CNT_E];
+		publish[ST_EBC] = ebc;
+		*part_count		 = ebc;
+	}
+	const int pbc = min(*pbc_ptr, cfg.cap);
+	for(int b = blockIdx.x; b < pbc; b += gridDim.x) {
 	const int kx = cur_keys[3 * b], ky = cur_keys[3 * b + 1], kz = cur_keys[3 * b + 2];
 	// ---- look-ups (model independent except for the bin offsets)
 	int srcno = -1, other = -1;
@@ -412,6 +429,7 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 		}
 		pm.blockinfo[m][(size_t) b * kInfoRow + lane] = info;
 	}
+	}
 }
 
 }// namespace mpm
@@ -427,56 +445,114 @@ struct RebuildModels {
 	int* size[kMaxModels];
 	int* row_of[kMaxModels];
 	int* binoff[kMaxModels];// destination bin offsets for the NEXT step (new numbering)
+	long long bin_cap[kMaxModels];
 };
+
+// Everything a substep has to reset, in two kernels instead of the runtime's fill / copy commands (the rebuild alone used to
+// enqueue five fills and three 4-byte copies: ~0.05 ms of a 1.8 ms substep, and launch gaps that weigh more the smaller a rank's share):
+//   kClearP2G     (before G2P2G):   the P2G accumulation grid and the advection-list append counters;
+//   kClearRebuild (before compact): the table of the partition about to be rebuilt - its old keys are UN-INSERTED instead of
+//                 an 8 MiB 0xff fill (reset_table, hash_table.cuh:110-112) -, the phase counters, the bin / particle totals (the
+//                 previous bin totals are kept: they size the source bins of the next G2P2G), the running max |v|^2 slots of the
+//                 fused grid update (an infinite one leaves a sticky flag behind first, gmpm_simulator.cuh:355-358).
+// mpm_run_fixed issues both parts in ONE launch before G2P2G (nobody looks at the old table in between).  All sizes are read
+// from the status block.
+enum { kClearP2G = 1, kClearRebuild = 2 };
+struct ClearArgs {
+	int flags;
+	int nmodels;
+	int* out_count[kMaxModels];
+	float* p2g_grid;
+	int* status;
+	unsigned* max_vel_bits;
+	int* old_table;		  // table of the partition about to be rebuilt
+	const int* old_keys;  // its key list
+	const int* old_count; // its exterior block count
+};
+__global__ __launch_bounds__(256) void substep_clear_kernel(GridCfg cfg, ClearArgs a) {
+	const int tid = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256;
+	if(a.flags & kClearP2G) {
+		const int nbc = min(a.status[ST_NBC], cfg.cap), ebc = min(a.status[ST_EBC], cfg.cap);
+		float4* g	  = reinterpret_cast<float4*>(a.p2g_grid);
+		for(int i = tid; i < nbc * 64; i += nthreads) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+		for(int m = 0; m < a.nmodels; ++m)
+			for(int i = tid; i <= ebc; i += nthreads) a.out_count[m][i] = 0;
+	}
+	if(a.flags & kClearRebuild) {
+		const int n = min(*a.old_count, cfg.cap);
+		for(int i = tid; i < n; i += nthreads) a.old_table[key_index(cfg, a.old_keys[3 * i], a.old_keys[3 * i + 1], a.old_keys[3 * i + 2])] = -1;
+		if(blockIdx.x == gridDim.x - 1) {
+			if(threadIdx.x < kMaxModels) {
+				a.status[ST_BINSPREV + threadIdx.x] = a.status[ST_BINS0 + threadIdx.x];
+				a.status[ST_BINS0 + threadIdx.x]	= 0;
+				a.status[ST_PART0 + threadIdx.x]	= 0;
+			}
+			if(threadIdx.x >= 8 && threadIdx.x < 11) a.status[ST_CNT_P + threadIdx.x - 8] = 0;
+			if(threadIdx.x == 11) a.status[ST_PBCPREV] = a.status[ST_PBC];// (particle blocks of the numbering the particle data will be laid out in)
+			if(threadIdx.x >= 64 && threadIdx.x < 64 + kMaxVelSlots) {
+				unsigned* slot = a.max_vel_bits + (threadIdx.x - 64) * kMaxVelStride;
+				if(*slot >= 0x7f800000u) a.status[ST_NONFINITE] = 1;
+				*slot = 0u;
+			}
+		}
+	}
+}
 
 // One pass replaces mark_active_particle_blocks + exclusive_scan + exclusive_scan_inverse + update_partition +
 // update_buckets + compute_bin_capacity + exclusive_scan (gmpm_simulator.cuh:436-505): blocks that received
-// particles get a new number (wave-aggregated atomic), their key goes into the new table, their bins are
+// particles get a new number (workgroup-aggregated atomic), their key goes into the new table, their bins are
 // allocated.  Order of the new numbering is arbitrary (as it is in the reference: insert order of atomics).
-__global__ __launch_bounds__(1024) void compact_blocks_kernel(GridCfg cfg, int ebc, RebuildModels rm, const int* __restrict__ old_keys, int* __restrict__ new_keys, int* __restrict__ new_table, int* __restrict__ new_count, int* __restrict__ status) {
+// The old exterior block count is read from the status block; the launch is sized by a host-side estimate of it.
+__global__ __launch_bounds__(1024) void compact_blocks_kernel(GridCfg cfg, RebuildModels rm, const int* __restrict__ old_keys, int* __restrict__ new_keys, int* __restrict__ new_table, int* __restrict__ status) {
 	// The three counters of this kernel (new block numbers, bins, particle totals) share a cache line: same-line atomics
 	// serialise in L2 at ~11 ns each, so they are issued once per 1024-thread workgroup (3 x 95 at C3), not once per wave
 	// (3 x 1516 = 33 us, which was the kernel's whole run time).
-	const int b = blockIdx.x * blockDim.x + threadIdx.x;
-	int c[kMaxModels];
-	bool any = false;
-	for(int m = 0; m < rm.n; ++m) {
-		c[m] = b < ebc ? rm.out_count[m][b] : 0;
-		if(c[m] > cfg.ppb) {// more arrivals than list slots: G2P2G has set the overflow flag and left the surplus records out (drop policy:
-							// the block goes on with the ppb particles it has slots for; otherwise the host reports MPM_ERR_CAPACITY)
-			atomicAdd(&status[ST_DROPPED], c[m] - cfg.ppb);
-			c[m] = cfg.ppb;
-		}
-		any |= c[m] > 0;
-	}
-	// particles per model (the reference's "total number of particles" check, gmpm_simulator.cuh:617)
 	__shared__ int s_part[kMaxModels];
-	if(threadIdx.x < kMaxModels) s_part[threadIdx.x] = 0;
-	__syncthreads();
-	for(int m = 0; m < rm.n; ++m) {
-		int t = c[m];
+	const int ebc = min(status[ST_EBC], cfg.cap);
+	for(int b0 = blockIdx.x * blockDim.x; b0 < ebc; b0 += gridDim.x * blockDim.x) {// uniform trip count per workgroup (block_append has barriers)
+		const int b = b0 + threadIdx.x;
+		int c[kMaxModels];
+		bool any = false;
+		for(int m = 0; m < rm.n; ++m) {
+			c[m] = b < ebc ? rm.out_count[m][b] : 0;
+			if(c[m] > cfg.ppb) {// more arrivals than list slots: G2P2G has set the overflow flag and left the surplus records out (drop policy:
+								// the block goes on with the ppb particles it has slots for; otherwise the host reports MPM_ERR_CAPACITY)
+				atomicAdd(&status[ST_DROPPED], c[m] - cfg.ppb);
+				c[m] = cfg.ppb;
+			}
+			any |= c[m] > 0;
+		}
+		// particles per model (the reference's "total number of particles" check, gmpm_simulator.cuh:617)
+		__syncthreads();
+		if(threadIdx.x < kMaxModels) s_part[threadIdx.x] = 0;
+		__syncthreads();
+		for(int m = 0; m < rm.n; ++m) {
+			int t = c[m];
 #pragma unroll
-		for(int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
-		if((threadIdx.x & 63) == 0 && t) atomicAdd(&s_part[m], t);
-	}
-	__syncthreads();
-	if((int) threadIdx.x < rm.n && s_part[threadIdx.x]) atomicAdd(&status[ST_PART0 + threadIdx.x], s_part[threadIdx.x]);
-	const int nb = block_append(new_count, any ? 1 : 0);
-	int kx = 0, ky = 0, kz = 0;
-	if(any) {
-		kx = old_keys[3 * b], ky = old_keys[3 * b + 1], kz = old_keys[3 * b + 2];
-		new_keys[3 * nb]					  = kx;
-		new_keys[3 * nb + 1]				  = ky;
-		new_keys[3 * nb + 2]				  = kz;
-		new_table[key_index(cfg, kx, ky, kz)] = nb;
-	}
-	for(int m = 0; m < rm.n; ++m) {
-		const int nbins = any ? (c[m] + kBin - 1) / kBin : 0;
-		const int first = block_append(&status[ST_BINS0 + m], nbins);
+			for(int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+			if((threadIdx.x & 63) == 0 && t) atomicAdd(&s_part[m], t);
+		}
+		__syncthreads();
+		if((int) threadIdx.x < rm.n && s_part[threadIdx.x]) atomicAdd(&status[ST_PART0 + threadIdx.x], s_part[threadIdx.x]);
+		const int nb = block_append(&status[ST_CNT_P], any ? 1 : 0);
+		int kx = 0, ky = 0, kz = 0;
 		if(any) {
-			rm.size[m][nb]	 = c[m];
-			rm.row_of[m][nb] = b;
-			rm.binoff[m][nb] = nbins ? first : 0;
+			kx = old_keys[3 * b], ky = old_keys[3 * b + 1], kz = old_keys[3 * b + 2];
+			new_keys[3 * nb]					  = kx;
+			new_keys[3 * nb + 1]				  = ky;
+			new_keys[3 * nb + 2]				  = kz;
+			new_table[key_index(cfg, kx, ky, kz)] = nb;
+		}
+		for(int m = 0; m < rm.n; ++m) {
+			const int nbins = any ? (c[m] + kBin - 1) / kBin : 0;
+			const int first = block_append(&status[ST_BINS0 + m], nbins);
+			if(any) {
+				const bool fits = (long long) first + nbins <= rm.bin_cap[m];// (the host sizes the bins for the worst case and grows them at 3/4: never expected)
+				if(!fits) atomicOr(&status[ST_OVERFLOW], 4);
+				rm.size[m][nb]	 = fits ? c[m] : 0;
+				rm.row_of[m][nb] = b;
+				rm.binoff[m][nb] = (nbins && fits) ? first : 0;
+			}
 		}
 	}
 }
@@ -484,12 +560,16 @@ __global__ __launch_bounds__(1024) void compact_blocks_kernel(GridCfg cfg, int e
 // register_neighbor_blocks / register_exterior_blocks (mgmpm_kernels.cuh:117-151); pbc is read from device memory.
 // One LANE per (particle block, offset): the (HI-LO+1)^3 look-ups of a block are independent loads instead of a chain of
 // dependent ones in one thread (27 x ~1 us), and the few lanes that really insert share one counter atomic per workgroup.
+// A newly registered block gets the number *pbc_ptr (+ *base2_ptr) + its rank in this phase's own counter; `publish` (may be
+// null) receives that base - the count the PREVIOUS phase ended with.
 template<int LO, int HI>
-__global__ __launch_bounds__(256) void register_blocks_kernel(GridCfg cfg, const int* __restrict__ pbc_ptr, int* table, int* keys, int* count, int* status) {
+__global__ __launch_bounds__(256) void register_blocks_kernel(GridCfg cfg, const int* __restrict__ pbc_ptr, const int* __restrict__ base2_ptr, int* counter, int* publish, int* table, int* keys, int* status) {
 	constexpr int W	   = HI - LO + 1;
 	constexpr int NOFF = W * W * W;
 	constexpr int LPB  = NOFF <= 8 ? 8 : 32;// lanes per block (27 padded to 32)
-	const int pbc	   = *pbc_ptr;
+	const int pbc	   = min(*pbc_ptr, cfg.cap);
+	const int base	   = *pbc_ptr + (base2_ptr ? *base2_ptr : 0);
+	if(publish && blockIdx.x == 0 && threadIdx.x == 0) *publish = base;
 	const long long total = (long long) pbc * LPB;
 	const long long bound = (total + blockDim.x - 1) / blockDim.x * blockDim.x;// whole workgroups stay in the loop together (block_append has barriers)
 	for(long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x; t < bound; t += (long long) gridDim.x * blockDim.x) {
@@ -507,7 +587,7 @@ __global__ __launch_bounds__(256) void register_blocks_kernel(GridCfg cfg, const
 				if(table[i] == -1) claim = atomicCAS(&table[i], -1, -2) == -1;
 			}
 		}
-		const int idx = block_append(count, claim ? 1 : 0);// one counter atomic per workgroup (same-address atomics serialise in L2)
+		const int idx = base + block_append(counter, claim ? 1 : 0);// one counter atomic per workgroup (same-address atomics serialise in L2)
 		if(claim) {
 			if(idx < cfg.cap) {
 				table[i]		  = idx;
@@ -528,9 +608,12 @@ __global__ __launch_bounds__(256) void register_blocks_kernel(GridCfg cfg, const
 // UPDATE: the grid update of the NEXT substep (update_grid_velocity_query_max, :325-420; same arithmetic as grid_update_kernel)
 // is applied on the way - momentum -> velocity, gravity, slip walls, max |v|^2 - which saves that kernel's own pass over the
 // grid.  Used between the substeps of mpm_run_fixed, where the next dt is known and nobody looks at the grid in between.
+// Runs between the neighbour and the exterior registration: the new neighbour count is the sum of the first two phase counters, the
+// published status[ST_NBC] is still the OLD one (the exterior registration publishes the new one).
 template<bool UPDATE>
-__global__ __launch_bounds__(256) void carry_grid_kernel(GridCfg cfg, const int* __restrict__ new_nbc_ptr, const int* __restrict__ new_keys, const int* __restrict__ old_table, int old_nbc, const float* __restrict__ p2g_grid, float* __restrict__ grid, float dt, unsigned* __restrict__ max_vel_bits) {
-	const int nbc  = min(*new_nbc_ptr, cfg.cap);
+__global__ __launch_bounds__(256) void carry_grid_kernel(GridCfg cfg, const int* __restrict__ status, const int* __restrict__ new_keys, const int* __restrict__ old_table, const float* __restrict__ p2g_grid, float* __restrict__ grid, float dt, unsigned* __restrict__ max_vel_bits) {
+	const int nbc	  = min(status[ST_CNT_P] + status[ST_CNT_N], cfg.cap);
+	const int old_nbc = min(status[ST_NBC], cfg.cap);
 	const int lane = threadIdx.x & 63;
 	float vel_sqr  = 0.f;
 	for(int nb = blockIdx.x * 4 + (threadIdx.x >> 6); nb < nbc; nb += gridDim.x * 4) {

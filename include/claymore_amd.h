@@ -62,7 +62,10 @@ typedef struct mpm_config {
 	int drop_overflow;	 /* 0 (default): a block receiving more than max_ppc * 64 particles is MPM_ERR_CAPACITY; 1: the particles beyond the
 							capacity are dropped and counted (mpm_diagnostics.dropped_particles) - what the reference does, silently and
 							per cell (particle_buffer.cuh:122-130) */
-	int reserved[4];
+	int sync_interval;	 /* mpm_run_fixed: substeps enqueued between two host synchronisations (the kernels read their block counts from
+							device memory; errors raised in between are reported at the next synchronisation).  0 = default (8), 1 = one
+							synchronisation per substep.  The reference synchronises six times per substep (gmpm_simulator.cuh:398-564) */
+	int reserved[3];
 } mpm_config;
 
 /* Material parameter block (Projects/GMPM/particle_buffer.cuh:141-264).  Unused fields are ignored. */

@@ -538,3 +538,83 @@ def test_long_run_sand_stays_close_to_the_oracle():
     assert err["n"] == scenes.total_particles(sc)
     assert err["pos_rel"] < 2e-6, err
     assert err["grid_mass_rel"] < 1e-6, err
+
+
+def test_setup_time_overflow_is_an_error_whatever_the_drop_policy():
+    """drop_overflow covers particles that ARRIVE in a full block at run time; a block that starts with more particles than it has
+    list slots is a configuration error (a dropped particle must not have been rasterised): MPM_ERR_CAPACITY, also with the policy on."""
+    sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=3.0)
+    sc["config"]["max_ppc"] = 4          # 256 particles per block < 512 needed
+    sc["config"]["drop_overflow"] = 1
+    eng = build_engine(sc)
+    with pytest.raises(Exception) as ei:
+        eng.initial_setup()
+    assert "set-up" in str(ei.value) or "capacity" in str(ei.value).lower()
+    eng.close()
+
+
+@pytest.mark.parametrize("material", [_ffi.FIXED_COROTATED, _ffi.SAND])
+def test_run_fixed_is_independent_of_the_sync_interval(material):
+    """mpm_run_fixed enqueues sync_interval substeps between two host synchronisations (every kernel reads its block counts from the
+    status block, launches are sized by stale estimates).  One synchronisation per substep, the default 8 and a window longer than the
+    run must give the same trajectory (to float-atomic noise) and the same counts, here in a fast collision where the block counts
+    change every few substeps - and all of them the oracle's."""
+    sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=2.0, speed=3.0, material=material)
+    nsteps = 90
+    runs = {}
+    for k in (1, 8, 64):
+        sc["config"]["sync_interval"] = k
+        eng = build_engine(sc)
+        eng.initial_setup()
+        eng.run_fixed(nsteps, sc["dt"])
+        c = eng.counts()
+        runs[k] = (np.concatenate([eng.retrieve_positions(0), eng.retrieve_positions(1)]), (c.particle_blocks, c.neighbor_blocks, c.exterior_blocks))
+        d = eng.diagnostics()
+        assert d.lost_particles == 0 and d.discarded_p2g == 0
+        eng.close()
+    from parity_util import match
+    for k in (8, 64):
+        assert runs[k][1] == runs[1][1], (k, runs[k][1], runs[1][1])
+        idx, _ = match(runs[1][0].astype(np.float64), runs[k][0].astype(np.float64))
+        rel = np.abs(runs[k][0][idx].astype(np.float64) - runs[1][0]).max(axis=1) / np.abs(runs[1][0]).max(axis=1)
+        assert rel.max() < 2e-6, (k, rel.max())
+    del sc["config"]["sync_interval"]
+    w = match_and_compare(run_pair(sc, nsteps))
+    assert w["pos_rel"] < POS_TOL, w
+
+
+def test_failed_run_then_checkpoint_load_recovers():
+    """A run that stops with an error between two substeps (here: block capacity exhausted with grow = 0) leaves the grid in the
+    pre-updated state of the fused carry-over; loading a checkpoint must bring the canonical state back - flags included - and the
+    run must follow the reference trajectory again (round-2 advisor finding: the flags survived the load)."""
+    from parity_util import match
+    sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=4.0, speed=2.0)
+    ref = build_engine(sc)
+    ref.initial_setup()
+    ebc = ref.counts().exterior_blocks
+    ckpt = ref.save_checkpoint().copy()
+    ref.run_fixed(3, sc["dt"])
+    want = ref.retrieve_positions(0)
+    ref.close()
+    small = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=4.0, speed=2.0)
+    small["config"]["max_blocks"] = ebc + 2
+    small["config"]["grow"] = 0
+    eng = build_engine(small)
+    eng.initial_setup()
+    failed = False
+    for _ in range(100):                     # the spheres move: sooner or later more blocks than the fixed capacity holds
+        try:
+            eng.run_fixed(10, sc["dt"])
+        except Exception as e:
+            failed = "block" in str(e).lower() or "capacity" in str(e).lower()
+            break
+    if not failed:
+        eng.close()
+        pytest.skip("the block count never exceeded the fixed capacity")
+    eng.load_checkpoint(ckpt)                # rewind to t = 0 (fits: set-up needed ebc blocks)
+    eng.run_fixed(3, sc["dt"])
+    got = eng.retrieve_positions(0)
+    idx, _ = match(want.astype(np.float64), got.astype(np.float64))
+    rel = np.abs(got[idx].astype(np.float64) - want).max(axis=1) / np.abs(want).max(axis=1)
+    assert rel.max() < 2e-6, rel.max()
+    eng.close()

@@ -78,7 +78,10 @@ def main():
             if "c3flow" in want:
                 eng = build_engine(sc3, api=api)
                 eng.initial_setup()
-                eng.load_checkpoint(ckpt)
+                try:
+                    eng.load_checkpoint(ckpt)
+                except Exception:      # another checkpoint format: this library walks into the flow by itself
+                    eng.run_fixed(args.flow_start, sc3["dt"])
                 g, p, w = window(eng, 5, 20, sc3["dt"])
                 row.append(f"| C3 flow: g2p2g {g:.4f} part {p:.4f} step {w:.4f}")
                 eng.close()
