@@ -6,14 +6,17 @@
 A "step" is one MPM substep (grid update -> fused G2P2G -> sparse partition rebuild [-> halo exchange for
 N > 1]) over one synthetic scene.  N = 1 runs BASELINE config 3, the configuration the metric is quoted on:
 the 40.1 M-particle Drucker-Prager sand column on a 512^3 sparse grid (`configs[2]`).  N > 1 is MGSP (static particle
-partition, one rank per GPU, the substep loop and the halo exchange in the C++ driver on RCCL) and keeps the work PER GPU
-fixed by default (weak scaling): N touching C3 columns on the same 512^3 grid, one per rank, N x 40.1 M particles, every
-rank with halo blocks on the faces it shares; `--scaling strong` cuts the one C3 column into N equal-count slabs
-instead.  Inputs are resident in HBM before the timed region; value = particles of all ranks * K / time.
+partition, one rank per GPU, the substep loop and the halo exchange in the C++ driver on RCCL) on the SAME workload - STRONG
+scaling, as BASELINE's metric states ("ms/step at 40 M particles, 512^3, 1/2/4/8 MI355X"; reference docs/benchmark.rst:43-48):
+the one C3 column cut into N equal-count slabs along its longest axis.  `--scaling weak` is the other experiment (N touching C3
+columns on the same grid, one per rank, N x 40.1 M particles).  Inputs are resident in HBM before the timed region;
+value = particles of all ranks * K / time.
 
 Extra objects on the JSON line:
   roofline     - G2P2G (the dominant kernel): algorithmic bytes per launch (144 B/particle
-                 for sand) / average kernel duration from HIP events on the engine's compute stream, vs 8 TB/s
+                 for sand) / average kernel duration from HIP events on the engine's compute stream, vs 8 TB/s;
+                 roofline.flow: the same for a second short window inside the flow (the default window of C3 is free fall, the
+                 kernel's cheapest regime); traffic / executed instructions from the PMC profile of the MATCHING window
   cpu_baseline - the CPU oracle ("port" of the reference pipeline, serial) timed on this host on a bounded,
                  geometrically similar sample of the same workload (rank 0, N = 1 only)
 """
@@ -117,8 +120,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mgsp", action="store_true", help="debug: drive the multi-GPU code path even with one rank")
     ap.add_argument("--max-ppc", type=int, default=0, help="debug: override the scene's particles-per-cell capacity (reference: 128)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = one C3 column per rank (N x 40.1 M particles), strong = the one C3 column cut N ways")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N > 1: strong (BASELINE's metric) = the one C3 column cut N ways, weak = one C3 column per rank (N x 40.1 M particles)")
+    ap.add_argument("--flow-start", type=int, default=3000,
+                    help="N = 1, default scene: after the timed window the run goes on to this substep and a second short window is timed "
+                         "inside the flow (reported as roofline.flow; 0 = skip)")
+    ap.add_argument("--sync-interval", type=int, default=0, help="debug: mpm_config.sync_interval (0 = library default)")
     args = ap.parse_args()
 
     # stdout carries exactly one line, the JSON record: libraries that print banners there (gloo's "connected to N peer ranks",
@@ -165,6 +172,8 @@ def main():
         n_total = scenes.total_particles(sc)
     if args.max_ppc:
         sc["config"]["max_ppc"] = args.max_ppc
+    if args.sync_interval:
+        sc["config"]["sync_interval"] = args.sync_interval
     material = sc["models"][0]["material"]
     dt = sc["dt"]
 
@@ -198,6 +207,23 @@ def main():
         assert bucketed == n_total, check
         assert diag.lost_particles == 0 and diag.discarded_p2g == 0, check
         assert check["grid_mass_rel_err"] < 1e-4 and np.isfinite(totals).all(), check
+        flow = None
+        done = args.start_step + args.warmup + args.steps
+        if args.scene == "sand40m" and args.fraction >= 1.0 and not args.start_step and args.flow_start > done:
+            # second window, inside the flow: the column is collapsing (block churn, mispredicted sort keys, plastic return mapping)
+            eng.run_fixed(args.flow_start - done, dt)
+            eng.run_fixed(5, dt)
+            torch.cuda.synchronize()
+            tf0 = time.perf_counter()
+            eng.run_fixed(20, dt)
+            torch.cuda.synchronize()
+            tf = time.perf_counter() - tf0
+            tmf = eng.timers()
+            df = eng.diagnostics()
+            cf = eng.counts()
+            assert sum(cf.particles[i] for i in range(cf.model_count)) == n_total and df.lost_particles == 0, "flow window lost particles"
+            flow = {"start_step": args.flow_start + 5, "steps": 20, "kernel_ms": tmf.g2p2g_ms, "ms_per_step": 1e3 * tf / 20,
+                    "blocks": {"particle": cf.particle_blocks, "neighbor": cf.neighbor_blocks, "exterior": cf.exterior_blocks}}
         eng.close()
     else:
         from claymore_amd.mgsp import MgspGroupRank
@@ -233,6 +259,7 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         check = {"particles_bucketed": int(tot[0].item()), "lost_particles": int(tot[1].item()), "discarded_p2g": int(tot[2].item())}
         assert check["particles_bucketed"] == n_total and check["lost_particles"] == 0 and check["discarded_p2g"] == 0, check
+        flow = None
         sim.close()
 
     if rank == 0:
@@ -243,7 +270,7 @@ def main():
         out = {
             "metric": "particles*steps/sec", "value": value, "unit": "particles*steps/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "particles": n_total, "dt": dt,
                        "parallelism": "single GPU" if not use_mgsp else
                        f"mgsp static particle partition x{world} ({'one column per rank' if weak else 'equal-count slabs of the one column'}), C++ driver on RCCL",
@@ -253,7 +280,8 @@ def main():
                          "kernel": "g2p2g_kernel", "bytes_per_particle": bpp, "particles_per_launch": n_rank,
                          "kernel_ms": g2p2g_ms},
         }
-        # the kernel's arithmetic intensity sits at the fp32-vector ridge, so the VALU bound is reported too
+        # the kernel's arithmetic intensity sits at the fp32-vector ridge, so the VALU side is reported too: the
+        # algorithmic figure of the reference formulation, and - from the PMC profile of the matching window - what this engine executes
         fpp = FLOPS_PER_PARTICLE[material]
         tfl = (n_rank * fpp) / (g2p2g_ms * 1e-3) / 1e12 if g2p2g_ms > 0 else 0.0
         out["roofline"]["valu"] = {"flops_per_particle": fpp, "achieved_tflops": tfl, "peak": FP32_VECTOR_PEAK_TFLOPS,
@@ -263,13 +291,34 @@ def main():
             out["config"]["start_step"] = args.start_step
         if check is not None:
             out["config"]["self_check"] = check
-        # measured HBM traffic of the same kernel on the same workload (PMC passes are separate runs, see profiles/)
-        tf = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-        if world == 1 and args.scene == "sand40m" and args.fraction >= 1.0 and os.path.exists(tf):
-            t = json.load(open(tf))
-            out["roofline"]["traffic"] = t["traffic_bytes"]
-            out["roofline"]["traffic_source"] = "profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, calibrated)"
-            out["roofline"]["algorithmic_bytes"] = n_rank * bpp
+        # measured HBM traffic and executed instructions of the same kernel on the same workload and WINDOW (PMC passes are separate
+        # runs, see profiles/): "rest" = the default window, "flow" = a window that starts after >= 2000 substeps
+        tf = os.path.join(ROOT, "profiles", "r03_pmc.json")
+        pmc = json.load(open(tf)) if os.path.exists(tf) else {}
+        c3 = world == 1 and args.scene == "sand40m" and args.fraction >= 1.0
+
+        def attach(dst, window, kernel_ms):
+            w = pmc.get(window)
+            if not (c3 and w):
+                return
+            dst["traffic"] = w["traffic_bytes"]
+            dst["traffic_source"] = f"profiles/r03_pmc.json[{window}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of g2p2g_kernel<2>, corrected as MI355X_MICROARCH.md prescribes)"
+            dst["algorithmic_bytes"] = n_rank * bpp
+            if "valu_insts" in w:
+                # one wave-instruction serves 64 particles: instructions per particle (= per 64-particle iteration of a wave)
+                per_particle = w["valu_insts"] * 64.0 / n_rank
+                # issue-busy: wave-instructions x the measured cost of this kernel's mix (profiles/r03_energy_model.txt: VOP2 2.07, VOP3 2.16,
+                # packed 4.26 cycles; ~2.75 on average) / SIMD cycles available at the sclk the launch runs at (1.97 GHz: it is power-limited)
+                busy = w["valu_insts"] * 2.75 / (1024 * kernel_ms * 1e-3 * 1.97e9) if kernel_ms > 0 else 0.0
+                dst["valu_executed"] = {"wave_instructions_per_launch": w["valu_insts"], "executed_per_particle": per_particle, "issue_busy": busy,
+                                        "note": "SQ_INSTS_VALU of the profiled launch; issue_busy prices an instruction at 2.75 cycles of a 1.97 GHz SIMD (measured mix and clock)"}
+
+        attach(out["roofline"], "flow" if args.start_step >= 2000 else "rest", g2p2g_ms)
+        if flow:
+            fa = (n_rank * bpp) / (flow["kernel_ms"] * 1e-3) / 1e9
+            out["roofline"]["flow"] = {"start_step": flow["start_step"], "steps": flow["steps"], "kernel_ms": flow["kernel_ms"], "achieved": fa,
+                                       "frac": fa / HBM_PEAK_GBS, "ms_per_step": flow["ms_per_step"], "blocks": flow["blocks"], "traffic": None}
+            attach(out["roofline"]["flow"], "flow", flow["kernel_ms"])
         if world == 1 and not args.no_cpu_baseline and not args.mgsp:
             out["cpu_baseline"] = cpu_baseline(args)
         sys.stdout.flush()

@@ -75,7 +75,7 @@ SIGNATURES = {
     "dump_grid": (_i, [_vp, _vp, _vp, _P(_sz)]),
     "default_collision_object": (_i, [_P(CollisionObject)]),
     "set_collision_object": (_i, [_vp, _P(CollisionObject), _vp, _vp, _vp, _vp]),
-    "test_svd": (_i, [_vp, _sz, _vp, _i]),
+    "test_eig": (_i, [_vp, _sz, _vp, _i]),
     "test_stress": (_i, [_i, _P(MaterialParams), _vp, _vp, _sz, _vp, _i]),
 }
 HALO = {

@@ -1066,15 +1066,16 @@ int mpm_dump_grid(mpm_ctx* ctx, int* keys, float* blocks, size_t* nblocks) {
 		if((expr) != hipSuccess) return MPM_ERR_DEVICE; \
 	} while(0)
 
-int mpm_test_svd(const float* F, size_t n, float* out21, int device) {
+int mpm_test_eig(const float* F, size_t n, float* out12, int device) {
+	if(!F || !out12 || n == 0) return MPM_ERR_INVALID;
 	HIP_TRY0(hipSetDevice(device));
 	DevScratch<float> dF, dO;
 	HIP_TRY0(dF.alloc(9 * n));
-	HIP_TRY0(dO.alloc(21 * n));
+	HIP_TRY0(dO.alloc(12 * n));
 	HIP_TRY0(hipMemcpy(dF.p, F, sizeof(float) * 9 * n, hipMemcpyHostToDevice));
-	test_svd_kernel<<<cdiv(n, 256), 256>>>(n, dF.p, dO.p);
+	test_eig_kernel<<<cdiv(n, 256), 256>>>(n, dF.p, dO.p);
 	HIP_TRY0(hipGetLastError());
-	HIP_TRY0(hipMemcpy(out21, dO.p, sizeof(float) * 21 * n, hipMemcpyDeviceToHost));
+	HIP_TRY0(hipMemcpy(out12, dO.p, sizeof(float) * 12 * n, hipMemcpyDeviceToHost));
 	return MPM_OK;
 }
 

@@ -1,7 +1,7 @@
 // mpm_device_math.hpp — register-resident per-particle math for gfx950 (CDNA4).
 //
-// Device versions of the arithmetic on claymore's G2P2G path.  Everything stays in VGPRs: 3x3 products,
-// the McAdams SVD and the four constitutive models (no MFMA: the contractions are 3-wide).  The
+// Device versions of the arithmetic on claymore's G2P2G path.  Everything stays in VGPRs: 3x3 products, the symmetric
+// eigen-decomposition that stands in for the reference's SVD and the four constitutive models (no MFMA: the contractions are 3-wide).  The
 // algorithms are the reference's (cited per function, paths relative to /root/reference); the code is
 // written for the AMD compiler: selects instead of bit masks (v_cndmask), v_rsq_f32 where the algorithm
 // tolerates an approximate reciprocal square root, FMA contraction allowed.
@@ -100,267 +100,13 @@ MPM_DEV float exp_fast(float x) {
 MPM_DEV float rsqrt_approx(float x) {
 	return __builtin_amdgcn_rsqf(x);// v_rsq_f32, ~1 ulp; the algorithm re-normalises (svd.cuh:210-215)
 }
-// rsqrt refined by one Newton step, svd.cuh:487-498
-MPM_DEV float rsqrt_newton(float x) {
-	float t1 = rsqrt_approx(x);
-	float t4 = t1 * 0.5f;
-	float t3 = t1 * t4;
-	t3		 = t1 * t3;
-	t3		 = x * t3;
-	t1		 = t1 + t4;
-	return t1 - t3;
-}
-
-// One Jacobi conjugation, Library/MnBase/Math/Matrix/svd.cuh:167-252 (and its two index-permuted copies): same
-// approximate Givens angle (rsqrt-normalised (ch, sh), pi/8 fallback).  Two deliberate simplifications, both exact
-// in exact arithmetic and ~1e-7 in fp32: (1) columns p, q of V are rotated directly instead of accumulating a
-// quaternion that is normalised and expanded afterwards (:236-252, :475-530); (2) the compensation factors
-// (sh^2 + ch^2), which equal 1 up to the rsqrt rounding, are dropped (:219-223).
-MPM_DEV void jacobi_conj(float& s11, float& s21, float& s22, float& s31, float& s32, float& s33, float (&vp)[3], float (&vq)[3]) {
-	float sh   = s21 * 0.5f;
-	float tmp5 = s11 - s22;
-	float tmp2 = sh * sh;
-	bool m	   = tmp2 >= 1.e-20f;
-	sh		   = m ? sh : 0.0f;
-	float ch   = m ? tmp5 : 1.0f;
-	float tmp1 = sh * sh;
-	tmp2	   = ch * ch;
-	const float tmp4 = rsqrt_approx(tmp1 + tmp2);
-	sh		   = tmp4 * sh;
-	ch		   = tmp4 * ch;
-	m		   = tmp2 <= 5.8284273147583007813f * tmp1;
-	sh		   = m ? __uint_as_float(1053028117u) : sh;// sin(pi/8)
-	ch		   = m ? __uint_as_float(1064076127u) : ch;// cos(pi/8)
-	const float c = ch * ch - sh * sh;
-	const float s = 2.f * ch * sh;
-	// Givens conjugation of the symmetric matrix
-	const float t31 = s * s31, t32 = s * s32;
-	s31				= c * s31 + t32;
-	s32				= c * s32 - t31;
-	const float ss = s * s, cc = c * c, cs = c * s;
-	const float n11 = s11 * cc + s22 * ss;
-	const float n22 = s22 * cc + s11 * ss;
-	const float t2	= (s21 + s21) * cs;
-	s21				= s21 * (cc - ss) - tmp5 * cs;
-	s11				= n11 + t2;
-	s22				= n22 - t2;
-	// V <- V G
-	const v2f_ p = {vp[0], vp[1]}, q = {vq[0], vq[1]};
-	const v2f_ pn = p * c + q * s, qn = q * c - p * s;
-	const float pz = vp[2], qz = vq[2];
-	vp[0] = pn.x;
-	vp[1] = pn.y;
-	vp[2] = c * pz + s * qz;
-	vq[0] = qn.x;
-	vq[1] = qn.y;
-	vq[2] = c * qz - s * pz;
-}
-
-MPM_DEV void cond_swap(bool c, float& x, float& y) {
-	const float t = x;
-	x			  = c ? y : x;
-	y			  = c ? t : y;
-}
-
-// One Givens step of the QR factorisation, svd.cuh:786-880.  (ap*, aq*) are rows p and q of B, (up*, uq*) columns
-// p and q of U; apiv / aqpiv are the pivot-column entries (aliases of ap*/aq* elements, read first).
-MPM_DEV void qr_givens(float apiv, float aqpiv, float& ap1, float& ap2, float& ap3, float& aq1, float& aq2, float& aq3, float& up1, float& up2, float& up3, float& uq1, float& uq2, float& uq3) {
-	float sh   = aqpiv * aqpiv;
-	sh		   = (sh >= 1.e-12f) ? aqpiv : 0.0f;
-	float ch   = fmaxf(fmaxf(-apiv, apiv), 1.e-12f);
-	const bool m = apiv >= 0.f;
-	float tmp2 = ch * ch + sh * sh;
-	float tmp1 = rsqrt_newton(tmp2) * tmp2;
-	ch		   = ch + tmp1;
-	{
-		const float nch = m ? ch : sh;
-		const float nsh = m ? sh : ch;
-		ch				= nch;
-		sh				= nsh;
-	}
-	tmp2	= ch * ch + sh * sh;
-	tmp1	= rsqrt_newton(tmp2);
-	ch		= ch * tmp1;
-	sh		= sh * tmp1;
-	const float c = ch * ch - sh * sh;
-	float s		  = sh * ch;
-	s			  = s + s;
-#define MPM_ROT(x, y)            \
-	{                            \
-		const float t1 = s * x;  \
-		const float t2 = s * y;  \
-		x			   = c * x + t2; \
-		y			   = c * y - t1; \
-	}
-	MPM_ROT(ap1, aq1)
-	MPM_ROT(ap2, aq2)
-	MPM_ROT(ap3, aq3)
-	MPM_ROT(up1, uq1)
-	MPM_ROT(up2, uq2)
-	MPM_ROT(up3, uq3)
-#undef MPM_ROT
-}
-
-// math::svd, Library/MnBase/Math/Matrix/svd.cuh:27-1123.  Column-major F, U, V.
-// Same algorithm as the reference (4 cyclic Jacobi sweeps on F^T F, columns sorted by norm with V kept a rotation,
-// sigma_3 carrying the sign of det F).  U and Sigma come from B = F V: when B is well conditioned its columns are
-// sigma_i u_i, so they are normalised directly (sigma_i = |b_i|, sign of sigma_3 from det B); the reference's Givens
-// QR (:771-1122) is kept as the path for ill-conditioned B (sigma_3 < 1e-3 sigma_1), where normalising would divide
-// by ~0.  Deviation from the reference's QR result is of the order of the Jacobi residual of the reference itself
-// (tests/test_parity_gpu.py, tools note in DESIGN.md section 6).
-//
 // Hook: the G2P2G kernel threads an unrelated, latency-bound chain of LDS read-modify-write steps (the P2G scatter of
-// the previous particle) through this arithmetic; `hk.at<SITE>()` is called at kSvdSites evenly spaced points that
+// the previous particle) through the per-particle arithmetic; `hk.at<SITE>()` is called at evenly spaced points that
 // every lane reaches (never inside divergent control flow).  NoHook compiles to nothing.
 struct NoHook {
 	template<int SITE>
 	MPM_DEV void at() {}
 };
-constexpr int kSvdSites = 16;
-// SORTED = false (the stress functions): the columns are left in the order Jacobi produced them.  Every consumer on
-// this path is symmetric under a simultaneous permutation of (sigma_i, u_i, v_i), and the three conditional column
-// swaps cost ~60 VALU instructions per particle; only the sign convention (a negative determinant goes to the SMALLEST
-// singular value) is kept.  SORTED = true is math::svd's contract and is what mpm_test_svd exposes.
-template<int BASE, class Hook, bool SORTED = true>
-MPM_DEV void svd3(const float (&F)[9], float (&U)[9], float (&S)[3], float (&V)[9], Hook& hk) {
-	float s11 = F[0] * F[0] + F[1] * F[1] + F[2] * F[2];
-	float s21 = F[3] * F[0] + F[4] * F[1] + F[5] * F[2];
-	float s31 = F[6] * F[0] + F[7] * F[1] + F[8] * F[2];
-	float s22 = F[3] * F[3] + F[4] * F[4] + F[5] * F[5];
-	float s32 = F[6] * F[3] + F[7] * F[4] + F[8] * F[5];
-	float s33 = F[6] * F[6] + F[7] * F[7] + F[8] * F[8];
-	float v1[3] = {1.f, 0.f, 0.f}, v2[3] = {0.f, 1.f, 0.f}, v3[3] = {0.f, 0.f, 1.f};
-	MPM_MARK("svd_jacobi");
-	hk.template at<BASE + 0>();
-	// The reference always runs 4 sweeps (svd.cuh:167) of its approximate-angle rotations.  Cyclic Jacobi converges
-	// quadratically, so once every off-diagonal entry of F^T F of every lane is below 1e-6 of the smallest diagonal
-	// entry, U's columns are orthogonal to ~1e-6 (what the reference's four approximate sweeps reach themselves) and
-	// the singular values are exact to ~1e-12 relative; the remaining sweeps are skipped for the whole wave then
-	// (`done` is wave-uniform: scalar branches).
-	bool done = false;
-#define MPM_SWEEP(IT)                                                                  \
-	if(!done) jacobi_conj(s11, s21, s22, s31, s32, s33, v1, v2);                      \
-	hk.template at<BASE + 1 + 3 * IT>();                                              \
-	if(!done) jacobi_conj(s22, s32, s33, s21, s31, s11, v2, v3);                      \
-	hk.template at<BASE + 2 + 3 * IT>();                                              \
-	if(!done) {                                                                       \
-		jacobi_conj(s33, s31, s11, s32, s21, s22, v3, v1);                            \
-		const float off = fmaxf(fmaxf(fabsf(s21), fabsf(s31)), fabsf(s32));           \
-		const float dia = fminf(fminf(fabsf(s11), fabsf(s22)), fabsf(s33));           \
-		done			= __all(off <= 1e-6f * dia);                                  \
-	}                                                                                 \
-	hk.template at<BASE + 3 + 3 * IT>();
-	MPM_SWEEP(0)
-	MPM_SWEEP(1)
-	MPM_SWEEP(2)
-	MPM_SWEEP(3)
-#undef MPM_SWEEP
-	MPM_MARK("svd_post");
-	// B = F V (svd.cuh:532-588), columns b1 b2 b3
-	float b1[3], b2[3], b3[3];
-	{
-		const v2f_ f0 = {F[0], F[1]}, f1 = {F[3], F[4]}, f2 = {F[6], F[7]};
-#define MPM_FV(bk, vk)                                            \
-	{                                                             \
-		const v2f_ xy = f0 * vk[0] + f1 * vk[1] + f2 * vk[2];     \
-		bk[0]		  = xy.x;                                     \
-		bk[1]		  = xy.y;                                     \
-		bk[2]		  = F[2] * vk[0] + F[5] * vk[1] + F[8] * vk[2]; \
-	}
-		MPM_FV(b1, v1)
-		MPM_FV(b2, v2)
-		MPM_FV(b3, v3)
-#undef MPM_FV
-	}
-	float n1 = b1[0] * b1[0] + b1[1] * b1[1] + b1[2] * b1[2];
-	float n2 = b2[0] * b2[0] + b2[1] * b2[1] + b2[2] * b2[2];
-	float n3 = b3[0] * b3[0] + b3[1] * b3[1] + b3[2] * b3[2];
-	hk.template at<BASE + 13>();
-	// sort columns by squared norm, descending; a swap negates one column so that V stays a rotation (svd.cuh:590-770)
-#define MPM_SWAPCOL(c, x, y, nx, ny, neg)                         \
-	{                                                             \
-		const float sg = (c) ? -1.f : 1.f;                        \
-		_Pragma("unroll") for(int r = 0; r < 3; ++r) {            \
-			cond_swap(c, b##x[r], b##y[r]);                       \
-			cond_swap(c, v##x[r], v##y[r]);                       \
-			b##neg[r] *= sg;                                      \
-			v##neg[r] *= sg;                                      \
-		}                                                         \
-		cond_swap(c, nx, ny);                                     \
-	}
-	if constexpr(SORTED) {
-		MPM_SWAPCOL(n1 < n2, 1, 2, n1, n2, 2)
-		MPM_SWAPCOL(n1 < n3, 1, 3, n1, n3, 1)
-		MPM_SWAPCOL(n2 < n3, 2, 3, n2, n3, 3)
-	}
-	const float nmin = fminf(fminf(n1, n2), n3), nmax = fmaxf(fmaxf(n1, n2), n3);
-	bool well = nmin > 1e-6f * nmax;
-	if constexpr(!SORTED) {
-		if(!well) {// ill conditioned (rare): sort after all, the Givens QR below wants descending columns
-			MPM_SWAPCOL(n1 < n2, 1, 2, n1, n2, 2)
-			MPM_SWAPCOL(n1 < n3, 1, 3, n1, n3, 1)
-			MPM_SWAPCOL(n2 < n3, 2, 3, n2, n3, 3)
-		}
-	}
-#undef MPM_SWAPCOL
-#pragma unroll
-	for(int r = 0; r < 3; ++r) {
-		V[r]	 = v1[r];
-		V[3 + r] = v2[r];
-		V[6 + r] = v3[r];
-	}
-	hk.template at<BASE + 14>();
-	if(well) {
-		// well conditioned: u_i = b_i / sigma_i
-		const float det = b1[0] * (b2[1] * b3[2] - b2[2] * b3[1]) - b2[0] * (b1[1] * b3[2] - b1[2] * b3[1]) + b3[0] * (b1[1] * b2[2] - b1[2] * b2[1]);
-		float i1 = rsqrt_approx(n1), i2 = rsqrt_approx(n2);// v_rsq_f32 is 1 ulp: no Newton step needed (svd.cuh:487-498 refines a 12-bit estimate)
-		float i3 = rsqrt_approx(n3);
-		if(det < 0.f) {// the smallest singular value carries the sign of det F (svd.cuh:590-770 does this through the sort)
-			if constexpr(SORTED) {
-				i3 = -i3;
-			} else {
-				const bool m1 = n1 <= n2 && n1 <= n3, m2 = !m1 && n2 <= n3;
-				i1 = m1 ? -i1 : i1;
-				i2 = m2 ? -i2 : i2;
-				i3 = (!m1 && !m2) ? -i3 : i3;
-			}
-		}
-		S[0] = n1 * i1;
-		S[1] = n2 * i2;
-		S[2] = n3 * i3;
-#pragma unroll
-		for(int r = 0; r < 3; ++r) {
-			U[r]	 = b1[r] * i1;
-			U[3 + r] = b2[r] * i2;
-			U[6 + r] = b3[r] * i3;
-		}
-	} else {
-		// ill conditioned: the reference's QR by three Givens rotations (svd.cuh:772-1090)
-		float a11 = b1[0], a21 = b1[1], a31 = b1[2], a12 = b2[0], a22 = b2[1], a32 = b2[2], a13 = b3[0], a23 = b3[1], a33 = b3[2];
-		float u11 = 1.f, u12 = 0.f, u13 = 0.f, u21 = 0.f, u22 = 1.f, u23 = 0.f, u31 = 0.f, u32 = 0.f, u33 = 1.f;
-		qr_givens(a11, a21, a11, a12, a13, a21, a22, a23, u11, u21, u31, u12, u22, u32);
-		qr_givens(a11, a31, a11, a12, a13, a31, a32, a33, u11, u21, u31, u13, u23, u33);
-		qr_givens(a22, a32, a21, a22, a23, a31, a32, a33, u12, u22, u32, u13, u23, u33);
-		U[0] = u11;
-		U[1] = u21;
-		U[2] = u31;
-		U[3] = u12;
-		U[4] = u22;
-		U[5] = u32;
-		U[6] = u13;
-		U[7] = u23;
-		U[8] = u33;
-		S[0] = a11;
-		S[1] = a22;
-		S[2] = a33;
-	}
-	hk.template at<BASE + 15>();
-	MPM_MARK("svd_end");
-}
-MPM_DEV void svd3(const float (&F)[9], float (&U)[9], float (&S)[3], float (&V)[9]) {
-	NoHook nh;
-	svd3<0>(F, U, S, V, nh);
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Symmetric eigen-decomposition b = F F^T = U diag(lam) U^T by cyclic Jacobi with EXACT rotations.
@@ -374,7 +120,7 @@ MPM_DEV void svd3(const float (&F)[9], float (&U)[9], float (&S)[3], float (&V)[
 // approximate Givens angle (svd.cuh:167-252), which costs half the arithmetic per rotation: the updated diagonal is
 // s_pp - t s_pq, s_qq + t s_pq and s_pq := 0.  Sweeps stop for the whole wave once every off-diagonal entry of every
 // lane is below 1e-6 of the smallest diagonal entry (at most 4 sweeps, the reference's fixed count).
-// Hook: see svd3.
+// Hook: see NoHook.
 // ---------------------------------------------------------------------------------------------------------------
 MPM_DEV void jacobi_rot(float& spp, float& spq, float& sqq, float& srp, float& srq, float (&up)[3], float (&uq)[3]) {
 	const float delta = sqq - spp;

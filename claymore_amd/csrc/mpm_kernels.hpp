@@ -808,15 +808,16 @@ __global__ void grid_totals_kernel(int nblocks, const float* __restrict__ grid, 
 // ------------------------------------------------------------------------------------------------------
 // Function-level test kernels (device math vs golden vectors)
 // ------------------------------------------------------------------------------------------------------
-__global__ void test_svd_kernel(size_t n, const float* __restrict__ Fin, float* __restrict__ out21) {
+__global__ void test_eig_kernel(size_t n, const float* __restrict__ Fin, float* __restrict__ out12) {
 	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t j = i < n ? i : n - 1;// every lane runs the decomposition (its sweep count is wave-uniform)
+	float F[9], lam[3], U[9];
+	for(int d = 0; d < 9; ++d) F[d] = Fin[9 * j + d];
+	NoHook nh;
+	sym_eig3<0>(F, lam, U, nh);
 	if(i >= n) return;
-	float F[9], U[9], S[3], V[9];
-	for(int d = 0; d < 9; ++d) F[d] = Fin[9 * i + d];
-	svd3(F, U, S, V);
-	for(int d = 0; d < 9; ++d) out21[21 * i + d] = U[d];
-	for(int d = 0; d < 3; ++d) out21[21 * i + 9 + d] = S[d];
-	for(int d = 0; d < 9; ++d) out21[21 * i + 12 + d] = V[d];
+	for(int d = 0; d < 9; ++d) out12[12 * i + d] = U[d];
+	for(int d = 0; d < 3; ++d) out12[12 * i + 9 + d] = lam[d];
 }
 __global__ void test_stress_kernel(int material, MaterialConst mc, size_t n, const float* __restrict__ Fin, const float* __restrict__ ljin, float* __restrict__ out19) {
 	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;

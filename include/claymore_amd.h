@@ -214,8 +214,10 @@ int mpm_dump_grid(mpm_ctx* ctx, int* keys, float* blocks, size_t* nblocks);
 int mpm_last_g2p2g_ms(mpm_ctx* ctx, float* ms);
 
 /* ---- function-level entry points used by the parity tests (device versions of the per-particle math) ---- */
-/* math::svd (Library/MnBase/Math/Matrix/svd.cuh:27-1123): F[n*9] column-major -> out[n*21] = U(9) S(3) V(9). */
-int mpm_test_svd(const float* F, size_t n, float* out21, int device);
+/* What the constitutive models take from math::svd (Library/MnBase/Math/Matrix/svd.cuh:27-1123; they need U and the singular
+ * values only, V cancels): the eigen-decomposition F F^T = U diag(lam) U^T, lam_k = sigma_k^2, U a rotation, columns in no
+ * particular order.  F[n*9] column-major -> out[n*12] = U(9) lam(3). */
+int mpm_test_eig(const float* F, size_t n, float* out12, int device);
 /* compute_stress<M> (Projects/GMPM/constitutive_models.cuh): out19 = F'(9) PF(9) logjp'(1). */
 int mpm_test_stress(int material, const mpm_material_params* p, const float* F, const float* logjp, size_t n, float* out19, int device);
 

@@ -1290,9 +1290,21 @@ void mpmo_fn_mat(const float* a, const float* b, const float* diag, float* out36
 	memcpy(out36 + 18, e, sizeof(e));
 	orc_deviatoric(e, out36 + 27);
 }
+/* math::svd itself (oracle only: golden vector G3) */
 int mpmo_test_svd(const float* F, size_t n, float* out21, int device) {
 	(void) device;
 	for(size_t i = 0; i < n; ++i) orc_svd3(F + 9 * i, out21 + 21 * i, out21 + 21 * i + 9, out21 + 21 * i + 12);
+	return MPM_OK;
+}
+/* the C ABI's view of the same decomposition: F F^T = U diag(S^2) U^T */
+int mpmo_test_eig(const float* F, size_t n, float* out12, int device) {
+	(void) device;
+	for(size_t i = 0; i < n; ++i) {
+		float U[9], S[3], V[9];
+		orc_svd3(F + 9 * i, U, S, V);
+		memcpy(out12 + 12 * i, U, sizeof(U));
+		for(int k = 0; k < 3; ++k) out12[12 * i + 9 + k] = S[k] * S[k];
+	}
 	return MPM_OK;
 }
 int mpmo_test_stress(int material, const mpm_material_params* p, const float* Fin, const float* logjp, size_t n, float* out19, int device) {

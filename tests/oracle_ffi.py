@@ -29,4 +29,6 @@ def oracle_api():
         lib.mpmo_check_table.restype = i
         lib.mpmo_set_threads.argtypes = [C.c_void_p, i]
         lib.mpmo_set_threads.restype = i
+        lib.mpmo_test_svd.argtypes = [C.c_void_p, sz, C.c_void_p, i]    # math::svd itself: oracle only (the HIP engine has no SVD on its path)
+        lib.mpmo_test_svd.restype = i
     return _api

@@ -55,7 +55,7 @@ def test_g3_svd_bit_exact():
     F = f32("g3_F_in.f32")
     want = f32("g3_svd_out.f32")
     got = np.empty_like(want)
-    assert api.test_svd(ptr(F), F.size // 9, ptr(got), 0) == 0
+    assert api.raw.mpmo_test_svd(ptr(F), F.size // 9, ptr(got), 0) == 0
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     # and it is an SVD: U S V^T == F to fp32 accuracy
     n = F.size // 9
