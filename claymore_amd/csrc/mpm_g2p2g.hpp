@@ -93,6 +93,68 @@ struct P2GPayload {
 // x / y components and the (w, w (x_i - x_p)) weight pairs go through packed fp32.  A node is {vx, vy, vz, vz}: the
 // duplicate makes the load a full ds_read_b128 (4.0 cycles per wave against 7.1 for ds_read_b96) and gives the z
 // accumulators a natural register pair.
+#ifndef MPM_SCALAR_GS
+#define MPM_SCALAR_GS 0// A/B switch: 1 = gather / scatter arithmetic in scalar VOP2 form (v_fmac_f32) instead of packed fp32.  The launch is power-bound and a
+					   // v_pk_fma_f32 costs 2.76x the energy of a v_fmac_f32 for twice the work (profiles/r03_energy_model.txt), which predicts -4 %; measured
+					   // (profiles/r03_ab_scalar_vs_packed.txt): sand -1..-2 % (inside the run-to-run noise), fixed-corotated +3 %: +230 instructions per
+					   // iteration cost what the cheaper encodings save.  Not the default.
+#endif
+#if MPM_SCALAR_GS
+// Same tensor-product contraction, one fused multiply-add per accumulator and node component: 27 x 6 + 9 x 9 + 3 x 12 v_fmac_f32
+// (4-byte VOP2 encodings, the accumulator is the destination).
+MPM_DEV void gather_apic(const float4* __restrict__ gbase, const float (&w)[3][3], const float (&fd)[3], float (&vel)[3], float (&A)[9]) {
+	float wz1[3], wy1[3], wx1[3];// w * (node - particle) per axis and stencil offset
+#pragma unroll
+	for(int t = 0; t < 3; ++t) {
+		wx1[t] = w[0][t] * ((float) t - fd[0]);
+		wy1[t] = w[1][t] * ((float) t - fd[1]);
+		wz1[t] = w[2][t] * ((float) t - fd[2]);
+	}
+#pragma unroll
+	for(int d = 0; d < 3; ++d) vel[d] = 0.f;
+#pragma unroll
+	for(int d = 0; d < 9; ++d) A[d] = 0.f;
+#pragma unroll
+	for(int i = 0; i < 3; ++i) {
+		float u0[3] = {0.f, 0.f, 0.f}, uy[3] = {0.f, 0.f, 0.f}, uz[3] = {0.f, 0.f, 0.f};// sum_jk W_j W_k v, ... (y_j - y_p), ... (z_k - z_p)
+#pragma unroll
+		for(int j = 0; j < 3; ++j) {
+			float t0[3] = {0.f, 0.f, 0.f}, t1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+			for(int k = 0; k < 3; ++k) {
+				const float4 v	 = gbase[i * kG2PStrideX + j * kG2PStrideY + k];
+#ifndef MPM_GATHER_B96
+				__asm__ volatile("" ::"v"(v.w));// keep the load a full ds_read_b128 (4.0 cycles per wave against 7.1 for ds_read_b96)
+#endif
+				const float vc[3] = {v.x, v.y, v.z};
+#pragma unroll
+				for(int c = 0; c < 3; ++c) {
+					t0[c] = fmaf(vc[c], w[2][k], t0[c]);
+					t1[c] = fmaf(vc[c], wz1[k], t1[c]);
+				}
+			}
+			__builtin_amdgcn_sched_barrier(0);// at most one z-pencil (3 nodes) of loads in flight
+#pragma unroll
+			for(int c = 0; c < 3; ++c) {
+				u0[c] = fmaf(t0[c], w[1][j], u0[c]);
+				uy[c] = fmaf(t0[c], wy1[j], uy[c]);
+				uz[c] = fmaf(t1[c], w[1][j], uz[c]);
+			}
+		}
+#pragma unroll
+		for(int c = 0; c < 3; ++c) {
+			vel[c]	 = fmaf(u0[c], w[0][i], vel[c]);
+			A[c]	 = fmaf(u0[c], wx1[i], A[c]);	  // column 0: (x_i - x_p)
+			A[3 + c] = fmaf(uy[c], w[0][i], A[3 + c]);// column 1
+			A[6 + c] = fmaf(uz[c], w[0][i], A[6 + c]);// column 2
+		}
+	}
+#pragma unroll
+	for(int d = 0; d < 9; ++d) __asm__ volatile("" : "+v"(A[d]));
+#pragma unroll
+	for(int d = 0; d < 3; ++d) __asm__ volatile("" : "+v"(vel[d]));
+}
+#else
 MPM_DEV void gather_apic(const float4* __restrict__ gbase, const float (&w)[3][3], const float (&fd)[3], float (&vel)[3], float (&A)[9]) {
 	v2f_ wz[3], wy[3], wx[3];// {w, w * (node - particle)} per axis and stencil offset
 #pragma unroll
@@ -153,6 +215,7 @@ MPM_DEV void gather_apic(const float4* __restrict__ gbase, const float (&w)[3][3
 #pragma unroll
 	for(int d = 0; d < 3; ++d) __asm__ volatile("" : "+v"(vel[d]));
 }
+#endif
 
 // P2G of the particles the chain cannot take - lanes that lost the claim of their stencil base (another lane of the
 // iteration holds the same base) and edge lanes, whose stencil reaches cube nodes 0 or 7 (cells of the 2x2x2 grid blocks
@@ -277,6 +340,12 @@ struct ScatterChain {
 			wij			   = pw[0][i] * pw[1][j];
 		}
 		const float W  = wij * pw[2][k];
+#if MPM_SCALAR_GS
+		const float c1 = b0 + cp6[k], c2 = b12.x + cp12[k].x, c3 = b12.y + cp12[k].y;
+		if(win) {
+			const float4 out = make_float4(fmaf(mass, W, acc.x), fmaf(c1, W, acc.y), fmaf(c2, W, acc.z), fmaf(c3, W, acc.w));
+			node0[i * kP2GStrideX + j * kP2GStrideY + k] = out;
+#else
 		const v2f_ m0  = {mass, b0 + cp6[k]};
 		const v2f_ t12 = b12 + cp12[k];
 		if(win) {// (letting the other lanes run the steps on a scratch stencil instead removes 81 exec-mask instructions per iteration and is slower: +1-4 % sand, +11 % J-fluid)
@@ -285,6 +354,7 @@ struct ScatterChain {
 			a01		 = m0 * W + a01;
 			a23		 = t12 * W + a23;
 			node0[i * kP2GStrideX + j * kP2GStrideY + k] = make_float4(a01.x, a01.y, a23.x, a23.y);
+#endif
 			__asm__ volatile("" ::: "memory");
 			if(o + 1 < 27) {
 				const int i1 = (o + 1) / 9, j1 = ((o + 1) / 3) % 3, k1 = (o + 1) % 3;

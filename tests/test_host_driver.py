@@ -195,3 +195,39 @@ def test_mgsp_executable_same_device(tmp_path):
         dy = p2[:, 1].astype(np.float64).mean() - p0[:, 1].astype(np.float64).mean()
         assert abs(dy - (-0.5 * 4.9 * t * t)) < 0.03 * 0.5 * 4.9 * t * t    # free fall under -9.8 * 0.5 (settings.h:108)
         assert abs(p2[:, 0].mean() - p0[:, 0].mean()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_mgsp_executable_equals_oracle(tmp_path):
+    """The `mgsp` executable (scenario 2 of Projects/MGSP/mgsp.cu:34-81: one lattice cube per device, MGSP gravity -4.9 and CFL 0.3,
+    adaptive dt) against the single-rank CPU oracle driven through MgspBenchmark::main_loop on the union of the cubes: the frames the
+    executable writes must hold the oracle's particles within 1e-5 relative."""
+    import __graft_entry__ as g
+    from test_mgsp_gpu import _oracle_mgsp_main_loop
+    from parity_util import match
+    from claymore_amd import _ffi
+    g.build_host()
+    bits, frames, fps = 7, 2, 200
+    out = subprocess.check_output([os.path.join(HOST, "mgsp"), "--devices", "2", "--same-device", "--bits", str(bits), "--frames", str(frames),
+                                   "--fps", str(fps), "--out", str(tmp_path)], text=True)
+    steps_exe = int(out.strip().splitlines()[-1].split()[-2])
+    n = 1 << bits
+    dx = 1.0 / n
+    length, stride, o = 54 * n // 256, 56 * n // 256, 18 * n // 256        # host/mgsp.cpp scenario 2 == mgsp.cu:51-79
+    models = []
+    for d in range(2):
+        lo = (o + (stride if d & 1 else 0), o + (d >> 1) * stride, o)
+        hi = tuple(c + length for c in lo)
+        xyz = scenes.lattice_box(bits, lo, hi)
+        assert np.array_equal(np.sort(read_bgeo(tmp_path / f"model_dev[{d}]_frame[0].bgeo"), axis=0), np.sort(xyz, axis=0))   # same lattice as the executable's sampler
+        models.append({"material": _ffi.FIXED_COROTATED, "xyz": xyz, "v0": (0.0, 0.0, 0.0), "params": {"volume": float(np.float32(dx) ** 3 / np.float32(8.0))}})
+    sc = {"name": "mgsp_scenario2", "bits": bits, "dt": 1e-4, "config": {"max_ppc": 128, "gravity": -9.8 * 0.5, "cfl": 0.3}, "models": models}
+    want, steps = _oracle_mgsp_main_loop(sc, frames, fps, 1e-4)
+    assert steps == steps_exe, (steps, steps_exe)
+    for d in range(2):
+        got = read_bgeo(tmp_path / f"model_dev[{d}]_frame[{frames}].bgeo")
+        xo = want[d][0]
+        assert got.shape == xo.shape
+        idx, _ = match(xo.astype(np.float64), got.astype(np.float64))
+        rel = np.abs(got[idx].astype(np.float64) - xo).max(axis=1) / np.abs(xo).max(axis=1)
+        assert rel.max() < 1e-5, (d, rel.max())

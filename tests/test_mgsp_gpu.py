@@ -237,3 +237,52 @@ def test_cpp_group_adaptive_main_loop_matches_frames():
     for r in res:
         for m in range(2):
             assert np.isfinite(r[0][m][0]).all()
+
+
+def _oracle_mgsp_main_loop(sc, frames, fps, dt_default, threads=8):
+    """MgspBenchmark::main_loop (mgsp_benchmark.cuh:361-559) on the single-rank CPU oracle: the same adaptive loop the C++ group
+    driver runs (MGSP's compute_dt - CFL 0.3, 0.51 frame-remainder rule, Projects/MGSP/utility_funcs.hpp:32-55 - from the maximum
+    grid velocity, per-frame clock), phase by phase through the oracle's C ABI."""
+    import types
+    from claymore_amd.engine import build_engine
+    api = oracle_api()
+    eng = build_engine(sc, api=api)
+    eng.initial_setup()
+    api.raw.mpmo_set_threads(eng.ctx, threads)
+    shim = types.SimpleNamespace(eng=types.SimpleNamespace(dx=eng.dx))
+    spf = float(np.float32(1.0) / np.float32(fps))
+    nd = MgspRank.compute_dt_mgsp(shim, 0.0, 0.0, spf, dt_default)
+    steps = 0
+    for _ in range(frames):
+        t = np.float32(0.0)
+        while t < np.float32(spf):
+            dt = nd
+            assert dt > 0.0
+            mv = float(np.sqrt(np.float32(eng.grid_update(dt))))
+            nd = MgspRank.compute_dt_mgsp(shim, mv, float(np.float32(t + np.float32(dt))), spf, dt_default)
+            if not nd > 0.0:
+                nd = MgspRank.compute_dt_mgsp(shim, mv, 0.0, spf, dt_default)
+            eng.g2p2g(dt, nd)
+            eng.rebuild_partition()
+            t = np.float32(t + np.float32(dt))
+            steps += 1
+    state = [eng.retrieve_state(m) for m in range(len(sc["models"]))]
+    eng.close()
+    return state, steps
+
+
+def test_cpp_group_adaptive_main_loop_equals_oracle():
+    """mpm_group_main_loop (adaptive dt from the maximum velocity over all ranks, CFL 0.3 / 0.51 rule, per-frame clock) against the
+    oracle driven through the same loop: same number of substeps, positions within 1e-5 relative."""
+    sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=0.5, speed=2.0, youngs=2e4)
+    frames, fps, dt_default = 2, 240, 1e-4
+    res = _run_group_threads(sc, 2, 0, 0.0, adaptive=(frames, fps, dt_default))
+    want, steps = _oracle_mgsp_main_loop(sc, frames, fps, dt_default)
+    assert [r[3] for r in res] == [steps, steps], ([r[3] for r in res], steps)
+    for m in range(len(sc["models"])):
+        xm = np.concatenate([r[0][m][0] for r in res])
+        xo = want[m][0]
+        assert xm.shape == xo.shape
+        idx, _ = match(xo.astype(np.float64), xm.astype(np.float64))
+        rel = np.abs(xm[idx].astype(np.float64) - xo).max(axis=1) / np.abs(xo).max(axis=1)
+        assert rel.max() < 1e-5, rel.max()
