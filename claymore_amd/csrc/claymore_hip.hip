@@ -613,6 +613,12 @@ static int launch_clear(mpm_ctx* ctx, int flags) {
 	a.old_table	   = Pn.table;
 	a.old_keys	   = Pn.keys;
 	a.old_count	   = Pn.count;
+	if((flags & kClearRebuild) && ctx->d_overlap) {// MGSP: the tagging that follows the rebuild starts from cleared marks and counters
+		a.overlap		= ctx->d_overlap;
+		a.overlap_n		= ctx->g.cap + 1;
+		a.halo_counts	= ctx->d_halo_counts;
+		a.halo_counts_n = 2 + 32;
+	}
 	substep_clear_kernel<<<1024, 256, 0, ctx->s_compute>>>(ctx->g, a);
 	return MPM_OK;
 }

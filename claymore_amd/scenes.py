@@ -62,6 +62,19 @@ def two_spheres(bits=7, radius_cells=9.0, gap_cells=None, speed=0.5, material=FI
     }
 
 
+def two_spheres_c4(bits=9, radius_cells=84.0, speed=1.0):
+    """C4 (BASELINE config 4): two fixed-corotated spheres of R = 84 dx on a 512^3 grid, centres (0.30, 0.5, 0.5) / (0.70, 0.5, 0.5),
+    approaching each other at +-1 m/s: 2 x 19.9 M particles; run as MGSP with 4 ranks (static particle partition, two slabs per sphere)."""
+    prm = {"volume": _vol(bits), "youngs_modulus": 5e3, "poisson_ratio": 0.4, "rho": 1e3}
+    return {
+        "name": "two_spheres_c4", "bits": bits, "dt": 1e-4, "config": {"max_ppc": 128},
+        "models": [
+            {"material": FIXED_COROTATED, "xyz": lattice_sphere(bits, (0.30, 0.5, 0.5), radius_cells), "v0": (speed, 0.0, 0.0), "params": dict(prm)},
+            {"material": FIXED_COROTATED, "xyz": lattice_sphere(bits, (0.70, 0.5, 0.5), radius_cells), "v0": (-speed, 0.0, 0.0), "params": dict(prm)},
+        ],
+    }
+
+
 def sphere_drop(bits=8, radius_cells=53.0, center=(0.5, 0.6, 0.5), material=FIXED_COROTATED):
     """C2: one elastic sphere dropped under gravity (~5.0 M particles at bits 8, R = 53 dx)."""
     prm = {"volume": _vol(bits)} if material != SAND else {}

@@ -286,3 +286,56 @@ def test_cpp_group_adaptive_main_loop_equals_oracle():
         idx, _ = match(xo.astype(np.float64), xm.astype(np.float64))
         rel = np.abs(xm[idx].astype(np.float64) - xo).max(axis=1) / np.abs(xo).max(axis=1)
         assert rel.max() < 1e-5, rel.max()
+
+
+def test_full_size_c4_two_spheres_4_ranks():
+    """BASELINE config 4 at size: two fixed-corotated spheres of R = 84 dx (2 x 19.9 M particles) on the 512^3 grid, MGSP static
+    particle partition over 4 ranks - here 4 engine contexts on the one GPU, the C++ group driver on its in-process transport.
+    20 substeps; every particle accounted for on its rank, nothing lost or discarded, halo blocks exchanged, and the spheres move
+    as free bodies do (they do not touch yet): x by +-1 m/s, y by g t^2 / 2."""
+    sc = scenes.two_spheres_c4()
+    n_models = [m["xyz"].shape[0] for m in sc["models"]]
+    assert 19.5e6 < n_models[0] < 20.5e6 and n_models[0] == n_models[1]
+    world, nsteps, dt = 4, 20, 1e-4
+    lg = LocalGroup(world)
+    ranks = [MgspGroupRank(sc, r, world, device=0, local_group=lg) for r in range(world)]
+    x0 = [m["xyz"][:, :2].astype(np.float64).mean(axis=0) for m in sc["models"]]
+    del sc
+    lg.create()
+    out, errors = [None] * world, []
+
+    def work(r):
+        try:
+            sim = ranks[r]
+            sim.initial_setup()
+            sim.run_fixed(nsteps, dt)
+            c, d = sim.eng.counts(), sim.eng.diagnostics()
+            sums = []
+            for m in range(2):
+                x = sim.eng.retrieve_positions(m)
+                assert np.isfinite(x).all()
+                sums.append((x.shape[0], x[:, :2].astype(np.float64).sum(axis=0)))
+            out[r] = dict(particles=[int(c.particles[m]) for m in range(2)], lost=int(d.lost_particles), disc=int(d.discarded_p2g),
+                          sent=sum(sim.send_counts), halo=sim.n_halo_blocks, n_local=sim.n_local, sums=sums)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=900)
+    for r in ranks:
+        r.close()
+    assert not errors, errors
+    assert sum(o["lost"] for o in out) == 0 and sum(o["disc"] for o in out) == 0
+    assert all(sum(o["particles"]) == o["n_local"] for o in out)
+    assert min(o["sent"] for o in out) > 0 and min(o["halo"] for o in out) > 0      # every rank shares a slab interface
+    t = nsteps * dt
+    for m, sign in ((0, 1.0), (1, -1.0)):
+        n = sum(o["sums"][m][0] for o in out)
+        assert n == n_models[m]
+        mean = sum(o["sums"][m][1] for o in out) / n
+        assert abs((mean[0] - x0[m][0]) - sign * 1.0 * t) < 2e-2 * t                 # x: +-1 m/s
+        fall = -9.8 * dt * dt * nsteps * (nsteps + 1) / 2                              # symplectic Euler: v_k = -g k dt, x += v_k dt
+        assert abs((mean[1] - x0[m][1]) - fall) < 5e-2 * abs(fall) + 1e-7

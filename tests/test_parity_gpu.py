@@ -362,6 +362,33 @@ def test_fuzz_parity():
         assert (ch.particle_blocks, ch.neighbor_blocks, ch.exterior_blocks) == (co.particle_blocks, co.neighbor_blocks, co.exterior_blocks), case
 
 
+def test_fuzz_parity_violent_tier():
+    """The same generator with bodies up to 6 m/s and up to 300 substeps (J-fluid / fixed-corotated / sand).  In this tier 1e-5 does
+    not hold everywhere - and the reason is a fact, not noise: a free-flying lattice body sits within 0.003 ulp of a rounding tie in
+    x + v dt, which the two engines' gathered velocities (3e-7 apart: summation order) resolve in opposite directions at EVERY substep
+    (tools/fuzz_tie_probe.py, profiles/r02_fuzz_parity.txt), so the distance grows linearly, by at most one ulp of the position per
+    substep.  Asserted here: (1) that growth bound - |dx| <= one ulp of the [0.5, 1) binade per substep -, (2) 2.5e-5 relative for
+    every case, (3) block counts equal, (4) at most a sixth of the cases above 1e-5 (6 of 200 in the long fuzz)."""
+    from fuzz_scenes import random_scene
+    rng = np.random.default_rng(7)
+    ulp = 2.0 ** -24                      # spacing of float32 in [0.5, 1) is 2^-23: positions live in (0, 1)
+    above = 0
+    ncases = 24
+    for case in range(ncases):
+        sc, nsteps = random_scene(rng, case, 6.0, 300, (_ffi.J_FLUID, _ffi.FIXED_COROTATED, _ffi.SAND))
+        res = run_pair(sc, nsteps)
+        co, ch = res["oracle"]["counts"], res["hip"]["counts"]
+        n_in = [m["xyz"].shape[0] for m in sc["models"]]
+        if any(co.particles[i] < n_in[i] for i in range(len(n_in))):
+            continue                      # the ORACLE dropped particles (the reference's per-cell capacity): nothing to compare against
+        w = match_and_compare(res)
+        assert w["pos_abs"] <= 2 * ulp * nsteps + 2e-6, (case, nsteps, w)          # <= 1 ulp (2^-23) per substep
+        assert w["pos_rel"] < 2.5e-5, (case, nsteps, w)
+        assert (ch.particle_blocks, ch.neighbor_blocks, ch.exterior_blocks) == (co.particle_blocks, co.neighbor_blocks, co.exterior_blocks), case
+        above += w["pos_rel"] >= 1e-5
+    assert above <= ncases // 6, above
+
+
 def test_runtime_overflow_error_or_drop():
     """A block that receives more particles than it has list slots (max_ppc * 64): MPM_ERR_CAPACITY by default; with
     mpm_config.drop_overflow the surplus is dropped and counted - what the reference does silently and per cell
