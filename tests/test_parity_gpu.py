@@ -16,6 +16,31 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 POS_TOL = 1e-5
 
 
+def oracle_api_threads(threads):
+    """The oracle with OpenMP over particle blocks in its G2P2G (test infrastructure: large cases only)."""
+    from oracle_ffi import oracle_api
+    api = oracle_api()
+    return _ThreadedApi(api, threads)
+
+
+class _ThreadedApi:
+    """Forwards to the oracle's Api; sets the thread count right after initial_setup (the oracle's contexts start serial)."""
+
+    def __init__(self, api, threads):
+        self._api, self._threads = api, threads
+
+    def __getattr__(self, name):
+        fn = getattr(self._api, name)
+        if name != "initial_setup":
+            return fn
+
+        def wrapped(ctx):
+            rc = fn(ctx)
+            self._api.raw.mpmo_set_threads(ctx, self._threads)
+            return rc
+        return wrapped
+
+
 def f32(name):
     return np.fromfile(os.path.join(G, name), dtype=np.float32)
 
@@ -261,6 +286,43 @@ def test_full_size_invariants_5m():
     t = steps * dt
     assert abs(xyz[:, 1].astype(np.float64).mean() - (y0 - 0.5 * 9.8 * t * t)) < 2e-6
     eng.close()
+
+
+def _lattice_order(x, bits):
+    """Order of the particles by the lattice site they started from (site spacing dx / 2): unique while they have moved less than dx / 4."""
+    q = np.rint(x.astype(np.float64) * (1 << (bits + 2))).astype(np.int64)      # units of dx / 4: sites sit at odd multiples
+    key = (q[:, 0] << 42) | (q[:, 1] << 21) | q[:, 2]
+    assert np.unique(key).size == key.size
+    return np.argsort(key, kind="stable")
+
+
+def test_full_size_c2_parity_with_contact_5m():
+    """C2 at size against the ORACLE, not only invariants: the 5 M-particle fixed-corotated sphere (R = 53 dx, 256^3) placed so that its
+    lowest layers sit in the floor's wall zone - the grid update zeroes their velocity from the first substep on, a stress wave runs up
+    the sphere - 12 substeps on both engines, particles matched by the lattice site they started from: positions within 1e-5 relative,
+    F within 1e-4 (the test_parity bound), block counts equal."""
+    bits = 8
+    sc = scenes.sphere_drop(bits=bits, radius_cells=53.0, center=(0.5, (53.0 + 6.5) / 256.0, 0.5))
+    sc["models"][0]["v0"] = (0.0, -0.5, 0.0)                 # thrown at the floor: 5e-5 per substep = 1.3 % of a cell (0.15 dx in all)
+    n = scenes.total_particles(sc)
+    assert n > 4.9e6
+    nsteps, dt = 12, 1e-4
+    hip = run_engine(sc, nsteps, dt)
+    api = oracle_api_threads(32)
+    ora = run_engine(sc, nsteps, dt, api=api)
+    xh, fh, _ = hip["state"][0]
+    xo, fo, _ = ora["state"][0]
+    assert xh.shape == xo.shape == (n, 3)
+    # both engines moved every particle by < dx / 4 from its site: undo the (common) rigid part before snapping to sites
+    shift = np.array([0.0, -0.5 * nsteps * dt, 0.0])
+    oh, oo = _lattice_order(xh - shift, bits), _lattice_order(xo - shift, bits)
+    dx = np.abs(xh[oh].astype(np.float64) - xo[oo].astype(np.float64)).max(axis=1)
+    rel = dx / np.abs(xo[oo]).max(axis=1)
+    assert rel.max() < POS_TOL, rel.max()
+    assert np.abs(fh[oh] - fo[oo]).max() < 1e-4
+    assert np.abs(fo - np.eye(3, dtype=np.float32).T.reshape(1, 9)).max() > 1e-3        # the contact really deformed something
+    ch, co = hip["counts"], ora["counts"]
+    assert (ch.particle_blocks, ch.neighbor_blocks, ch.exterior_blocks) == (co.particle_blocks, co.neighbor_blocks, co.exterior_blocks)
 
 
 def test_full_size_invariants_c5_rank_share_12m():
