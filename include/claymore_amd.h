@@ -143,7 +143,10 @@ int mpm_rebuild_partition(mpm_ctx* ctx, mpm_counts* counts);
 /* One whole substep = grid update, host dt, g2p2g, rebuild (the body of the loop gmpm_simulator.cuh:324-580).
  * dt is the current step; *next_dt = compute_dt(sqrt(max|v|^2), step_time, frame_time, dt_default). */
 int mpm_substep(mpm_ctx* ctx, float dt, float step_time, float frame_time, float dt_default, float* next_dt, float* max_vel);
-/* Convenience for benchmarking: n substeps with a fixed dt (next_dt = dt), no host dt logic in between. */
+/* n substeps with a fixed dt (next_dt = dt): the loop of gmpm_simulator.cuh:324-580 without its host logic.  The substeps are enqueued
+ * mpm_config.sync_interval at a time; between two host synchronisations every kernel reads its block counts from device memory.  A capacity
+ * overflow or a non-finite velocity raised inside a window is reported when the window ends (the context is then in an undefined state, as
+ * after any error of a run: load a checkpoint or destroy it).  Timers: per-substep averages over the call. */
 int mpm_run_fixed(mpm_ctx* ctx, int nsteps, float dt);
 
 /* output_model (gmpm_simulator.cuh:594-634; kernel mgmpm_kernels.cuh:1087-1122): positions of a model, order
