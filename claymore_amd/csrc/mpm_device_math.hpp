@@ -170,28 +170,36 @@ MPM_DEV void sym_eig3(const float (&F)[9], float (&lam)[3], float (&U)[9], Hook&
 	MPM_MARK("eig_jacobi");
 	hk.template at<BASE + 0>();
 	// The convergence test runs BEFORE every sweep (the first one included: a particle in free fall or rigid translation
-	// has b diagonal already, and a whole wave of them skips the rotations altogether), not after the last one.
-	bool done;
+	// has b diagonal already, and a whole wave of them skips the rotations altogether), not after the last one.  `conv` is the lane's
+	// own verdict, `done` the wave's: a sweep runs while any lane needs it (scalar branch), but only the lanes that need it rotate
+	// (exec mask), so the number of sweeps a particle gets - and with it its result - depends on the particle alone, not on the other
+	// 63 lanes of its wave (i.e. not on the sort order, the block numbering or the partitioning of an MGSP run).
+	bool done, conv;
 #define MPM_CONVERGED()                                                                 \
 	{                                                                                   \
 		const float off = fmaxf(fmaxf(fabsf(s21), fabsf(s31)), fabsf(s32));             \
 		const float dia = fminf(fminf(fabsf(s11), fabsf(s22)), fabsf(s33));             \
-		done			= __all(off <= MPM_EIG_TOL * dia);                               \
+		conv			= off <= MPM_EIG_TOL * dia;                                     \
+		done			= __all(conv);                                                  \
 	}
 #define MPM_SWEEP(IT, LAST)                                                    \
-	if(!done) jacobi_rot(s11, s21, s22, s31, s32, u1, u2);                     \
+	if(!done) {                                                                \
+		if(!conv) jacobi_rot(s11, s21, s22, s31, s32, u1, u2);                 \
+	}                                                                          \
 	hk.template at<BASE + 1 + 3 * IT>();                                       \
-	if(!done) jacobi_rot(s22, s32, s33, s21, s31, u2, u3);                     \
+	if(!done) {                                                                \
+		if(!conv) jacobi_rot(s22, s32, s33, s21, s31, u2, u3);                 \
+	}                                                                          \
 	hk.template at<BASE + 2 + 3 * IT>();                                       \
 	if(!done) {                                                                \
-		jacobi_rot(s33, s31, s11, s32, s21, u3, u1);                           \
+		if(!conv) jacobi_rot(s33, s31, s11, s32, s21, u3, u1);                 \
 		if(!(LAST)) MPM_CONVERGED()                                            \
 	}                                                                          \
 	hk.template at<BASE + 3 + 3 * IT>();
 #if MPM_EIG_PRECHECK
 	MPM_CONVERGED()
 #else
-	done = false;
+	done = conv = false;
 #endif
 	MPM_SWEEP(0, false)
 	MPM_SWEEP(1, false)

@@ -339,3 +339,25 @@ def test_full_size_c4_two_spheres_4_ranks():
         assert abs((mean[0] - x0[m][0]) - sign * 1.0 * t) < 2e-2 * t                 # x: +-1 m/s
         fall = -9.8 * dt * dt * nsteps * (nsteps + 1) / 2                              # symplectic Euler: v_k = -g k dt, x += v_k dt
         assert abs((mean[1] - x0[m][1]) - fall) < 5e-2 * abs(fall) + 1e-7
+
+
+@pytest.mark.parametrize("material", [_ffi.SAND, _ffi.FIXED_COROTATED])
+def test_cpp_group_equals_single_engine(material):
+    """N ranks against ONE rank of the same engine: the static particle partition changes block numbering, sort order and the
+    order of the float additions on shared grid blocks, and nothing else - every per-particle decision (Jacobi sweeps included: the
+    convergence mask is per lane) depends on the particle alone.  150 substeps of two colliding bodies, 2 and 3 ranks: positions within
+    1e-6 relative of the single-engine run (measured 2-3e-7, i.e. float-atomic noise; tools/nrank_vs_one.py)."""
+    sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=0.5, speed=2.0, youngs=2e4, material=material)
+    if material == _ffi.SAND:
+        for m in sc["models"]:
+            m["params"] = {}
+    nsteps = 150
+    one = run_engine(sc, nsteps, 1e-4)
+    for world in (2, 3):
+        res = _run_group_threads(sc, world, nsteps, 1e-4, fixed=True)
+        for m in range(len(sc["models"])):
+            xm = np.concatenate([r[0][m][0] for r in res])
+            xo = one["state"][m][0]
+            idx, _ = match(xo.astype(np.float64), xm.astype(np.float64))
+            rel = np.abs(xm[idx].astype(np.float64) - xo).max(axis=1) / np.abs(xo).max(axis=1)
+            assert rel.max() < 1e-6, (world, m, rel.max())
