@@ -152,12 +152,19 @@ MPM_DEV void jacobi_rot(float& spp, float& spq, float& sqq, float& srp, float& s
 #ifndef MPM_EIG_TOL
 #define MPM_EIG_TOL 1e-6f// sweeps stop once every off-diagonal entry of every lane is below this fraction of the smallest diagonal entry
 #endif
+#ifndef MPM_UNDEFORMED_EXIT
+#define MPM_UNDEFORMED_EXIT 1// A/B switch: 0 = the stress of an undeformed wave (F F^T = I) is computed like any other
+#endif
 #ifndef MPM_EIG_PRECHECK
 #define MPM_EIG_PRECHECK 1// A/B switch: 0 = always run the first sweep (round 2)
 #endif
 constexpr int kEigSites = 13;
+// undeformed (wave-uniform, out): F F^T is the identity for every lane of the wave - diagonal exactly 1, off-diagonals below the
+// tolerance - and F is a proper rotation near the identity (diagonal entries > 1/2, i.e. trace > 3/2: no reflection has that).  Such a
+// particle (free fall, rigid translation: the default window of the C3 bench) has zero stress in every model on this path, exactly,
+// and no plastic update: the stress functions return early.
 template<int BASE, class Hook>
-MPM_DEV void sym_eig3(const float (&F)[9], float (&lam)[3], float (&U)[9], Hook& hk) {
+MPM_DEV void sym_eig3(const float (&F)[9], float (&lam)[3], float (&U)[9], Hook& hk, bool& undeformed) {
 	// b = F F^T (column-major F: F[3 j + i] = F_ij)
 	const v2f_ f01 = {F[0], F[1]}, f34 = {F[3], F[4]}, f67 = {F[6], F[7]};
 	const v2f_ f12 = {F[1], F[2]}, f45 = {F[4], F[5]}, f78 = {F[7], F[8]};
@@ -196,8 +203,12 @@ MPM_DEV void sym_eig3(const float (&F)[9], float (&lam)[3], float (&U)[9], Hook&
 		if(!(LAST)) MPM_CONVERGED()                                            \
 	}                                                                          \
 	hk.template at<BASE + 3 + 3 * IT>();
+	undeformed = false;
 #if MPM_EIG_PRECHECK
 	MPM_CONVERGED()
+#if MPM_UNDEFORMED_EXIT
+	if(done) undeformed = __all((s11 == 1.f) & (s22 == 1.f) & (s33 == 1.f) & (F[0] > 0.5f) & (F[4] > 0.5f) & (F[8] > 0.5f));
+#endif
 #else
 	done = conv = false;
 #endif
@@ -318,7 +329,14 @@ constexpr int kFcSites = kEigSites + 1;
 template<int BASE, class Hook>
 MPM_DEV void stress_fixed_corotated(const MaterialConst& mc, const float (&F)[9], float (&PF)[9], Hook& hk) {
 	float lam[3], U[9];
-	sym_eig3<BASE>(F, lam, U, hk);
+	bool undeformed;
+	sym_eig3<BASE>(F, lam, U, hk, undeformed);
+	if(undeformed) {// sigma_k = 1, J = 1: P F^T = 0 exactly
+#pragma unroll
+		for(int d = 0; d < 9; ++d) PF[d] = 0.f;
+		hk.template at<BASE + kEigSites>();
+		return;
+	}
 	if(ill_conditioned(lam)) refine_eigs(F, U, lam);
 	float sig[3];
 #pragma unroll
@@ -350,58 +368,66 @@ constexpr int kSandSites = kEigSites + 3;
 template<int BASE, class Hook>
 MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9], Hook& hk, float* __restrict__ Fdst = nullptr, int Fstride = 0) {
 	float lam[3], U[9];
-	sym_eig3<BASE>(F, lam, U, hk);
-	const bool ill = ill_conditioned(lam);
-	if(ill) refine_eigs(F, U, lam);
+	bool undeformed;
+	sym_eig3<BASE>(F, lam, U, hk, undeformed);
+	// undeformed, no cohesion, log Jp >= 0: ln sigma = 0 sits at the cone tip with zero strain (:282-289): F and log Jp stay, P F^T = 0.
+	// (The three parts are skipped in place, around the hook sites, so that every site exists once in the code.)
+	const bool skip = undeformed && mc.cohesion == 0.f && __all(log_jp >= 0.f);
 	const float scaled_mu = 2.0f * mc.mu;
-	float lns[3], epsilon[3];
+	bool ill = false;
+	float lns[3], epsilon[3], epsilon_hat[3], dl[3], lnS[3];
+	float sum_epsilon = 0.f, trace_epsilon = 0.f, epsilon_hat_norm = 0.f;
+	if(!skip) {
+		ill = ill_conditioned(lam);
+		if(ill) refine_eigs(F, U, lam);
 #pragma unroll
-	for(int i = 0; i < 3; i++) {
-		lns[i]	   = 0.5f * log_fast(fmaxf(lam[i], 1e-8f));// ln max(|S|, 1e-4) (:262)
-		epsilon[i] = lns[i] - mc.cohesion;
-	}
-	const float sum_epsilon	  = epsilon[0] + epsilon[1] + epsilon[2];
-	const float trace_epsilon = sum_epsilon + log_jp;
-	float epsilon_hat[3];
-#pragma unroll
-	for(int i = 0; i < 3; i++) epsilon_hat[i] = epsilon[i] - (trace_epsilon * (1.0f / 3.0f));
-	const float epsilon_hat_norm = __builtin_amdgcn_sqrtf(epsilon_hat[0] * epsilon_hat[0] + epsilon_hat[1] * epsilon_hat[1] + epsilon_hat[2] * epsilon_hat[2]);
-	hk.template at<BASE + kEigSites>();
-	// Return mapping without divergent branches (the three cases of :282-316 as selects; a wave of sand particles usually
-	// holds all of them): dl = ln S_new - ln sigma is -epsilon at the cone tip (case II), -r epsilon_hat with
-	// r = max(delta_gamma, 0) / |epsilon_hat| otherwise (case III; r = 0 is case I, inside the cone).
-	const bool tip	= trace_epsilon >= 0.0f;
-	const bool dead = !tip && mc.mu == 0.f;// reference: logf(0) when mu == 0 (:298-300): P is NaN, F is left as it is
-	const float delta_gamma = epsilon_hat_norm + (3.0f * mc.lambda + scaled_mu) * rcp_fast(scaled_mu) * trace_epsilon * mc.yield_surface;
-	const float r			= fmaxf(delta_gamma, 0.f) * rcp_fast(fmaxf(epsilon_hat_norm, 1e-30f));
-	float dl[3], lnS[3];
-#pragma unroll
-	for(int i = 0; i < 3; i++) {
-		dl[i]  = tip ? -epsilon[i] : -r * epsilon_hat[i];
-		lnS[i] = dead ? -__builtin_inff() : lns[i] + dl[i];
-	}
-	log_jp = tip ? (mc.volume_correction ? mc.beta * sum_epsilon + log_jp : log_jp) : (dead ? log_jp : 0.f);
-	// The projected F = U diag(exp(dl)) U^T F.  While every particle of the wave is inside the cone (dl = 0: elastic, the
-	// state of a column at rest) the factor is the identity and the rebuild is skipped for the whole wave; the reference
-	// rebuilds U S V^T there too, which only adds its rounding.  Reflected or collapsed F (rare) goes through V, as the
-	// reference's does, whether the strain changed or not (the rebuild removes the reflection).
-	const bool odd	   = !dead && (ill || !(det3(F) > 0.f));
-	// (dl == 0 exactly: inside the cone, or at the tip with zero strain - free fall; exp(0) = 1 would only add the rounding of U U^T)
-	const bool changed = !dead && !odd && ((dl[0] != 0.f) | (dl[1] != 0.f) | (dl[2] != 0.f));
-	if(__any(changed)) {
-		if(changed) {
-			float ratio[3];
-#pragma unroll
-			for(int i = 0; i < 3; i++) ratio[i] = exp_fast(dl[i]);
-			rescale_principal(F, U, ratio);
+		for(int i = 0; i < 3; i++) {
+			lns[i]	   = 0.5f * log_fast(fmaxf(lam[i], 1e-8f));// ln max(|S|, 1e-4) (:262)
+			epsilon[i] = lns[i] - mc.cohesion;
 		}
-	}
-	if(__any(odd)) {
-		if(odd) {
-			float Sn[3];
+		sum_epsilon	  = epsilon[0] + epsilon[1] + epsilon[2];
+		trace_epsilon = sum_epsilon + log_jp;
 #pragma unroll
-			for(int i = 0; i < 3; i++) Sn[i] = exp_fast(lnS[i]);
-			rebuild_through_v(F, U, lam, Sn);
+		for(int i = 0; i < 3; i++) epsilon_hat[i] = epsilon[i] - (trace_epsilon * (1.0f / 3.0f));
+		epsilon_hat_norm = __builtin_amdgcn_sqrtf(epsilon_hat[0] * epsilon_hat[0] + epsilon_hat[1] * epsilon_hat[1] + epsilon_hat[2] * epsilon_hat[2]);
+	}
+	hk.template at<BASE + kEigSites>();
+	if(!skip) {
+		// Return mapping without divergent branches (the three cases of :282-316 as selects; a wave of sand particles usually
+		// holds all of them): dl = ln S_new - ln sigma is -epsilon at the cone tip (case II), -r epsilon_hat with
+		// r = max(delta_gamma, 0) / |epsilon_hat| otherwise (case III; r = 0 is case I, inside the cone).
+		const bool tip	= trace_epsilon >= 0.0f;
+		const bool dead = !tip && mc.mu == 0.f;// reference: logf(0) when mu == 0 (:298-300): P is NaN, F is left as it is
+		const float delta_gamma = epsilon_hat_norm + (3.0f * mc.lambda + scaled_mu) * rcp_fast(scaled_mu) * trace_epsilon * mc.yield_surface;
+		const float r			= fmaxf(delta_gamma, 0.f) * rcp_fast(fmaxf(epsilon_hat_norm, 1e-30f));
+#pragma unroll
+		for(int i = 0; i < 3; i++) {
+			dl[i]  = tip ? -epsilon[i] : -r * epsilon_hat[i];
+			lnS[i] = dead ? -__builtin_inff() : lns[i] + dl[i];
+		}
+		log_jp = tip ? (mc.volume_correction ? mc.beta * sum_epsilon + log_jp : log_jp) : (dead ? log_jp : 0.f);
+		// The projected F = U diag(exp(dl)) U^T F.  While every particle of the wave is inside the cone (dl = 0: elastic, the
+		// state of a column at rest) the factor is the identity and the rebuild is skipped for the whole wave; the reference
+		// rebuilds U S V^T there too, which only adds its rounding.  Reflected or collapsed F (rare) goes through V, as the
+		// reference's does, whether the strain changed or not (the rebuild removes the reflection).
+		const bool odd	   = !dead && (ill || !(det3(F) > 0.f));
+		// (dl == 0 exactly: inside the cone, or at the tip with zero strain - free fall; exp(0) = 1 would only add the rounding of U U^T)
+		const bool changed = !dead && !odd && ((dl[0] != 0.f) | (dl[1] != 0.f) | (dl[2] != 0.f));
+		if(__any(changed)) {
+			if(changed) {
+				float ratio[3];
+#pragma unroll
+				for(int i = 0; i < 3; i++) ratio[i] = exp_fast(dl[i]);
+				rescale_principal(F, U, ratio);
+			}
+		}
+		if(__any(odd)) {
+			if(odd) {
+				float Sn[3];
+#pragma unroll
+				for(int i = 0; i < 3; i++) Sn[i] = exp_fast(lnS[i]);
+				rebuild_through_v(F, U, lam, Sn);
+			}
 		}
 	}
 	hk.template at<BASE + kEigSites + 1>();
@@ -409,12 +435,15 @@ MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, 
 #pragma unroll
 		for(int d = 0; d < 9; ++d) Fdst[d * Fstride] = F[d];
 	}
-	{
+	if(!skip) {
 		const float trace_log_S = lnS[0] + lnS[1] + lnS[2];
 		float d[3];
 #pragma unroll
 		for(int k = 0; k < 3; ++k) d[k] = (scaled_mu * lnS[k] + mc.lambda * trace_log_S) * mc.volume;
 		sym_from_eig(U, d, PF);
+	} else {
+#pragma unroll
+		for(int d = 0; d < 9; ++d) PF[d] = 0.f;
 	}
 	hk.template at<BASE + kEigSites + 2>();
 }
@@ -431,85 +460,97 @@ constexpr int kNaccSites = kEigSites + 2;
 template<int BASE, class Hook>
 MPM_DEV void stress_nacc(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9], Hook& hk) {
 	float lam[3], U[9];
-	sym_eig3<BASE>(F, lam, U, hk);
-	const bool ill = ill_conditioned(lam);
-	if(ill) refine_eigs(F, U, lam);
+	bool undeformed;
+	sym_eig3<BASE>(F, lam, U, hk, undeformed);
+	// undeformed: p_trial = 0 lies strictly inside (p_min, p0) and y < 0 (:113-151): no projection, no hardening; dev(b) = 0, J = 1: P F^T = 0.
+	// (The two parts are skipped in place, around the hook site, so that every site exists once in the code.)
+	const bool skip = undeformed && mc.bm > 0.f && mc.beta > 0.f;
 	const float bm = mc.bm;
-	const float ex = exp_fast(mc.xi * fmaxf(-log_jp, 0.f));
-	const float p0 = bm * (0.00001f + 0.5f * (ex - rcp_fast(ex)));// sinh
-	const float p_min = -mc.beta * p0;
-	const float detF	 = det3(F);
-	const float lg2J	 = 0.5f * __builtin_amdgcn_logf(lam[0] * lam[1] * lam[2]);// log2 |Je_trial|
-	const float Je_abs	 = __builtin_amdgcn_exp2f(lg2J);
-	const float Je_trial = detF < 0.f ? -Je_abs : Je_abs;
-	const float trB3	 = (lam[0] + lam[1] + lam[2]) * (1.f / 3.f);
-	// a reflected F makes the reference's powf(Je_trial, -2/3) NaN (:96); the same happens here through the sign of Je
-	const float Jm23mu = detF < 0.f ? __builtin_nanf("") : mc.mu * __builtin_amdgcn_exp2f(lg2J * (-2.f / 3.f));
-	const float sh0 = Jm23mu * (lam[0] - trB3), sh1 = Jm23mu * (lam[1] - trB3), sh2 = Jm23mu * (lam[2] - trB3);
-	const float p_trial		   = -bm * 0.5f * (Je_trial - rcp_fast(Je_trial)) * Je_trial;
-	const float y_s_half_coeff = 1.5f * (1.f + 2.f * mc.beta);
-	const float y_p_half	   = mc.msqr * (p_trial - p_min) * (p_trial - p0);
-	const float s_sqrnorm	   = sh0 * sh0 + sh1 * sh1 + sh2 * sh2;
-	const float y			   = y_s_half_coeff * s_sqrnorm + y_p_half;
+	bool ill = false, rebuild = false;
+	float p0 = 0.f, p_min = 0.f, detF = 1.f, lg2J = 0.f, trB3 = 0.f, sh0 = 0.f, sh1 = 0.f, sh2 = 0.f, p_trial = 0.f, y_s_half_coeff = 0.f, y_p_half = 0.f, s_sqrnorm = 0.f, y = 0.f;
 	float Bn[3] = {lam[0], lam[1], lam[2]};// new squared stretches
-	bool rebuild = false;
+	if(!skip) {
+		ill = ill_conditioned(lam);
+		if(ill) refine_eigs(F, U, lam);
+		const float ex = exp_fast(mc.xi * fmaxf(-log_jp, 0.f));
+		p0 = bm * (0.00001f + 0.5f * (ex - rcp_fast(ex)));// sinh
+		p_min = -mc.beta * p0;
+		detF	 = det3(F);
+		lg2J	 = 0.5f * __builtin_amdgcn_logf(lam[0] * lam[1] * lam[2]);// log2 |Je_trial|
+		const float Je_abs	 = __builtin_amdgcn_exp2f(lg2J);
+		const float Je_trial = detF < 0.f ? -Je_abs : Je_abs;
+		trB3	 = (lam[0] + lam[1] + lam[2]) * (1.f / 3.f);
+		// a reflected F makes the reference's powf(Je_trial, -2/3) NaN (:96); the same happens here through the sign of Je
+		const float Jm23mu = detF < 0.f ? __builtin_nanf("") : mc.mu * __builtin_amdgcn_exp2f(lg2J * (-2.f / 3.f));
+		sh0 = Jm23mu * (lam[0] - trB3), sh1 = Jm23mu * (lam[1] - trB3), sh2 = Jm23mu * (lam[2] - trB3);
+		p_trial		   = -bm * 0.5f * (Je_trial - rcp_fast(Je_trial)) * Je_trial;
+		y_s_half_coeff = 1.5f * (1.f + 2.f * mc.beta);
+		y_p_half	   = mc.msqr * (p_trial - p_min) * (p_trial - p0);
+		s_sqrnorm	   = sh0 * sh0 + sh1 * sh1 + sh2 * sh2;
+		y			   = y_s_half_coeff * s_sqrnorm + y_p_half;
+	}
 	hk.template at<BASE + kEigSites>();
-	if(p_trial > p0 || p_trial < p_min) {// cases 1, 2: project to a tip of the yield surface (:113-143)
-		const float Je_new2 = -2.f * (p_trial > p0 ? p0 : p_min) * rcp_fast(bm) + 1.f;// Je_new^2
-		const float l2		= __builtin_amdgcn_logf(Je_new2);						// 2 log2 Je_new
-		Bn[0] = Bn[1] = Bn[2] = __builtin_amdgcn_exp2f(l2 * (1.f / 3.f));				// Je_new^(2/3)
-		rebuild				  = true;
-		if(mc.hardening_on) log_jp += (lg2J - 0.5f * l2) * 0.693147180559945f;
-	} else if(y >= 1e-4f) {// case 3: project to the yield surface (:151-203)
-		const float B_s_coeff = __builtin_amdgcn_exp2f(lg2J * (2.f / 3.f)) * rcp_fast(mc.mu) * __builtin_amdgcn_sqrtf(-y_p_half * rcp_fast(y_s_half_coeff)) * rsqrt_approx(s_sqrnorm);
-		Bn[0]				  = sh0 * B_s_coeff + trB3;
-		Bn[1]				  = sh1 * B_s_coeff + trB3;
-		Bn[2]				  = sh2 * B_s_coeff + trB3;
-		rebuild				  = true;
-		if(mc.hardening_on && p0 > 1e-4f && p_trial < p0 - 1e-4f && p_trial > 1e-4f + p_min) {
-			const float p_center = (1.0f - mc.beta) * p0 * 0.5f;
-			const float q_trial	 = __builtin_amdgcn_sqrtf(1.5f * s_sqrnorm);
-			float d0 = p_center - p_trial, d1 = -q_trial;
-			const float dn = rsqrt_approx(d0 * d0 + d1 * d1);
-			d0 *= dn;
-			d1 *= dn;
-			const float C  = mc.msqr * (p_center - p_min) * (p_center - p0);
-			const float B  = mc.msqr * d0 * (2.f * p_center - p0 - p_min);
-			const float A  = mc.msqr * d0 * d0 + (1.f + 2.f * mc.beta) * d1 * d1;
-			const float sq = __builtin_amdgcn_sqrtf(B * B - 4.f * A * C);
-			const float ia = rcp_fast(2.f * A);
-			const float p1 = p_center + (-B + sq) * ia * d0;
-			const float p2 = p_center + (-B - sq) * ia * d0;
-			const float p_fake		= (p_trial - p_center) * (p1 - p_center) > 0.f ? p1 : p2;
-			const float Je_new_fake2 = fabsf(-2.f * p_fake * rcp_fast(bm) + 1.f);// Je_new_fake^2
-			if(Je_new_fake2 > 1e-8f) log_jp += (lg2J - 0.5f * __builtin_amdgcn_logf(Je_new_fake2)) * 0.693147180559945f;
+	if(!skip) {
+		if(p_trial > p0 || p_trial < p_min) {// cases 1, 2: project to a tip of the yield surface (:113-143)
+			const float Je_new2 = -2.f * (p_trial > p0 ? p0 : p_min) * rcp_fast(bm) + 1.f;// Je_new^2
+			const float l2		= __builtin_amdgcn_logf(Je_new2);						// 2 log2 Je_new
+			Bn[0] = Bn[1] = Bn[2] = __builtin_amdgcn_exp2f(l2 * (1.f / 3.f));				// Je_new^(2/3)
+			rebuild				  = true;
+			if(mc.hardening_on) log_jp += (lg2J - 0.5f * l2) * 0.693147180559945f;
+		} else if(y >= 1e-4f) {// case 3: project to the yield surface (:151-203)
+			const float B_s_coeff = __builtin_amdgcn_exp2f(lg2J * (2.f / 3.f)) * rcp_fast(mc.mu) * __builtin_amdgcn_sqrtf(-y_p_half * rcp_fast(y_s_half_coeff)) * rsqrt_approx(s_sqrnorm);
+			Bn[0]				  = sh0 * B_s_coeff + trB3;
+			Bn[1]				  = sh1 * B_s_coeff + trB3;
+			Bn[2]				  = sh2 * B_s_coeff + trB3;
+			rebuild				  = true;
+			if(mc.hardening_on && p0 > 1e-4f && p_trial < p0 - 1e-4f && p_trial > 1e-4f + p_min) {
+				const float p_center = (1.0f - mc.beta) * p0 * 0.5f;
+				const float q_trial	 = __builtin_amdgcn_sqrtf(1.5f * s_sqrnorm);
+				float d0 = p_center - p_trial, d1 = -q_trial;
+				const float dn = rsqrt_approx(d0 * d0 + d1 * d1);
+				d0 *= dn;
+				d1 *= dn;
+				const float C  = mc.msqr * (p_center - p_min) * (p_center - p0);
+				const float B  = mc.msqr * d0 * (2.f * p_center - p0 - p_min);
+				const float A  = mc.msqr * d0 * d0 + (1.f + 2.f * mc.beta) * d1 * d1;
+				const float sq = __builtin_amdgcn_sqrtf(B * B - 4.f * A * C);
+				const float ia = rcp_fast(2.f * A);
+				const float p1 = p_center + (-B + sq) * ia * d0;
+				const float p2 = p_center + (-B - sq) * ia * d0;
+				const float p_fake		= (p_trial - p_center) * (p1 - p_center) > 0.f ? p1 : p2;
+				const float Je_new_fake2 = fabsf(-2.f * p_fake * rcp_fast(bm) + 1.f);// Je_new_fake^2
+				if(Je_new_fake2 > 1e-8f) log_jp += (lg2J - 0.5f * __builtin_amdgcn_logf(Je_new_fake2)) * 0.693147180559945f;
+			}
 		}
-	}
-	if(rebuild) {
-		if(!ill && detF > 0.f) {
-			float ratio[3];
-#pragma unroll
-			for(int i = 0; i < 3; i++) ratio[i] = __builtin_amdgcn_sqrtf(Bn[i] * rcp_fast(lam[i]));
-			rescale_principal(F, U, ratio);
-		} else {
-			float Sn[3];
-#pragma unroll
-			for(int i = 0; i < 3; i++) Sn[i] = __builtin_amdgcn_sqrtf(Bn[i]);
-			rebuild_through_v(F, U, lam, Sn);
+		if(rebuild) {
+			if(!ill && detF > 0.f) {
+				float ratio[3];
+	#pragma unroll
+				for(int i = 0; i < 3; i++) ratio[i] = __builtin_amdgcn_sqrtf(Bn[i] * rcp_fast(lam[i]));
+				rescale_principal(F, U, ratio);
+			} else {
+				float Sn[3];
+	#pragma unroll
+				for(int i = 0; i < 3; i++) Sn[i] = __builtin_amdgcn_sqrtf(Bn[i]);
+				rebuild_through_v(F, U, lam, Sn);
+			}
 		}
-	}
-	// elasticity (:206-230): J, dev(b) of the renewed F
-	const float lg2Jn	   = 0.5f * __builtin_amdgcn_logf(Bn[0] * Bn[1] * Bn[2]);
-	const float Jn_abs	   = __builtin_amdgcn_exp2f(lg2Jn);
-	const bool neg		   = detF < 0.f && !rebuild;
-	const float J2		   = Jn_abs * Jn_abs;
-	const float dev_b_coeff = neg ? __builtin_nanf("") : mc.mu * __builtin_amdgcn_exp2f(lg2Jn * (-2.f / 3.f));
-	const float i_coeff	   = bm * .5f * ((J2 - 1.f) * 0.5f - (neg ? __builtin_nanf("") : lg2Jn * 0.693147180559945f));
-	const float trBn3	   = (Bn[0] + Bn[1] + Bn[2]) * (1.f / 3.f);
-	float d[3];
+		// elasticity (:206-230): J, dev(b) of the renewed F
+		const float lg2Jn	   = 0.5f * __builtin_amdgcn_logf(Bn[0] * Bn[1] * Bn[2]);
+		const float Jn_abs	   = __builtin_amdgcn_exp2f(lg2Jn);
+		const bool neg		   = detF < 0.f && !rebuild;
+		const float J2		   = Jn_abs * Jn_abs;
+		const float dev_b_coeff = neg ? __builtin_nanf("") : mc.mu * __builtin_amdgcn_exp2f(lg2Jn * (-2.f / 3.f));
+		const float i_coeff	   = bm * .5f * ((J2 - 1.f) * 0.5f - (neg ? __builtin_nanf("") : lg2Jn * 0.693147180559945f));
+		const float trBn3	   = (Bn[0] + Bn[1] + Bn[2]) * (1.f / 3.f);
+		float d[3];
+	#pragma unroll
+		for(int k = 0; k < 3; ++k) d[k] = (dev_b_coeff * (Bn[k] - trBn3) + i_coeff) * mc.volume;
+		sym_from_eig(U, d, PF);
+	} else {
 #pragma unroll
-	for(int k = 0; k < 3; ++k) d[k] = (dev_b_coeff * (Bn[k] - trBn3) + i_coeff) * mc.volume;
-	sym_from_eig(U, d, PF);
+		for(int d = 0; d < 9; ++d) PF[d] = 0.f;
+	}
 	hk.template at<BASE + kEigSites + 1>();
 }
 MPM_DEV void stress_nacc(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9]) {

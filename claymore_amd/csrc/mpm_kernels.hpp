@@ -822,7 +822,8 @@ __global__ void test_eig_kernel(size_t n, const float* __restrict__ Fin, float* 
 	float F[9], lam[3], U[9];
 	for(int d = 0; d < 9; ++d) F[d] = Fin[9 * j + d];
 	NoHook nh;
-	sym_eig3<0>(F, lam, U, nh);
+	bool undeformed;
+	sym_eig3<0>(F, lam, U, nh, undeformed);
 	if(i >= n) return;
 	for(int d = 0; d < 9; ++d) out12[12 * i + d] = U[d];
 	for(int d = 0; d < 3; ++d) out12[12 * i + 9 + d] = lam[d];

@@ -170,6 +170,41 @@ def test_device_nacc_vs_closed_form_and_reference_golden():
         assert np.median(relF) < 1e-5
 
 
+@pytest.mark.parametrize("material", [_ffi.FIXED_COROTATED, _ffi.SAND, _ffi.NACC])
+def test_device_undeformed_wave_early_exit(material):
+    """A whole wave of undeformed particles (F F^T = I to rounding: free fall, rigid translation - the default window of the C3 bench)
+    leaves the stress functions early: P F^T = 0 exactly, F and log Jp untouched - which is what the models give there anyway (the
+    float64 closed forms say so).  A wave that holds ONE deformed particle takes the full path: its undeformed lanes must come out the same."""
+    import exact_models as X
+    hip = _ffi.load_hip()
+    n = 256
+    F = np.tile(np.eye(3, dtype=np.float32).reshape(1, 9), (n, 1))
+    F[:, 1] = 2e-10                       # the off-diagonal dust a free-falling particle carries (dt grad v of a rounding-level velocity gradient)
+    F[:, 5] = -3e-10
+    p = _params(material)
+    lj0 = float(p.log_jp0)
+    lj = np.full(n, lj0, dtype=np.float32)
+    got = np.empty((n, 19), dtype=np.float32)
+    assert hip.test_stress(material, C.byref(p), ptr(F), ptr(lj), n, ptr(got), 0) == 0
+    assert np.array_equal(got[:, 0:9], F) and np.all(got[:, 9:18] == 0.0) and np.all(got[:, 18] == lj0)
+    mixed = F.copy()
+    mixed[70] = np.array([0.95, 0.02, 0, -0.01, 0.90, 0.03, 0, 0.01, 0.93], dtype=np.float32)     # lane 6 of the second wave: compressed (sand carries no tension)
+    got2 = np.empty((n, 19), dtype=np.float32)
+    assert hip.test_stress(material, C.byref(p), ptr(mixed), ptr(lj), n, ptr(got2), 0) == 0
+    keep = np.arange(n) != 70
+    scale = p.volume * p.youngs_modulus
+    assert np.abs(got2[keep, 9:18]).max() / scale < 1e-7 and np.abs(got2[keep, 0:9] - F[keep]).max() < 2e-7 and np.abs(got2[keep, 18] - lj0).max() < 1e-7
+    assert np.abs(got2[70, 9:18]).max() / scale > 1e-3
+    mu, lam = _lame(p)
+    if material == _ffi.FIXED_COROTATED:
+        ex = X.fixed_corotated(F, mu, lam, p.volume)
+    elif material == _ffi.SAND:
+        ex = X.sand(F, lj, mu, lam, p.volume, p.cohesion, p.beta, p.yield_surface, p.volume_correction)[1]
+    else:
+        ex = X.nacc(F, lj, mu, lam, p.volume, p.beta, p.xi, p.msqr, p.hardening_on)[1]
+    assert np.abs(ex).max() / scale < 1e-8                                                          # the truth is zero too
+
+
 def test_device_sym_eig3_vs_float64():
     """The eigen-decomposition the stress functions are built on (sym_eig3 in mpm_device_math.hpp: cyclic Jacobi on F F^T with exact
     rotations), tested directly on the reference SVD's golden inputs (G3): U orthogonal, U diag(lam) U^T = F F^T, eigenvalues equal to

@@ -20,7 +20,8 @@ extern "C" int host_test_eig(const float* Fin, size_t n, float* out12) {
 	for(size_t i = 0; i < n; ++i) {
 		float F[9], lam[3], U[9];
 		for(int d = 0; d < 9; ++d) F[d] = Fin[9 * i + d];
-		sym_eig3<0>(F, lam, U, nh);
+		bool und;
+		sym_eig3<0>(F, lam, U, nh, und);
 		for(int d = 0; d < 9; ++d) out12[12 * i + d] = U[d];
 		for(int d = 0; d < 3; ++d) out12[12 * i + 9 + d] = lam[d];
 	}
