@@ -598,10 +598,10 @@ static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, co
 // part precedes the rebuild (reset_table + the counters, :436-446); with_rebuild issues both in one launch
 static int launch_clear(mpm_ctx* ctx, int flags) {
 	if(flags & kClearRebuild) {
-		if(ctx->rebuild_cleared) flags &= ~kClearRebuild;// (already issued with this substep's P2G part)
+		if(ctx->rebuild_cleared) flags &= ~(kClearRebuild | kClearMaxVel);// (already issued with this substep's P2G part)
 		ctx->rebuild_cleared = false;
 	}
-	if(!flags) return MPM_OK;
+	if(!(flags & (kClearP2G | kClearRebuild))) return MPM_OK;
 	ClearArgs a {};
 	a.flags	  = flags;
 	a.nmodels = (int) ctx->models.size();
@@ -622,15 +622,17 @@ static int launch_clear(mpm_ctx* ctx, int flags) {
 	substep_clear_kernel<<<1024, 256, 0, ctx->s_compute>>>(ctx->g, a);
 	return MPM_OK;
 }
-static int launch_g2p2g_prologue(mpm_ctx* ctx, bool with_rebuild = false) {
-	int rc = launch_clear(ctx, with_rebuild ? (kClearP2G | kClearRebuild) : kClearP2G);
+// with_rebuild: the rebuild's clear rides along (nobody looks at the old table before the rebuild); fused_update: that rebuild's
+// carry-over applies the next grid update, i.e. writes the max |v|^2 slots
+static int launch_g2p2g_prologue(mpm_ctx* ctx, bool with_rebuild = false, bool fused_update = false) {
+	int rc = launch_clear(ctx, with_rebuild ? (kClearP2G | kClearRebuild | (fused_update ? kClearMaxVel : 0)) : kClearP2G);
 	if(rc == MPM_OK && with_rebuild) ctx->rebuild_cleared = true;
 	return rc;
 }
 
-static int launch_g2p2g(mpm_ctx* ctx, float dt, float next_dt, hipEvent_t e0, hipEvent_t e1, bool with_rebuild_clear = false) {
+static int launch_g2p2g(mpm_ctx* ctx, float dt, float next_dt, hipEvent_t e0, hipEvent_t e1, bool with_rebuild_clear = false, bool fused_update = false) {
 	hipStream_t s = ctx->s_compute;
-	int rc		  = launch_g2p2g_prologue(ctx, with_rebuild_clear);
+	int rc		  = launch_g2p2g_prologue(ctx, with_rebuild_clear, fused_update);
 	if(rc) return rc;
 	HIP_TRY(hipEventRecord(e0, s));
 	if(ctx->pbc)
@@ -688,7 +690,8 @@ static int launch_rebuild(mpm_ctx* ctx, float fuse_dt = 0.f) {
 	const int r = ctx->rollid, n = r ^ 1;
 	Partition& Pn = ctx->part[n];
 	Partition& Pr = ctx->part[r];
-	int rc		  = launch_clear(ctx, kClearRebuild);// un-insert the old keys of Pn (reset_table, hash_table.cuh:110-112), counters, totals
+	const bool fused = fuse_dt > 0.f && !ctx->has_collision;
+	int rc			 = launch_clear(ctx, kClearRebuild | (fused ? kClearMaxVel : 0));// un-insert the old keys of Pn (reset_table, hash_table.cuh:110-112), counters, totals
 	if(rc) return rc;
 	RebuildModels rm {};
 	rm.n = (int) ctx->models.size();
@@ -705,7 +708,7 @@ static int launch_rebuild(mpm_ctx* ctx, float fuse_dt = 0.f) {
 	compact_blocks_kernel<<<std::max(1u, cdiv(ebc_est, 1024)), 1024, 0, s>>>(g, rm, Pr.keys, Pn.keys, Pn.table, st);
 	const unsigned rg8 = std::max(1u, std::min(4096u, cdiv((size_t) ebc_est * 8, 256))), rg32 = std::max(1u, std::min(8192u, cdiv((size_t) ebc_est * 32, 256)));
 	register_blocks_kernel<0, 1><<<rg8, 256, 0, s>>>(g, &st[ST_CNT_P], nullptr, &st[ST_CNT_N], &st[ST_PBC], Pn.table, Pn.keys, st);
-	if(fuse_dt > 0.f && !ctx->has_collision) {
+	if(fused) {
 		carry_grid_kernel<true><<<2048, 256, 0, s>>>(g, st, Pn.keys, Pr.table, ctx->grid[1], ctx->grid[0], fuse_dt, ctx->d_maxvel);
 		ctx->grid_preupdated = true;
 		ctx->preupdate_dt	 = fuse_dt;
@@ -879,9 +882,10 @@ int mpm_run_fixed(mpm_ctx* ctx, int nsteps, float dt) {
 		HIP_TRY(hipEventRecord(ev[0], s));
 		int rc = launch_grid_update(ctx, dt);
 		if(rc) return run_fixed_fail(ctx, rc);
-		rc = launch_g2p2g(ctx, dt, dt, ev[1], ev[2], true);
+		const bool fuse_next = it + 1 < nsteps;// the last substep leaves the canonical state behind
+		rc = launch_g2p2g(ctx, dt, dt, ev[1], ev[2], true, fuse_next && !ctx->has_collision);
 		if(rc) return run_fixed_fail(ctx, rc);
-		rc = launch_rebuild(ctx, it + 1 < nsteps ? dt : 0.f);// the last substep leaves the canonical state behind
+		rc = launch_rebuild(ctx, fuse_next ? dt : 0.f);
 		if(rc) return run_fixed_fail(ctx, rc);
 		HIP_TRY(hipEventRecord(ev[3], s));
 		roll_partition(ctx);

@@ -457,7 +457,7 @@ struct RebuildModels {
 //                 fused grid update (an infinite one leaves a sticky flag behind first, gmpm_simulator.cuh:355-358).
 // mpm_run_fixed issues both parts in ONE launch before G2P2G (nobody looks at the old table in between).  All sizes are read
 // from the status block.
-enum { kClearP2G = 1, kClearRebuild = 2 };
+enum { kClearP2G = 1, kClearRebuild = 2, kClearMaxVel = 4 };// kClearMaxVel: the rebuild that follows writes the slots (fused grid update)
 struct ClearArgs {
 	int flags;
 	int nmodels;
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void substep_clear_kernel(GridCfg cfg, ClearAr
 			if(threadIdx.x >= 64 && threadIdx.x < 64 + kMaxVelSlots) {
 				unsigned* slot = a.max_vel_bits + (threadIdx.x - 64) * kMaxVelStride;
 				if(*slot >= 0x7f800000u) a.status[ST_NONFINITE] = 1;
-				*slot = 0u;
+				if(a.flags & kClearMaxVel) *slot = 0u;// (otherwise the slots keep this substep's grid-update result for the host)
 			}
 		}
 	}

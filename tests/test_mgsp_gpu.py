@@ -361,3 +361,36 @@ def test_cpp_group_equals_single_engine(material):
             idx, _ = match(xo.astype(np.float64), xm.astype(np.float64))
             rel = np.abs(xm[idx].astype(np.float64) - xo).max(axis=1) / np.abs(xo).max(axis=1)
             assert rel.max() < 1e-6, (world, m, rel.max())
+
+
+def test_group_substep_reports_this_ranks_max_velocity():
+    """mpm_group_substep returns the rank's max |v|^2 after its grid update (the input of MGSP's compute_dt, mgsp_benchmark.cuh:410-418),
+    whether the grid update ran as its own kernel (phase by phase) or rode on the previous rebuild's carry-over (mpm_group_run_fixed)."""
+    sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=3.0, speed=2.0)
+    world = 2
+    lg = LocalGroup(world)
+    ranks = [MgspGroupRank(sc, r, world, device=0, local_group=lg) for r in range(world)]
+    lg.create()
+    out, errors = [None] * world, []
+
+    def work(r):
+        try:
+            sim = ranks[r]
+            sim.initial_setup()
+            mv = [sim.substep(1e-4, 1e-4) for _ in range(3)]        # separate grid-update kernel
+            sim.run_fixed(4, 1e-4)                                  # fused into the carry-over
+            mv.append(sim.substep(1e-4, 1e-4))
+            out[r] = mv
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    for r in ranks:
+        r.close()
+    assert not errors, errors
+    for mv in out:
+        assert all(3.9 < v < 4.2 for v in mv), mv                   # |v|^2 = 2^2 (+ a few mm/s of gravity)
