@@ -4,6 +4,7 @@
 //   usage: energy_microbench <mode> <seconds>
 //   modes: 0 idle waves (s_sleep)   1 v_fmac_f32   2 v_pk_fma_f32   3 v_fma_f32 (VOP3)   4 ds_read_b128   5 ds_write_b128
 //          6 ds read-modify-write b128 pair   7 global_load_dwordx4 stream (4 GiB, HBM)   8 global_store_dwordx4 stream   9 v_mov_b32
+//          10 ds_write_b64 x 2   11 ds_write2_b64   12 ds_read2_b64   13 ds_write_b96
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -26,6 +27,8 @@ __global__ __launch_bounds__(64) void burn(int n, float* sink) {
 	__syncthreads();
 	const unsigned addr = threadIdx.x * 16;// linear: conflict-free
 	v4f r0 = {0, 0, 0, 0}, r1 = r0, r2 = r0, r3 = r0;
+	typedef float v3f __attribute__((ext_vector_type(3)));
+	v3f q3 = {a0, a1, a2};
 	for(int i = 0; i < n; ++i) {
 		if constexpr(MODE == 0) {
 			asm volatile(REP8("s_sleep 16\n"));
@@ -60,6 +63,30 @@ __global__ __launch_bounds__(64) void burn(int n, float* sink) {
 						 :
 						 : "v"(addr), "v"(r0)
 						 : "memory");
+		} else if constexpr(MODE == 10) {// 16 B per lane as two ds_write_b64
+			asm volatile(REP8("ds_write_b64 %0, %1\n ds_write_b64 %0, %2 offset:8\n ds_write_b64 %0, %1 offset:1024\n ds_write_b64 %0, %2 offset:1032\n"
+							  "ds_write_b64 %0, %1\n ds_write_b64 %0, %2 offset:8\n ds_write_b64 %0, %1 offset:1024\n ds_write_b64 %0, %2 offset:1032\n s_waitcnt lgkmcnt(0)\n")
+						 :
+						 : "v"(addr), "v"(p0), "v"(p1)
+						 : "memory");
+		} else if constexpr(MODE == 11) {// 16 B per lane as one ds_write2_b64 (offsets in units of 8 B)
+			asm volatile(REP8("ds_write2_b64 %0, %1, %2 offset0:0 offset1:1\n ds_write2_b64 %0, %1, %2 offset0:128 offset1:129\n ds_write2_b64 %0, %1, %2 offset0:0 offset1:1\n ds_write2_b64 %0, %1, %2 offset0:128 offset1:129\n"
+							  "ds_write2_b64 %0, %1, %2 offset0:0 offset1:1\n ds_write2_b64 %0, %1, %2 offset0:128 offset1:129\n ds_write2_b64 %0, %1, %2 offset0:0 offset1:1\n ds_write2_b64 %0, %1, %2 offset0:128 offset1:129\n s_waitcnt lgkmcnt(0)\n")
+						 :
+						 : "v"(addr), "v"(p0), "v"(p1)
+						 : "memory");
+		} else if constexpr(MODE == 12) {// 16 B per lane as one ds_read2_b64
+			asm volatile(REP8("ds_read2_b64 %0, %4 offset0:0 offset1:1\n ds_read2_b64 %1, %4 offset0:128 offset1:129\n ds_read2_b64 %2, %4 offset0:0 offset1:1\n ds_read2_b64 %3, %4 offset0:128 offset1:129\n"
+							  "ds_read2_b64 %0, %4 offset0:0 offset1:1\n ds_read2_b64 %1, %4 offset0:128 offset1:129\n ds_read2_b64 %2, %4 offset0:0 offset1:1\n ds_read2_b64 %3, %4 offset0:128 offset1:129\n s_waitcnt lgkmcnt(0)\n")
+						 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+						 : "v"(addr)
+						 : "memory");
+		} else if constexpr(MODE == 13) {// 12 B per lane: ds_write_b96
+			asm volatile(REP8("ds_write_b96 %0, %1\n ds_write_b96 %0, %1 offset:1024\n ds_write_b96 %0, %1\n ds_write_b96 %0, %1 offset:1024\n"
+							  "ds_write_b96 %0, %1\n ds_write_b96 %0, %1 offset:1024\n ds_write_b96 %0, %1\n ds_write_b96 %0, %1 offset:1024\n s_waitcnt lgkmcnt(0)\n")
+						 :
+						 : "v"(addr), "v"(q3)
+						 : "memory");
 		} else if constexpr(MODE == 6) {
 			asm volatile(REP8("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)\n ds_write_b128 %1, %0\n ds_read_b128 %0, %1 offset:1024\n s_waitcnt lgkmcnt(0)\n ds_write_b128 %1, %0 offset:1024\n"
 							  "ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)\n ds_write_b128 %1, %0\n ds_read_b128 %0, %1 offset:1024\n s_waitcnt lgkmcnt(0)\n ds_write_b128 %1, %0 offset:1024\n")
@@ -90,7 +117,7 @@ template<int MODE>
 static void run(double seconds, float* sink, int per_iter, const char* what) {
 	const int W		 = 8;
 	const int blocks = 256 * 4 * W;
-	const int n		 = MODE == 0 ? 2000 : (MODE == 4 || MODE == 5 || MODE == 6 ? 400 : 200);
+	const int n		 = MODE == 0 ? 2000 : (MODE == 4 || MODE == 5 || MODE == 6 || MODE >= 10 ? 400 : 200);
 	burn<MODE><<<blocks, 64>>>(10, sink);
 	hipDeviceSynchronize();
 	const auto t0 = std::chrono::steady_clock::now();
@@ -120,6 +147,10 @@ int main(int argc, char** argv) {
 		case 4: run<4>(seconds, sink, 64, "ds_read_b128"); break;
 		case 5: run<5>(seconds, sink, 64, "ds_write_b128"); break;
 		case 6: run<6>(seconds, sink, 64, "ds rmw b128 (read+write = 2)"); break;
+		case 10: run<10>(seconds, sink, 64, "ds_write_b64 (2 per 16 B)"); break;
+		case 11: run<11>(seconds, sink, 64, "ds_write2_b64 (16 B)"); break;
+		case 12: run<12>(seconds, sink, 64, "ds_read2_b64 (16 B)"); break;
+		case 13: run<13>(seconds, sink, 64, "ds_write_b96"); break;
 		case 7:
 		case 8: {
 			const size_t n = (size_t) 1 << 28;// 4 GiB of float4
