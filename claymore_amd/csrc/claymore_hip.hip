@@ -597,7 +597,7 @@ static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, co
 // substep_clear_kernel: the P2G part precedes G2P2G (clear_grid + the bucket counters, gmpm_simulator.cuh:383,:389), the rebuild
 // part precedes the rebuild (reset_table + the counters, :436-446); with_rebuild issues both in one launch
 static int launch_clear(mpm_ctx* ctx, int flags) {
-	if(flags & kClearRebuild) {
+	if((flags & kClearRebuild) && !(flags & kClearP2G)) {// called by the rebuild itself
 		if(ctx->rebuild_cleared) flags &= ~(kClearRebuild | kClearMaxVel);// (already issued with this substep's P2G part)
 		ctx->rebuild_cleared = false;
 	}
