@@ -86,7 +86,7 @@ struct mpm_ctx {
 	// halo state (MGSP)
 	int* d_overlap	   = nullptr;// per neighbour block: bit mask of peers that also own it
 	int* d_halo_list   = nullptr;// particle blocks touching an overlap block
-	int* d_inner_list  = nullptr;
+	int* d_inner_list  = nullptr;// per particle block: 1 = interior (not touched by the halo-first pass)
 	int* d_halo_counts = nullptr;// [0]=halo blocks, [1]=interior blocks, [2+peer]=send count for peer
 	int* h_halo_counts = nullptr;// pinned mirror
 	int* d_peer_rows   = nullptr;// key-list lengths exported by every rank (fused substep); lives behind d_halo_counts
@@ -571,7 +571,7 @@ static inline int hint_blocks(const mpm_ctx* ctx, int n) {
 
 // nblocks_ptr != nullptr: the block count is read from device memory, `nblocks` is the host's estimate of it (launch size);
 // otherwise `nblocks` is exact (the halo / interior lists of the MGSP path, whose lengths the host has read back)
-static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, const int* nblocks_ptr, int nblocks, float dt, float next_dt, hipStream_t s) {
+static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, const int* nblocks_ptr, int nblocks, float dt, float next_dt, hipStream_t s, const int* only_flag = nullptr) {
 	const int r = ctx->rollid;
 	ModelView v = make_view(ctx, m);
 	const int* cur_keys	  = ctx->part[r].keys;
@@ -587,10 +587,10 @@ static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, co
 	const int nwg = nblocks_ptr ? hint_blocks(ctx, nblocks) : nblocks;
 #endif
 	switch(m.material) {
-		case MPM_J_FLUID: g2p2g_kernel<0><<<nwg, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, nblocks_ptr, nblocks, dt, next_dt, sk, ctx->d_status); break;
-		case MPM_FIXED_COROTATED: g2p2g_kernel<1><<<nwg, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, nblocks_ptr, nblocks, dt, next_dt, sk, ctx->d_status); break;
-		case MPM_SAND: g2p2g_kernel<2><<<nwg, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, nblocks_ptr, nblocks, dt, next_dt, sk, ctx->d_status); break;
-		default: g2p2g_kernel<3><<<nwg, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, nblocks_ptr, nblocks, dt, next_dt, sk, ctx->d_status); break;
+		case MPM_J_FLUID: g2p2g_kernel<0><<<nwg, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, only_flag, nblocks_ptr, nblocks, dt, next_dt, sk, ctx->d_status); break;
+		case MPM_FIXED_COROTATED: g2p2g_kernel<1><<<nwg, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, only_flag, nblocks_ptr, nblocks, dt, next_dt, sk, ctx->d_status); break;
+		case MPM_SAND: g2p2g_kernel<2><<<nwg, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, only_flag, nblocks_ptr, nblocks, dt, next_dt, sk, ctx->d_status); break;
+		default: g2p2g_kernel<3><<<nwg, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, only_flag, nblocks_ptr, nblocks, dt, next_dt, sk, ctx->d_status); break;
 	}
 }
 

@@ -392,7 +392,7 @@ MPM_DEV int code_off(int c) {
 }
 
 template<int MAT>
-__global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : MPM_G2P2G_WAVES) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_keys, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, const int* __restrict__ nblocks_ptr, int nblocks, float dt, float new_dt, StepConst sk, int* __restrict__ status) {
+__global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : MPM_G2P2G_WAVES) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_keys, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, const int* __restrict__ only_flag, const int* __restrict__ nblocks_ptr, int nblocks, float dt, float new_dt, StepConst sk, int* __restrict__ status) {
 	constexpr int NCH = MatTraits<MAT>::nch;
 	// 10.8 KB of LDS per wave: 15 single-wave workgroups per CU.
 	__shared__ float4 g2p[kG2PNodes];	   // node velocities {vx, vy, vz, vz} of cube nodes 1..6 per axis
@@ -430,7 +430,10 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 	const int size		 = mv.size[b];
 	const int row		 = mv.row_of[b];
 	const int binoff_dst = mv.binoff_dst[b];
-	if(size == 0) continue;// (:692-697)
+	// only_flag (MGSP interior pass): the launch covers ALL particle blocks in their own (spatially coherent) order and skips the ones the
+	// halo-first pass has done - no indirection through a compacted list, whose atomic append order loses that coherence
+	const int flag = only_flag ? only_flag[b] : 1;
+	if(size == 0 || flag == 0) continue;// (:692-697)
 	const int* list		= mv.list_in + (size_t) row * cfg.ppb;
 	const float dx_inv	= cfg.dx_inv;
 	const float mass	= mv.mc.mass;
