@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -18,6 +19,10 @@
 using namespace mpm;
 
 namespace {
+// ONE device block (and its pinned mirror) holds everything the host reads back at a synchronisation: the status words, the MGSP halo
+// counters + the peers' key-list lengths, and the max |v|^2 slots - one device-to-host copy instead of three.
+constexpr int kHaloWords	 = 128;// 2 + 32 send counts + 32 peer list lengths, padded
+constexpr int kStatusBlock = ST_WORDS + kHaloWords + kMaxVelSlots * kMaxVelStride;// in 4-byte words
 
 struct Partition {
 	int* table = nullptr;
@@ -300,16 +305,13 @@ void mpm_destroy(mpm_ctx* ctx) {
 		hipFree(m.out_count);
 	}
 	hipFree(ctx->d_status);
-	hipFree(ctx->d_maxvel);
 	hipFree(ctx->d_totals);
 	hipFree(ctx->d_counter);
 	hipFree(ctx->d_overlap);
 	hipFree(ctx->d_halo_list);
 	hipFree(ctx->d_inner_list);
-	hipFree(ctx->d_halo_counts);
 	for(auto& p: ctx->d_send_ids) hipFree(p);
 	if(ctx->h_status) hipHostFree(ctx->h_status);
-	if(ctx->h_maxvel) hipHostFree(ctx->h_maxvel);
 	if(ctx->ev_a) hipEventDestroy(ctx->ev_a);
 	if(ctx->ev_b) hipEventDestroy(ctx->ev_b);
 	if(ctx->ev_g0) hipEventDestroy(ctx->ev_g0);
@@ -317,7 +319,6 @@ void mpm_destroy(mpm_ctx* ctx) {
 	if(ctx->ev_comm) hipEventDestroy(ctx->ev_comm);
 	if(ctx->ev_halo) hipEventDestroy(ctx->ev_halo);
 	for(hipEvent_t e: ctx->ev_ring) hipEventDestroy(e);
-	if(ctx->h_halo_counts) hipHostFree(ctx->h_halo_counts);
 	if(ctx->s_compute) hipStreamDestroy(ctx->s_compute);
 	if(ctx->s_comm) hipStreamDestroy(ctx->s_comm);
 	delete ctx;
@@ -352,9 +353,20 @@ int mpm_add_model(mpm_ctx* ctx, int material, const mpm_material_params* params,
 	return MPM_OK;
 }
 
+// Host synchronisation with a short spin in front of the blocking wait: when the stream is about to drain (the end of a substep whose
+// kernels are already running) the blocking wait's wake-up latency (~15-20 us) would sit between two substeps as GPU idle time.
+static hipError_t sync_stream(hipStream_t s) {
+	const auto t0 = std::chrono::steady_clock::now();
+	for(;;) {
+		const hipError_t q = hipStreamQuery(s);
+		if(q != hipErrorNotReady) return q;
+		if(std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) break;
+	}
+	return hipStreamSynchronize(s);
+}
 static int read_status(mpm_ctx* ctx) {
-	HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int) * ST_WORDS, hipMemcpyDeviceToHost, ctx->s_compute));
-	HIP_TRY(hipStreamSynchronize(ctx->s_compute));
+	HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int) * kStatusBlock, hipMemcpyDeviceToHost, ctx->s_compute));// status + halo counters + max |v|^2 slots
+	HIP_TRY(sync_stream(ctx->s_compute));
 	return MPM_OK;
 }
 
@@ -374,13 +386,18 @@ int mpm_initial_setup(mpm_ctx* ctx) {
 	hipStream_t s	   = ctx->s_compute;
 	const size_t table = (size_t) g.G * g.G * g.G;
 	const int r = ctx->rollid, n = r ^ 1;
-	HIP_TRY(dalloc(&ctx->d_status, ST_WORDS));
-	HIP_TRY(hipHostMalloc((void**) &ctx->h_status, sizeof(int) * ST_WORDS));
-	HIP_TRY(dalloc(&ctx->d_maxvel, kMaxVelSlots * kMaxVelStride));
-	HIP_TRY(hipHostMalloc((void**) &ctx->h_maxvel, sizeof(float) * kMaxVelSlots * kMaxVelStride));
+	HIP_TRY(dalloc(&ctx->d_status, kStatusBlock));
+	HIP_TRY(hipHostMalloc((void**) &ctx->h_status, sizeof(int) * kStatusBlock));
+	memset(ctx->h_status, 0, sizeof(int) * kStatusBlock);
+	ctx->d_halo_counts = ctx->d_status + ST_WORDS;
+	ctx->h_halo_counts = ctx->h_status + ST_WORDS;
+	ctx->d_peer_rows   = ctx->d_halo_counts + 2 + 32;
+	ctx->h_peer_rows   = ctx->h_halo_counts + 2 + 32;
+	ctx->d_maxvel	   = reinterpret_cast<unsigned*>(ctx->d_status + ST_WORDS + kHaloWords);
+	ctx->h_maxvel	   = reinterpret_cast<float*>(ctx->h_status + ST_WORDS + kHaloWords);
 	HIP_TRY(dalloc(&ctx->d_totals, 4));
 	HIP_TRY(dalloc(&ctx->d_counter, 1));
-	HIP_TRY(hipMemsetAsync(ctx->d_status, 0, sizeof(int) * ST_WORDS, s));
+	HIP_TRY(hipMemsetAsync(ctx->d_status, 0, sizeof(int) * kStatusBlock, s));
 	for(int i = 0; i < 2; ++i) {
 		HIP_TRY(dalloc(&ctx->part[i].table, table));
 		HIP_TRY(dalloc(&ctx->part[i].count, 1));
@@ -891,9 +908,8 @@ int mpm_run_fixed(mpm_ctx* ctx, int nsteps, float dt) {
 		roll_partition(ctx);
 		++in_window;
 		if(in_window == K || it + 1 == nsteps) {
-			HIP_TRY(hipMemcpyAsync(ctx->h_maxvel, ctx->d_maxvel, sizeof(float) * kMaxVelSlots * kMaxVelStride, hipMemcpyDeviceToHost, s));
 			HIP_TRY(hipGetLastError());
-			rc = sync_counts(ctx, nullptr);
+			rc = sync_counts(ctx, nullptr);// (one read-back: status, halo counters, max |v|^2 slots)
 			if(rc) return run_fixed_fail(ctx, rc);
 			if(std::isinf(host_maxvel(ctx))) return run_fixed_fail(ctx, fail(ctx, MPM_ERR_NONFINITE, "Maximum velocity is infinity"));
 			for(int w = 0; w < in_window; ++w) {
