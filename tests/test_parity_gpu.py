@@ -545,6 +545,42 @@ def test_block_capacity_grows_like_check_capacity():
     assert xyz.shape == xyz_ref.shape and rel.max() < POS_TOL, rel.max()
 
 
+def test_capacity_grows_inside_a_long_run_between_windows():
+    """Capacity growth happens at host synchronisations only, i.e. once per window of sync_interval substeps: two touching
+    spheres flying apart keep entering new blocks (190 -> ~265 exterior blocks over 300 substeps, never more than ~8 % inside
+    one window).  The context starts 70 % full - below the 3/4 mark, so nothing grows at the entry of the run - and must be
+    grown in time at some window boundary of ONE long mpm_run_fixed call; same trajectory as a roomy context."""
+    def scene():
+        return scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=0.5, speed=-3.0)     # negative speed: apart
+    sc = scene()
+    ref = build_engine(sc)
+    ref.initial_setup()
+    nm = len(sc["models"])
+    ebc0 = ref.counts().exterior_blocks
+    peak = ebc0
+    for _ in range(30):
+        ref.run_fixed(10, sc["dt"])
+        peak = max(peak, ref.counts().exterior_blocks)
+    want = [ref.retrieve_positions(m) for m in range(nm)]
+    ref.close()
+    sc = scene()
+    sc["config"]["max_blocks"] = int(ebc0 / 0.70)          # 70 % full at set-up: below the 3/4 growth mark
+    eng = build_engine(sc)
+    eng.initial_setup()
+    cap0, _, ev0 = eng.capacity()
+    assert ev0 == 0 and peak > cap0 * 3 // 4, (ebc0, peak, cap0)      # the run will have to grow
+    eng.run_fixed(300, sc["dt"])                           # one call: 38 windows of 8 substeps
+    cap1, _, ev1 = eng.capacity()
+    assert ev1 >= 1 and cap1 > cap0
+    from parity_util import match
+    for m in range(nm):
+        got = eng.retrieve_positions(m)
+        idx, _ = match(want[m].astype(np.float64), got.astype(np.float64))
+        rel = np.abs(got[idx].astype(np.float64) - want[m]).max(axis=1) / np.abs(want[m]).max(axis=1)
+        assert rel.max() < 2e-6, rel.max()
+    eng.close()
+
+
 def test_fixed_capacity_reports_error_when_exceeded():
     """grow = 0: the reference's abort path (gmpm_simulator.cuh:473-476) becomes MPM_ERR_CAPACITY."""
     sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=4.0)
