@@ -340,7 +340,7 @@ int mpm_add_model(mpm_ctx* ctx, int material, const mpm_material_params* params,
 	m.material = material;
 	m.p		   = *params;
 	m.mc	   = make_material_const(*params);
-	m.nch	   = material == MPM_J_FLUID ? 4 : (material == MPM_FIXED_COROTATED ? 12 : 16);// floats per particle record (mpm_g2p2g.hpp)
+	m.nch	   = material == MPM_J_FLUID ? 4 : (material == MPM_FIXED_COROTATED ? 12 : 13);// floats per particle in a bin (mpm_g2p2g.hpp: 48-B records + a row of log Jp)
 	m.n		   = n;
 	for(int d = 0; d < 3; ++d) m.v0[d] = v0 ? v0[d] : 0.f;
 	HIP_TRY(dalloc(&m.d_xyz, 3 * n));

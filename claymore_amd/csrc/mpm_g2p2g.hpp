@@ -57,28 +57,30 @@ struct ModelView {
 };
 
 // Particle storage: bins of 64 particle RECORDS, a record = {x, y, z, state...} contiguous in memory (16 B for the J-fluid
-// {x, y, z, J}, 48 B fixed-corotated {x, y, z, F[9]}, 64 B sand / NACC {x, y, z, F[9], log Jp, 3 x pad}), moved with 16-byte
-// loads and stores.  The reference's (and round 1's) AoSoA bins [channel][slot] are ideal only while the sorted order of a
+// {x, y, z, J}, 48 B {x, y, z, F[9]} for the other models), moved with 16-byte loads and stores; sand / NACC keep their 13th
+// float, log Jp, in a 64-float row behind the bin's 64 records (bin = 64 x 48 B + 256 B = 3328 B: `nch` = 13 floats per
+// particle, `rec` = 12 per record).  Round 2 padded those records to one 64-B sector: 24 of the 152 bytes a particle moved
+// per step were padding, and the launch pays for bytes: 1.39 -> 1.2x ms in the default window of C3.  The reference's (and round 1's) AoSoA bins [channel][slot] are ideal only while the sorted order of a
 // step equals the order the particles were written in; in a flow the 64 lanes of an iteration read 64 scattered slots, and
 // with one 256-B row per channel that is 13 x ~16 cache lines per wave-load and a 6x HBM read amplification
-// (profiles/r02_moving_window_pmc.txt).  A record is one 64-B sector whatever the permutation.
+// (profiles/r02_moving_window_pmc.txt).  A record is contiguous whatever the permutation.
 template<int MAT>
 struct MatTraits;
 template<>
 struct MatTraits<0> {
-	static constexpr int nch = 4;
+	static constexpr int nch = 4, rec = 4;
 };
 template<>
 struct MatTraits<1> {
-	static constexpr int nch = 12;
+	static constexpr int nch = 12, rec = 12;
 };
 template<>
 struct MatTraits<2> {
-	static constexpr int nch = 16;
+	static constexpr int nch = 13, rec = 12;
 };
 template<>
 struct MatTraits<3> {
-	static constexpr int nch = 16;
+	static constexpr int nch = 13, rec = 12;
 };
 
 // P2G payload of one particle: everything the scatter needs after the material update.
@@ -393,7 +395,8 @@ MPM_DEV int code_off(int c) {
 
 template<int MAT>
 __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : MPM_G2P2G_WAVES) void g2p2g_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_keys, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, const int* __restrict__ only_flag, const int* __restrict__ nblocks_ptr, int nblocks, float dt, float new_dt, StepConst sk, int* __restrict__ status) {
-	constexpr int NCH = MatTraits<MAT>::nch;
+	constexpr int NCH = MatTraits<MAT>::nch;// floats per particle in a bin
+	constexpr int REC = MatTraits<MAT>::rec;// floats per record (the rest: one 64-float row per channel behind the records)
 	// 10.8 KB of LDS per wave: 15 single-wave workgroups per CU.
 	__shared__ float4 g2p[kG2PNodes];	   // node velocities {vx, vy, vz, vz} of cube nodes 1..6 per axis
 	__shared__ float4 p2g[2 * kP2GNodes];  // {mass, momentum} accumulators of cube nodes 1..6 per axis; even lanes use the first
@@ -467,17 +470,20 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 	// compiler can count them in s_waitcnt; their arrival is implied by the list-append atomics' results being consumed
 	// at the end of the iteration (memory operations return in order).
 	struct Prefetch {
-		float4 q[NCH / 4];// the particle record
+		float4 q[REC / 4];// the particle record
+		float lj;		  // log Jp (sand / NACC)
 		int key;		  // the stencil base this particle was predicted to have after this step (its sort key)
 	};
 	auto fetch = [&](int rec, Prefetch& f) {
 		const int tag	  = (rec >> tag_shift) & 31;
 		const int sp	  = rec & (cfg.ppb - 1);
 		const int sbin	  = __shfl(info, tag) + (sp >> 6);
-		const float4* src = reinterpret_cast<const float4*>(mv.bins_src + ((size_t) sbin * kBin + (sp & 63)) * NCH);
+		const float* bin  = mv.bins_src + (size_t) sbin * (kBin * NCH);
+		const float4* src = reinterpret_cast<const float4*>(bin + (sp & 63) * REC);
 		f.key			  = (rec >> key_shift) & 255;
 #pragma unroll
-		for(int d = 0; d < NCH / 4; ++d) f.q[d] = src[d];
+		for(int d = 0; d < REC / 4; ++d) f.q[d] = src[d];
+		if constexpr(NCH > REC) f.lj = bin[kBin * REC + (sp & 63)];
 	};
 	Prefetch pf;
 	fetch(rec_cur, pf);
@@ -524,7 +530,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 			st[6] = pf.q[2].y;
 			st[7] = pf.q[2].z;
 			st[8] = pf.q[2].w;
-			if constexpr(NCH == 16) st[9] = pf.q[3].x;
+			if constexpr(NCH > REC) st[9] = pf.lj;
 		}
 		const int slot_nn = idx0 + 128 < size ? idx0 + 128 : 0;
 		const int cnt_nn  = idx0 + 128 < size ? slice_records_at(size, idx0 + 128) : 1;
@@ -620,7 +626,8 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		if constexpr(kPreSites == 3) chain.template at<2>();
 		MPM_MARK("L_material");
 		// ---- material update, store to the destination bin (slot == pidib: consecutive records) (:470-663)
-		float4* dst = reinterpret_cast<float4*>(mv.bins_dst + ((size_t) (binoff_dst + (pidib >> 6)) * kBin + (pidib & 63)) * NCH);
+		float* dbin = mv.bins_dst + (size_t) (binoff_dst + (pidib >> 6)) * (kBin * NCH);
+		float4* dst = reinterpret_cast<float4*>(dbin + (pidib & 63) * REC);
 		if constexpr(MAT == 0) {
 			float Aw[9];
 #pragma unroll
@@ -651,7 +658,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 			dst[0] = make_float4(pos[0], pos[1], pos[2], F[0]);
 			dst[1] = make_float4(F[1], F[2], F[3], F[4]);
 			dst[2] = make_float4(F[5], F[6], F[7], F[8]);
-			if constexpr(NCH == 16) dst[3] = make_float4(lj, 0.f, 0.f, 0.f);
+			if constexpr(NCH > REC) dbin[kBin * REC + (pidib & 63)] = lj;// (lane == slot: one 256-B row per wave)
 		}
 		MPM_MARK("L_contrib");
 		chain.template at<kSites - 1>();

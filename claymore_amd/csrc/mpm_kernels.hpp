@@ -721,7 +721,9 @@ __global__ __launch_bounds__(256) void fill_bins_kernel(GridCfg cfg, int nch, fl
 	const int n = size[b];
 	for(int pidib = threadIdx.x; pidib < n; pidib += blockDim.x) {
 		const int pid = ids[(size_t) b * cfg.ppb + pidib];
-		float* dst = bins + ((size_t) (binoff[b] + (pidib >> 6)) * kBin + (pidib & 63)) * nch;// record layout: mpm_g2p2g.hpp
+		const int rec = nch == 13 ? 12 : nch;// record layout: mpm_g2p2g.hpp (the 13th float, log Jp, sits in a row behind the bin's records)
+		float* bin = bins + (size_t) (binoff[b] + (pidib >> 6)) * (kBin * nch);
+		float* dst = bin + (pidib & 63) * rec;
 		dst[0]	   = xyz[3 * (size_t) pid];
 		dst[1]	   = xyz[3 * (size_t) pid + 1];
 		dst[2]	   = xyz[3 * (size_t) pid + 2];
@@ -729,10 +731,7 @@ __global__ __launch_bounds__(256) void fill_bins_kernel(GridCfg cfg, int nch, fl
 			dst[3] = 1.f;
 		} else {
 			for(int d = 0; d < 9; ++d) dst[3 + d] = (d % 4 == 0) ? 1.f : 0.f;
-			if(nch == 16) {
-				dst[12] = log_jp0;
-				dst[13] = dst[14] = dst[15] = 0.f;
-			}
+			if(nch == 13) bin[kBin * rec + (pidib & 63)] = log_jp0;
 		}
 		const int cx = node_index(xyz[3 * (size_t) pid], cfg.dx_inv) - 2, cy = node_index(xyz[3 * (size_t) pid + 1], cfg.dx_inv) - 2, cz = node_index(xyz[3 * (size_t) pid + 2], cfg.dx_inv) - 2;
 		const int key = (((cy & 3) + 1) * 6 + ((cx & 3) + 1)) * 6 + ((cz & 3) + 1);// stencil base in the block's node cube, y slowest (mpm_g2p2g.hpp); no motion predicted
@@ -781,7 +780,9 @@ __global__ __launch_bounds__(256) void retrieve_kernel(GridCfg cfg, int nch, con
 		dir_components((rec >> (cfg.pid_bits + kKeyBits)) & 31, ox, oy, oz);
 		const int sp	 = rec & (cfg.ppb - 1);
 		const int srcno	 = table_query(cfg, prev_table, kx + ox, ky + oy, kz + oz);
-		const float* src = bins_src + ((size_t) (binoff_src[srcno] + (sp >> 6)) * kBin + (sp & 63)) * nch;
+		const int recf	 = nch == 13 ? 12 : nch;
+		const float* bin = bins_src + (size_t) (binoff_src[srcno] + (sp >> 6)) * (kBin * nch);
+		const float* src = bin + (sp & 63) * recf;
 		const unsigned long long o = atomicAdd(counter, 1ull);
 		if(o >= capacity) continue;
 		xyz[3 * o]	   = src[0];
@@ -795,7 +796,7 @@ __global__ __launch_bounds__(256) void retrieve_kernel(GridCfg cfg, int nch, con
 				for(int d = 0; d < 9; ++d) state9[9 * o + d] = src[3 + d];
 			}
 		}
-		if(logjp) logjp[o] = nch == 16 ? src[12] : 0.f;
+		if(logjp) logjp[o] = nch == 13 ? bin[kBin * recf + (sp & 63)] : 0.f;
 	}
 }
 
