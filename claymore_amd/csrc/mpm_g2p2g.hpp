@@ -287,6 +287,85 @@ MPM_DEV void p2g_serial(float4* __restrict__ arena, bool pending, int code, cons
 	}
 }
 
+// Deferred variant of p2g_serial (round 3, MPM_SERIAL_QUEUE): the lanes that cannot take the chain park their payload in a small LDS
+// queue (16 dwords per particle: no round trip, the stores are fire-and-forget) and the queue is worked off once per block, after
+// the particle loop - or when it is full -, two particles per step as above.  Per pair the payload then comes from four broadcast
+// ds_read_b128 (all lanes of a half read the same entry) instead of 17 ds_bpermute, and consecutive pairs are independent up to the
+// read-modify-write itself, so their loads and arithmetic overlap; issued inside the particle loop every pair was an exposed
+// bpermute -> arithmetic -> LDS round trip (0.28 of 2.15 ms in the flow window of C3 for 3.6 % of the particles).
+#ifndef MPM_SERIAL_QUEUE
+#define MPM_SERIAL_QUEUE 1
+#endif
+constexpr int kSerialQueue = 28;// entries of 64 B: 10.8 + 1.8 KB of LDS per wave, still 12 single-wave workgroups per CU
+MPM_DEV void serial_flush(float4* __restrict__ arena, const float4* __restrict__ queue, int qn, float mass, int lane, int info, float* __restrict__ next_grid) {
+	__asm__ volatile("" : "+v"(lane));
+	const int l	   = lane & 31;
+	const int half = lane >> 5;
+	const int oi = l / 9, oj = (l / 3) % 3, ok = l % 3;
+	const float fi = (float) oi, fj = (float) oj, fk = (float) ok;
+	float4* const my_arena = arena + half * kP2GNodes;
+	for(int e = 0; e < qn; e += 2) {
+		const bool live	 = e + half < qn;
+		const float4* en = queue + 4 * (live ? e + half : e);
+		const float4 q0 = en[0], q1 = en[1], q2 = en[2], q3 = en[3];
+		const float fd[3] = {q0.x, q0.y, q0.z};
+		const int cd	  = __float_as_int(q0.w);
+		const int nx = cd & 15, ny = (cd >> 4) & 15, nz = cd >> 8;
+		float w[3][3];
+#pragma unroll
+		for(int d = 0; d < 3; ++d) bspline_weight_cells(fd[d], w[d]);
+		const float wx = oi == 0 ? w[0][0] : (oi == 1 ? w[0][1] : w[0][2]);
+		const float wy = oj == 0 ? w[1][0] : (oj == 1 ? w[1][1] : w[1][2]);
+		const float wz = ok == 0 ? w[2][0] : (ok == 1 ? w[2][1] : w[2][2]);
+		const float W  = wx * wy * wz;
+		const float px = fi - fd[0], py = fj - fd[1], pz = fk - fd[2];
+		const float v0 = mass * W;
+		const float v1 = (q1.x + q1.w * px + q2.z * py + q3.y * pz) * W;// mv[0] + c[0] px + c[3] py + c[6] pz
+		const float v2 = (q1.y + q2.x * px + q2.w * py + q3.z * pz) * W;// mv[1] + c[1] px + c[4] py + c[7] pz
+		const float v3 = (q1.z + q2.y * px + q3.x * py + q3.w * pz) * W;// mv[2] + c[2] px + c[5] py + c[8] pz
+		const int gx = nx + oi, gy = ny + oj, gz = nz + ok;// cube coordinates 0..7
+		const bool inside = ((unsigned) (gx - 1) < 6u) & ((unsigned) (gy - 1) < 6u) & ((unsigned) (gz - 1) < 6u);
+		const int nb	  = __shfl(info, 54 + ((gx >> 2) & 1) * 4 + ((gy >> 2) & 1) * 2 + ((gz >> 2) & 1));
+		if(l < 27 && live) {
+			if(inside) {
+				float4* node	 = my_arena + (gx - 1) * kP2GStrideX + (gy - 1) * kP2GStrideY + (gz - 1);
+				const float4 acc = *node;
+				*node			 = make_float4(acc.x + v0, acc.y + v1, acc.z + v2, acc.w + v3);
+			} else if(nb >= 0) {
+				float* g = next_grid + (size_t) nb * 256 + (gx & 3) * 16 + (gy & 3) * 4 + (gz & 3);
+				unsafeAtomicAdd(g, v0);
+				unsafeAtomicAdd(g + 64, v1);
+				unsafeAtomicAdd(g + 128, v2);
+				unsafeAtomicAdd(g + 192, v3);
+			}
+		}
+		__asm__ volatile("" ::: "memory");// the next pair may hit the same nodes: keep the LDS operations in program order
+	}
+}
+// park the payloads of the `pending` lanes; qn (wave-uniform) = entries in the queue
+MPM_DEV void serial_push(float4* __restrict__ arena, float4* __restrict__ queue, int& qn, bool pending, int code, const P2GPayload& pl, float mass, int lane, int info, float* __restrict__ next_grid) {
+	unsigned long long todo = __ballot(pending);
+	while(todo) {
+		const int room = kSerialQueue - qn;
+		const int rank = (int) __builtin_amdgcn_mbcnt_hi((unsigned) (todo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) todo, 0u));
+		const bool mine = ((todo >> lane) & 1ull) != 0ull && rank < room;
+		if(mine) {
+			float4* en = queue + 4 * (qn + rank);
+			en[0]	   = make_float4(pl.fd[0], pl.fd[1], pl.fd[2], __int_as_float(code));
+			en[1]	   = make_float4(pl.mv[0], pl.mv[1], pl.mv[2], pl.contrib[0]);
+			en[2]	   = make_float4(pl.contrib[1], pl.contrib[2], pl.contrib[3], pl.contrib[4]);
+			en[3]	   = make_float4(pl.contrib[5], pl.contrib[6], pl.contrib[7], pl.contrib[8]);
+		}
+		qn += min(__popcll(todo), room);
+		todo &= ~__ballot(mine);
+		__asm__ volatile("" ::: "memory");
+		if(todo) {// the queue is full: work it off now
+			serial_flush(arena, queue, qn, mass, lane, info, next_grid);
+			qn = 0;
+		}
+	}
+}
+
 // The P2G scatter of one particle per lane as a chain of 27 ordered LDS read-modify-write steps that is threaded through
 // unrelated register-only arithmetic: the NEXT particle's F update, eigen-decomposition and material model, a latency-
 // bound dependent VALU stream itself (a dependent VALU instruction issues every ~9 cycles).  Each step is an LDS round
@@ -403,6 +482,9 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 										   // copy, odd lanes the second: the sort puts two particles of one key that share a slice
 										   // into neighbouring lanes, so both scatter in the same pass (summed in the write-back)
 	__shared__ unsigned char s_owner[2 * 216];
+	// (not for the J-fluid: its instantiation runs at four waves per SIMD and 14 workgroups per CU, which the queue's LDS would cost)
+	constexpr bool kQueue = MPM_SERIAL_QUEUE && MAT != 0;
+	__shared__ float4 s_queue[kQueue ? 4 * kSerialQueue : 1];// payloads of the lanes that could not take the scatter chain (serial_push / serial_flush)
 #ifdef MPM_LDS_PAD
 	__shared__ float s_pad[MPM_LDS_PAD / 4];// experiment: lower the occupancy without touching the code
 	if(size_t(grid) == 1) s_pad[threadIdx.x] = 0.f;
@@ -498,6 +580,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 	// update of iteration i; `pv` is the payload in flight, pv_code its stencil base (-1: none).
 	P2GPayload pv;
 	int pv_code = -1;
+	int qn = 0;// entries in s_queue (wave-uniform)
 #ifdef MPM_G2P2G_STATS
 	int st_iter = 0, st_losers = 0, st_edge = 0, st_retry_iters = 0, st_partial = 0;
 #endif
@@ -696,7 +779,17 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 				st_retry_iters += __any(left) ? 1 : 0;
 			}
 #endif
-			if(__any(left)) p2g_serial(p2g, left, pv_code, pv, mass, lane, info, next_grid);
+#ifdef MPM_HACK_NOSERIAL// timing experiment only: claim losers and edge lanes are dropped (wrong physics)
+			if(false)
+#else
+			if(__any(left))
+#endif
+			{
+				if constexpr(kQueue)
+					serial_push(p2g, s_queue, qn, left, pv_code, pv, mass, lane, info, next_grid);
+				else
+					p2g_serial(p2g, left, pv_code, pv, mass, lane, info, next_grid);
+			}
 		}
 		if(drain) break;
 		MPM_MARK("L_handoff");
@@ -724,6 +817,9 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		atomicAdd(&status[28], st_partial);
 	}
 #endif
+	if constexpr(kQueue) {
+		if(qn) serial_flush(p2g, s_queue, qn, mass, lane, info, next_grid);
+	}
 	__syncthreads();
 	// ---- arena -> next grid: one hardware f32 atomic per touched node and channel (:907-936).  Lane = cell of one of the
 	//      eight grid blocks, like the staging above: every atomic instruction covers (27 cells of) ONE 256-B channel row.
