@@ -838,7 +838,12 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		const int n	  = in ? ax * kP2GStrideX + ay * kP2GStrideY + az : 0;
 		const float4 va = p2g[n], vb = p2g[kP2GNodes + n];
 		const float4 v	= make_float4(va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w);
-		if(in && nb >= 0) {
+#ifdef MPM_HACK_NOWB// timing experiment only: no write-back of the arenas (wrong physics)
+		if(size_t(next_grid) == 1)
+#else
+		if(in && nb >= 0)
+#endif
+		{
 			float* g = next_grid + (size_t) nb * 256 + lane_wb;
 			if(v.x != 0.f) unsafeAtomicAdd(g, v.x);
 			if(v.y != 0.f) unsafeAtomicAdd(g + 64, v.y);

@@ -19,7 +19,7 @@ pmc() { # name, counters (quoted), bench args...
   rm -rf /tmp/pmc_$name
   timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_$name -o p -- python $R/bench.py --no-cpu-baseline --flow-start 0 "$@" > /dev/null 2>&1
   echo "# rocprofv3 --kernel-trace --pmc $ctr -- python bench.py --no-cpu-baseline --flow-start 0 $*" >> $O/${name}_pmc.txt
-  python $R/tools/rocpd_summary.py /tmp/pmc_$name/p_results.db | grep -E "g2p2g|carry_grid|prepare_blocks|grid_update|substep_clear|compact_blocks|register_blocks" >> $O/${name}_pmc.txt 2>&1
+  python $R/tools/rocpd_summary.py /tmp/pmc_$name/p_results.db $LAST | grep -E "g2p2g|carry_grid|prepare_blocks|grid_update|substep_clear|compact_blocks|register_blocks" >> $O/${name}_pmc.txt 2>&1
   rm -rf /tmp/pmc_$name
 }
 SQA="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
@@ -30,10 +30,12 @@ pmc c3_default "WRITE_SIZE" --steps 3 --warmup 2
 pmc c3_default "$SQA" --steps 3 --warmup 2
 pmc c3_default "$SQB" --steps 3 --warmup 2
 trace c3_moving --start-step 3000 --steps 100 --warmup 10
+LAST="--last 5"   # counters of the flow window only (the 5 launches after the 3000 untimed substeps), not of the ramp into it
 pmc c3_moving "FETCH_SIZE" --start-step 3000 --steps 3 --warmup 2
 pmc c3_moving "WRITE_SIZE" --start-step 3000 --steps 3 --warmup 2
 pmc c3_moving "$SQA" --start-step 3000 --steps 3 --warmup 2
 pmc c3_moving "$SQB" --start-step 3000 --steps 3 --warmup 2
+LAST=""
 if [ "$1" = "all" ]; then
   trace c2_fc --scene sphere5m
   pmc c2_fc "$SQA" --scene sphere5m --steps 3 --warmup 2

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 rocpd (.db) result: per-kernel time stats and, if present, PMC counter sums per kernel.
-Usage: python tools/rocpd_summary.py results.db [> profiles/xyz.txt]"""
+Usage: python tools/rocpd_summary.py results.db [--last N] [> profiles/xyz.txt]
+--last N: the PMC section covers only the last N dispatches of each kernel (a window at the end of a long run)."""
 import sqlite3
 import sys
 
@@ -10,7 +11,7 @@ def short(name):
     return name if len(name) < 70 else name[:67] + "..."
 
 
-def main(path):
+def main(path, last=0):
     db = sqlite3.connect(path)
     c = db.cursor()
     print(f"# {path}")
@@ -25,7 +26,17 @@ def main(path):
     for r in regs:
         print(f"{short(r[0]):70s} {r[1]} {r[2]} {r[3]} {r[4]} {r[5]} {r[6]}")
     try:
-        pm = c.execute("select k.name, p.counter_name, count(*), sum(p.value), avg(p.value) from counters_collection p join kernels k on k.dispatch_id = p.dispatch_id group by k.name, p.counter_name order by k.name").fetchall()
+        if last > 0:
+            pm = []
+            for (kname,) in c.execute("select distinct name from kernels").fetchall():
+                ids = [r[0] for r in c.execute("select dispatch_id from kernels where name = ? order by dispatch_id desc limit ?", (kname, last)).fetchall()]
+                q = ",".join(str(i) for i in ids)
+                pm += c.execute(f"select ?, p.counter_name, count(*), sum(p.value), avg(p.value) from counters_collection p where p.dispatch_id in ({q}) group by p.counter_name", (kname,)).fetchall()
+                t = c.execute(f"select count(*), avg(duration) from kernels where dispatch_id in ({q})").fetchone()
+                print(f"## last {last} dispatches: {short(kname):60s} n={t[0]} avg_ns={t[1]:.0f}")
+            pm.sort(key=lambda r: (r[0], r[1]))
+        else:
+            pm = c.execute("select k.name, p.counter_name, count(*), sum(p.value), avg(p.value) from counters_collection p join kernels k on k.dispatch_id = p.dispatch_id group by k.name, p.counter_name order by k.name").fetchall()
     except Exception as e:  # schema differences
         pm = []
         try:
@@ -40,4 +51,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[sys.argv.index("--last") + 1]) if "--last" in sys.argv else 0)
