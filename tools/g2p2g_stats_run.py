@@ -3,10 +3,15 @@ import numpy as np
 from claymore_amd import scenes
 from claymore_amd.engine import build_engine
 sc = scenes.sand_column(9)
-eng = build_engine(sc); eng.initial_setup()
+api = None
+if len(sys.argv) > 1:   # an engine library built with -DMPM_G2P2G_STATS (tools/build_variant.sh stats -DMPM_G2P2G_STATS)
+    import ctypes as C, os
+    from claymore_amd import _ffi
+    api = _ffi.bind(C.CDLL(os.path.abspath(sys.argv[1]), mode=os.RTLD_LOCAL | os.RTLD_NOW), "mpm_", hip=True)
+eng = build_engine(sc, api=api); eng.initial_setup()
 prev = np.zeros(5)
 done = 0
-for upto in (10, 500, 1000, 2000, 3000, 3100):
+for upto in (10, 1000, 3000, 3100):
     eng.run_fixed(upto - done, 1e-4); done = upto
     d = eng.diagnostics(); cur = np.array([d.reserved[i] for i in range(4)] + [0], dtype=np.float64)
     # counters are int32 cumulative: use per-window deltas modulo 2^32

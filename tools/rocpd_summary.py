@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 rocpd (.db) result: per-kernel time stats and, if present, PMC counter sums per kernel.
 Usage: python tools/rocpd_summary.py results.db [--last N] [> profiles/xyz.txt]
---last N: the PMC section covers only the last N dispatches of each kernel (a window at the end of a long run)."""
+--last N [--skip K]: the PMC section covers only the last N dispatches of each kernel (a window at the end of a long run), after skipping the K most recent."""
 import sqlite3
 import sys
 
@@ -11,7 +11,7 @@ def short(name):
     return name if len(name) < 70 else name[:67] + "..."
 
 
-def main(path, last=0):
+def main(path, last=0, skip=0):
     db = sqlite3.connect(path)
     c = db.cursor()
     print(f"# {path}")
@@ -29,7 +29,7 @@ def main(path, last=0):
         if last > 0:
             pm = []
             for (kname,) in c.execute("select distinct name from kernels").fetchall():
-                ids = [r[0] for r in c.execute("select dispatch_id from kernels where name = ? order by dispatch_id desc limit ?", (kname, last)).fetchall()]
+                ids = [r[0] for r in c.execute("select dispatch_id from kernels where name = ? order by dispatch_id desc limit ? offset ?", (kname, last, skip)).fetchall()]
                 q = ",".join(str(i) for i in ids)
                 pm += c.execute(f"select ?, p.counter_name, count(*), sum(p.value), avg(p.value) from counters_collection p where p.dispatch_id in ({q}) group by p.counter_name", (kname,)).fetchall()
                 t = c.execute(f"select count(*), avg(duration) from kernels where dispatch_id in ({q})").fetchone()
@@ -51,4 +51,4 @@ def main(path, last=0):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[sys.argv.index("--last") + 1]) if "--last" in sys.argv else 0)
+    main(sys.argv[1], int(sys.argv[sys.argv.index("--last") + 1]) if "--last" in sys.argv else 0, int(sys.argv[sys.argv.index("--skip") + 1]) if "--skip" in sys.argv else 0)
