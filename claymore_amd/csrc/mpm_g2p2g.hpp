@@ -526,10 +526,11 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 	const int tag_shift = cfg.pid_bits + kKeyBits;
 	// ---- round trip 2: the block's row of look-up results and the records of the first two iterations
 	const int info = mv.blockinfo[(size_t) b * kInfoRow + lane];
-	// (sliced list layout, mpm_kernels.hpp: every slot of a slice holds a record or a hole = a flagged copy of a record, bit 31)
-	const int rec_cur = list[lane];
-	int rec_next	  = list[(64 < size ? 64 : 0) + lane];
-	unsigned long long act_cur = __ballot(rec_cur >= 0);// lanes of the coming iteration that carry a particle
+	// (sliced list layout, mpm_kernels.hpp: a 64-slot slice holds its records in its first slots; idle lanes re-read the last one)
+	int cnt_cur	   = slice_records_at(size, 0);
+	int cnt_next   = 64 < size ? slice_records_at(size, 64) : 1;
+	int rec_cur	   = list[min(lane, cnt_cur - 1)];
+	int rec_next   = list[(64 < size ? 64 : 0) + min(lane, cnt_next - 1)];
 	// (`info` stays in its register: lane l < 27 holds the bin offset of source block l, lanes 27..53 the destination block
 	//  numbers, lanes 54..61 the eight grid blocks; they are read with __shfl = ds_bpermute, which costs no LDS space)
 	for(int i = lane; i < 2 * kP2GNodes; i += 64) p2g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		gv[lb].w = gv[lb].z;
 	}
 	// Software prefetch: the particle data of iteration i+1 is requested at the top of iteration i (HBM latency under load
-	// is 2-4 us).  The loads are unconditional - a hole re-reads a record of its slice - so that the
+	// is 2-4 us).  The loads are unconditional - lanes past the end of the block re-read its last record - so that the
 	// compiler can count them in s_waitcnt; their arrival is implied by the list-append atomics' results being consumed
 	// at the end of the iteration (memory operations return in order).
 	struct Prefetch {
@@ -594,7 +595,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		int ncode	  = -1;
 		if(!drain) {
 		MPM_MARK("L_top");
-		const bool active = ((act_cur >> lane) & 1ull) != 0ull;
+		const bool active = lane < cnt_cur;
 #ifdef MPM_G2P2G_STATS
 		st_partial += __popcll(__ballot(!active));
 #endif
@@ -615,12 +616,14 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 			if constexpr(NCH > REC) st[9] = pf.lj;
 		}
 		const int slot_nn = idx0 + 128 < size ? idx0 + 128 : 0;
-		const int rec_nn  = list[slot_nn + lane];
+		const int cnt_nn  = idx0 + 128 < size ? slice_records_at(size, idx0 + 128) : 1;
+		const int rec_nn  = list[slot_nn + min(lane, cnt_nn - 1)];
 		// the next iteration's particle record is requested a whole iteration ahead: record loads of 64 scattered 64-B sectors
 		// take long to return, and at three waves per SIMD the 16 registers are there
 		fetch(rec_next, pf);
-		act_cur	 = __ballot(rec_next >= 0);
 		rec_next = rec_nn;
+		cnt_cur			   = cnt_next;
+		cnt_next		   = cnt_nn;
 		MPM_MARK("L_gather");
 		// ---- stencil base + weights (:774-797) for ALL lanes (idle lanes of a last partial iteration carry a dummy
 		//      position inside the block); offsets in cell units (exact: dx is a power of two)

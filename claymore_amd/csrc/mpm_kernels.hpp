@@ -132,14 +132,12 @@ __device__ __forceinline__ int block_append(int* counter, int amount) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Layout of a block's advection list after prepare_blocks_kernel: ceil(size / 64) slices of 64 slots, one G2P2G iteration each
-// (lane = slot); a slot holds a record or a HOLE - bit 31 set, the other bits a copy of a record of the same slice, so that the
-// iteration's unconditional loads stay harmless.  A block of at most kListChunk records is laid out by the sticky rule (round 3,
-// prepare_blocks_kernel); a larger one is cut into chunks of kListChunk records, chunk c occupying slots [512 c, 512 c + n): S =
-// ceil(n / 64) slices, slice s holding n / S + (s < n % S) records in its first slots, records of one sort key in consecutive
-// slices (wrap-around rule), so that a slice holds a key twice only if the key has more than S particles.
+// Layout of a block's advection list after prepare_blocks_kernel.  The list is cut into chunks of kListChunk slots
+// (records [512 c, 512 c + n) of the block); a chunk with n records is laid out as S = ceil(n / 64) slices of 64 slots
+// (one G2P2G iteration each), slice s holding n / S + (s < n % S) records in its first slots: records of one sort key go
+// to consecutive slices (wrap-around rule), so a slice holds a key twice only if the key has more than S particles.
+// The slots behind a slice's records are holes (never read); a block still occupies ceil(size / 64) * 64 slots.
 // ------------------------------------------------------------------------------------------------------
-constexpr int kListHole = (int) 0x80000000u;
 constexpr int kListChunk = 512;
 __device__ __forceinline__ int div_small(int n, int d) {// n / d for 0 <= n <= 512, 1 <= d <= 8 (exact, checked exhaustively)
 	return (n * ((65536 + d - 1) / d)) >> 16;
@@ -152,11 +150,22 @@ __device__ __forceinline__ int slice_records(int n, int s) {// records in slice 
 	const int q = div_small(n, S);
 	return q + (s < n - q * S ? 1 : 0);
 }
-// index (in slice-major order) of the first record of slice sl of a chunk with n records
-__device__ __forceinline__ int chunk_first(int n, int sl) {
+// slot of the i-th record (in slice-major order) of a chunk with n records
+__device__ __forceinline__ int chunk_slot(int n, int i) {
 	const int S = (n + 63) >> 6;
 	const int q = div_small(n, S), r = n - q * S;
-	return sl * q + min(sl, r);
+	const int big = r * (q + 1);
+	if(i < big) {
+		const int sl = i / (q + 1);
+		return sl * 64 + (i - sl * (q + 1));
+	}
+	const int j = i - big, sl = j / q;
+	return (r + sl) * 64 + (j - sl * q);
+}
+// number of records in the 64-slot slice that starts at slot idx0 of a block with `size` particles
+__device__ __forceinline__ int slice_records_at(int size, int idx0) {
+	const int chunk = idx0 / kListChunk;
+	return slice_records(chunk_records(size, chunk), (idx0 >> 6) & (kListChunk / 64 - 1));
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -261,28 +270,18 @@ __global__ __launch_bounds__(64) void pack_lists_kernel(int ppb, const int* __re
 	const int b = blockIdx.x;
 	const int n = size[b];
 	const int* row = list + (size_t) row_of[b] * ppb;
-	int done	   = 0;// the records of the block in slot order, holes skipped
-	for(int q0 = 0; q0 < ((n + 63) & ~63); q0 += 64) {
-		const int rec				= row[q0 + threadIdx.x];
-		const unsigned long long m = __ballot(rec >= 0);
-		if(rec >= 0) packed[offset[b] + done + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = rec;
-		done += __popcll(m);
+	for(int i = threadIdx.x; i < n; i += 64) {
+		const int chunk = i / kListChunk;
+		packed[offset[b] + i] = row[chunk * kListChunk + chunk_slot(chunk_records(n, chunk), i - chunk * kListChunk)];
 	}
 }
 __global__ __launch_bounds__(64) void unpack_lists_kernel(int ppb, const int* __restrict__ size, int* __restrict__ row_of, const long long* __restrict__ offset, int* __restrict__ list, const int* __restrict__ packed) {
 	const int b = blockIdx.x;
 	const int n = size[b];
 	int* row	= list + (size_t) b * ppb;// rows are re-seated at their own block number
-	// balanced compact slices per chunk of kListChunk records, holes behind a slice's records (any layout is valid: the records say where
-	// the particle data is, the slot only decides where the next step writes it)
-	for(int c0 = 0; c0 < n; c0 += kListChunk) {
-		const int nc = min(kListChunk, n - c0);
-		for(int sl = 0; sl * 64 < nc; ++sl) {
-			const int cnt	= slice_records(nc, sl);
-			const int first = chunk_first(nc, sl);
-			const int src	= packed[offset[b] + c0 + first + min((int) threadIdx.x, cnt - 1)];
-			row[c0 + sl * 64 + threadIdx.x] = (int) threadIdx.x < cnt ? src : (src | kListHole);
-		}
+	for(int i = threadIdx.x; i < n; i += 64) {
+		const int chunk = i / kListChunk;
+		row[chunk * kListChunk + chunk_slot(chunk_records(n, chunk), i - chunk * kListChunk)] = packed[offset[b] + i];
 	}
 	if(threadIdx.x == 0) row_of[b] = b;
 }
@@ -306,25 +305,16 @@ __device__ __forceinline__ void dir_components(int dir, int& dx, int& dy, int& d
 
 // ------------------------------------------------------------------------------------------------------
 // Per-block preparation for G2P2G, run once per substep after the partition rebuild with one wave per particle block:
-//  * the block's advection records are dealt IN PLACE to slices of 64 slots (one G2P2G iteration each) such that the 64 lanes of an
-//    iteration scatter to distinct stencil bases - the sort key is the base the particle is PREDICTED to have after the coming step
-//    (written into the record one step earlier from x + v dt, exact for > 99.9 % of the particles); two particles of one key may
-//    share a slice in lanes of different parity (the two scatter arenas of G2P2G) (replaces cell_bucket_to_block, mgmpm_kernels.cuh:70-84).
-//    STICKY rule (round 3): a particle that stayed in the block keeps the slot it was processed - and its data written - in one step
-//    earlier, unless a particle of the same key and lane parity already holds its slice; only the others (newcomers from neighbouring
-//    blocks, evicted ones: a few per cent in a flow) are dealt to the free slots.  The 64 lanes of an iteration then read the records
-//    that the same lanes wrote: whole cache lines.  The full counting sort used before (kept for blocks of more than 512 particles)
-//    re-dealt every record whenever any key count changed: each lane read a record from a random slot of the block, 48 B out of
-//    two 64-B sectors, and G2P2G fetched 5.0 GB per launch in the flow window of C3 against 2.5 GB at rest;
+//  * the block's advection records are counting-sorted IN PLACE into "k-th particle of every key" order, the key being the
+//    stencil base the particle is PREDICTED to have after the coming step (written into the record one step earlier from
+//    x + v dt, exact for > 99.9 % of the particles): the 64 lanes of a G2P2G iteration then scatter to 64 distinct
+//    stencil bases (replaces cell_bucket_to_block, mgmpm_kernels.cuh:70-84);
 //  * the 27 source-block bin offsets, the 27 destination block numbers and the 8 grid-block numbers the block will need are
 //    looked up in the two dense tables and written as one 256-B row.
 // Both used to be the per-block prologue of g2p2g_kernel.  There they were a chain of dependent LDS / global round trips
 // executed at 2 waves per SIMD (the register budget of the main loop); here the same work runs at full occupancy, and
 // G2P2G starts its first particle fetch two round trips earlier.
 // ------------------------------------------------------------------------------------------------------
-#ifndef MPM_STICKY_SLOTS
-#define MPM_STICKY_SLOTS 0// A/B switch: 1 = sticky slot rule for blocks of at most 512 particles (see above; measured: no gain), 0 = full counting sort of every block in every substep
-#endif
 constexpr int kInfoRow = 64;// ints per block: [0,27) source bin offsets, [27,54) destination block numbers, [54,62) grid blocks
 struct PrepareModels {
 	int n;
@@ -343,9 +333,7 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 	// records are sorted in chunks of 512 (8 per lane): every 64-slot slice of a chunk is one G2P2G iteration
 	constexpr int kPrepChunk = kListChunk;
 	__shared__ int s_sorted[kPrepChunk];
-	__shared__ int s_cnt[256];// per key (216 used): count, then first position of the key in key-major order (sticky rule: slices x parities the key occupies)
-	__shared__ unsigned short s_free[kPrepChunk];// sticky rule: the free slots
-	__shared__ int s_home[kPrepChunk];			 // ... the records that need one
+	__shared__ int s_cnt[256];// per key (216 used): count, then first position of the key in key-major order
 	const int lane = threadIdx.x;
 	if(publish && blockIdx.x == 0 && lane == 0) {
 		const int ebc	 = publish[ST_CNT_P] + publish[ST_CNT_N] + publish[ST_CNT_E];
@@ -428,95 +416,12 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 			__syncthreads();
 #pragma unroll
 			for(int it = 0; it < NIT; ++it)
-				if(it < S) list[chunk0 + it * 64 + lane] = lane < slice_records(nrec, it) ? s_sorted[it * 64 + lane] : (s_sorted[it * 64] | kListHole);
+				if(it < S && lane < slice_records(nrec, it)) list[chunk0 + it * 64 + lane] = s_sorted[it * 64 + lane];
 			__syncthreads();
 		};
-		auto sticky = [&](int nrec) -> bool {
-			const int S = (nrec + 63) >> 6, M = S * 64;
-#pragma unroll
-			for(int q = 0; q < 4; ++q) s_cnt[lane + 64 * q] = 0;
-#pragma unroll
-			for(int it = 0; it < NIT; ++it) s_sorted[it * 64 + lane] = -1;
-			__syncthreads();
-			// phase 1: every particle that stayed in the block claims the slot it was processed in (the slots of two stayers differ),
-			// provided its key is new to that slice and lane parity
-			unsigned homeless = 0u;
-#pragma unroll
-			for(int it = 0; it < NIT; ++it) {
-				if(it * 64 + lane < nrec) {
-					const unsigned rec = recs[it] & rec_mask;
-					const int sp	   = (int) (rec & (unsigned) (cfg.ppb - 1));
-					bool ok			   = ((rec >> tag_shift) & 31u) == (unsigned) kStay && sp < M;
-					if(ok) {
-						const int bit = 1 << (2 * (sp >> 6) + (sp & 1));
-						ok			  = (atomicOr(&s_cnt[(rec >> key_shift) & 255], bit) & bit) == 0;
-						if(ok) s_sorted[sp] = (int) rec;
-					}
-					if(!ok) homeless |= 1u << it;
-				}
-			}
-			__syncthreads();
-			// (a block most of whose records are homeless - after set-up, after a restart, when many keys changed at once - is sorted from
-			//  scratch: the greedy placement below cannot untangle a full block, the counting sort leaves no conflict behind)
-			{
-				int nh = __popc(homeless);
-#pragma unroll
-				for(int off = 32; off > 0; off >>= 1) nh += __shfl_xor(nh, off);
-				if(nh * 4 > nrec) return false;
-			}
-			// phase 2: the free slots and the records without one, as lists (slot order / list order)
-			int nfree = 0, nhome = 0;
-#pragma unroll
-			for(int it = 0; it < NIT; ++it) {
-				const int q					= it * 64 + lane;
-				const bool is_free			= q < M && s_sorted[q] == -1;
-				const unsigned long long mf = __ballot(is_free);
-				if(is_free) s_free[nfree + __popcll(mf & ((1ull << lane) - 1ull))] = (unsigned short) q;
-				nfree += __popcll(mf);
-				const bool is_home			= (homeless >> it) & 1u;
-				const unsigned long long mh = __ballot(is_home);
-				if(is_home) s_home[nhome + __popcll(mh & ((1ull << lane) - 1ull))] = (int) (recs[it] & rec_mask);
-				nhome += __popcll(mh);
-			}
-			__syncthreads();
-			// phase 3: each record tries a few free slots for one whose slice and parity do not hold its key yet; round t of record h looks at
-			// free slot h + t * nhome (distinct records, distinct slots within a round); whoever finds none takes the next free slot there is
-			for(int h = lane; h < nhome; h += 64) {
-				const int rec = s_home[h];
-				const int key = (rec >> key_shift) & 255;
-				bool placed	  = false;
-				for(int t = 0; t < 6 && !placed; ++t) {
-					const int q = s_free[(h + t * nhome) % nfree];
-					if(s_sorted[q] != -1) continue;
-					const int bit = 1 << (2 * (q >> 6) + (q & 1));
-					if(atomicOr(&s_cnt[key], bit) & bit) continue;
-					placed = atomicCAS(&s_sorted[q], -1, rec) == -1;
-					if(!placed) atomicAnd(&s_cnt[key], ~bit);
-				}
-				for(int t = 0; t < nfree && !placed; ++t) {// (nfree >= nhome: there is a slot for everyone)
-					const int q = s_free[(h + t) % nfree];
-					placed		= s_sorted[q] == -1 && atomicCAS(&s_sorted[q], -1, rec) == -1;
-				}
-			}
-			__syncthreads();
-			// write-back: a hole carries a copy of a record of its slice (every slice holds one: the other slices cannot take all records)
-#pragma unroll
-			for(int it = 0; it < NIT; ++it) {
-				if(it < S) {
-					const int v					= s_sorted[it * 64 + lane];
-					const unsigned long long mv = __ballot(v != -1);
-					const int fill				= __shfl(v, mv ? __ffsll((long long) mv) - 1 : 0);
-					list[it * 64 + lane]		= v != -1 ? v : (fill | kListHole);
-				}
-			}
-			__syncthreads();
-			return true;
-		};
-		if(!(size > 0 && size <= kPrepChunk && MPM_STICKY_SLOTS && sticky(size))) {
-			for(int chunk0 = 0; chunk0 < size; chunk0 += kPrepChunk) {
-				if(chunk0) load_chunk(chunk0, min(kPrepChunk, size - chunk0));
-				sort_chunk(chunk0, min(kPrepChunk, size - chunk0));
-			}
+		for(int chunk0 = 0; chunk0 < size; chunk0 += kPrepChunk) {
+			if(chunk0) load_chunk(chunk0, min(kPrepChunk, size - chunk0));
+			sort_chunk(chunk0, min(kPrepChunk, size - chunk0));
 		}
 		}
 		if constexpr(!SORT) {
@@ -869,8 +774,8 @@ __global__ __launch_bounds__(256) void retrieve_kernel(GridCfg cfg, int nch, con
 	const int kx = cur_keys[3 * b], ky = cur_keys[3 * b + 1], kz = cur_keys[3 * b + 2];
 	const int* list = list_in + (size_t) row_of[b] * cfg.ppb;
 	for(int pidib = threadIdx.x; pidib < ((n + 63) & ~63); pidib += blockDim.x) {
+		if((pidib & 63) >= slice_records_at(n, pidib & ~63)) continue;// a hole of the sliced list layout
 		const int rec = list[pidib];
-		if(rec < 0) continue;// a hole of the sliced list layout
 		int ox, oy, oz;
 		dir_components((rec >> (cfg.pid_bits + kKeyBits)) & 31, ox, oy, oz);
 		const int sp	 = rec & (cfg.ppb - 1);
