@@ -1,4 +1,5 @@
 #!/usr/bin/env bash
+# WARNING: this pass did not finish on the MI355X pool of round 3 (the first rocprofv3 run with TCC_EA0_* counters was still running after 15 minutes): bound it with a short timeout before trying again.
 # L2 (TCC) request mix of the C3 G2P2G launch at rest and in the flow window: reads / writes / atomics at the L2 and towards the fabric
 cd "$(dirname "$0")/.."
 R=$PWD
