@@ -303,6 +303,9 @@ def main():
                 return
             dst["traffic"] = w["traffic_bytes"]
             dst["traffic_source"] = f"profiles/r03_pmc.json[{window}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of g2p2g_kernel<2>, corrected as MI355X_MICROARCH.md prescribes)"
+            if window == "flow" and "traffic_bytes_low" in w:
+                # the x1.8 fetch calibration is that of a streaming kernel; the flow window reads scattered 48-B records, whose requests the counter tallies in full
+                dst["traffic_range"] = [w["traffic_bytes_low"], w["traffic_bytes"]]
             dst["algorithmic_bytes"] = n_rank * bpp
             if "valu_insts" in w:
                 # one wave-instruction serves 64 particles: instructions per particle (= per 64-particle iteration of a wave)

@@ -332,6 +332,9 @@ MPM_DEV void serial_flush(float4* __restrict__ arena, const float4* __restrict__
 				const float4 acc = *node;
 				*node			 = make_float4(acc.x + v0, acc.y + v1, acc.z + v2, acc.w + v3);
 			} else if(nb >= 0) {
+#ifdef MPM_HACK_NOSHELL// timing / traffic experiment only: the shell contributions of the serial path are dropped (wrong physics)
+				if(size_t(next_grid) != 1) continue;
+#endif
 				float* g = next_grid + (size_t) nb * 256 + (gx & 3) * 16 + (gy & 3) * 4 + (gz & 3);
 				unsafeAtomicAdd(g, v0);
 				unsafeAtomicAdd(g + 64, v1);

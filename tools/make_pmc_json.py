@@ -25,8 +25,9 @@ def window(path, particles):
     calib = carry["WRITE_SIZE"] / carry["FETCH_SIZE"]           # KiB written (= blocks carried) / KiB the fetch counter saw for the same blocks
     read = g["FETCH_SIZE"] * 1024 * calib
     write = g["WRITE_SIZE"] * 1024
-    return {"fetch_size_kib": g["FETCH_SIZE"], "write_size_kib": g["WRITE_SIZE"], "fetch_calibration": calib, "read_bytes": int(read), "write_bytes": int(write),
-            "traffic_bytes": int(read + write), "algorithmic_bytes": particles * 144, "valu_insts": g.get("SQ_INSTS_VALU"), "salu_insts": g.get("SQ_INSTS_SALU"),
+    raw = g["FETCH_SIZE"] * 1024
+    return {"fetch_size_kib": g["FETCH_SIZE"], "write_size_kib": g["WRITE_SIZE"], "fetch_calibration": calib, "read_bytes": int(read), "read_bytes_uncalibrated": int(raw), "write_bytes": int(write),
+            "traffic_bytes": int(read + write), "traffic_bytes_low": int(raw + write), "algorithmic_bytes": particles * 144, "valu_insts": g.get("SQ_INSTS_VALU"), "salu_insts": g.get("SQ_INSTS_SALU"),
             "lds_insts": g.get("SQ_INSTS_LDS"), "wave_cycles": g.get("SQ_WAVE_CYCLES"), "wait_any": g.get("SQ_WAIT_ANY"), "wait_inst_any": g.get("SQ_WAIT_INST_ANY"),
             "active_inst_any": g.get("SQ_ACTIVE_INST_ANY"), "lds_bank_conflict": g.get("SQ_LDS_BANK_CONFLICT"), "lds_idx_active": g.get("SQ_LDS_IDX_ACTIVE")}
 
@@ -34,7 +35,9 @@ def window(path, particles):
 def main(src, dst):
     n = 40108032
     out = {"_comment": "g2p2g_kernel<2> per launch on C3 (40 108 032 sand particles, 512^3), MI355X; rocprofv3 --pmc passes of tools/gpu_profile_r03.sh "
-                       "(profiles/r03_c3_default_pmc.txt, r03_c3_moving_pmc.txt); FETCH_SIZE calibrated on carry_grid_kernel of the same pass, WRITE_SIZE as reported",
+                       "(profiles/r03_c3_default_pmc.txt, r03_c3_moving_pmc.txt); FETCH_SIZE calibrated on carry_grid_kernel of the same pass (a streaming kernel: the counter tallies a "
+                       "128-B request as 64 B), WRITE_SIZE as reported.  The calibration holds for the rest window, whose record reads are streams; the flow window reads scattered 48-B records "
+                       "(64-B requests are tallied in full), so its true read volume lies between read_bytes_uncalibrated and read_bytes: traffic_bytes is an UPPER bound there, traffic_bytes_low the lower one",
            "kernel": "g2p2g_kernel<2>", "particles": n,
            "rest": window(f"{src}/c3_default_pmc.txt", n), "flow": window(f"{src}/c3_moving_pmc.txt", n)}
     json.dump(out, open(dst, "w"), indent=1)

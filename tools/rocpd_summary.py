@@ -29,7 +29,9 @@ def main(path, last=0, skip=0):
         if last > 0:
             pm = []
             for (kname,) in c.execute("select distinct name from kernels").fetchall():
-                ids = [r[0] for r in c.execute("select dispatch_id from kernels where name = ? order by dispatch_id desc limit ? offset ?", (kname, last, skip)).fetchall()]
+                ids = [r[0] for r in c.execute("select dispatch_id from kernels where name = ? order by dispatch_id desc", (kname,)).fetchall()][skip:skip + last]
+                if not ids:
+                    continue
                 q = ",".join(str(i) for i in ids)
                 pm += c.execute(f"select ?, p.counter_name, count(*), sum(p.value), avg(p.value) from counters_collection p where p.dispatch_id in ({q}) group by p.counter_name", (kname,)).fetchall()
                 t = c.execute(f"select count(*), avg(duration) from kernels where dispatch_id in ({q})").fetchone()
