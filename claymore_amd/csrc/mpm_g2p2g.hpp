@@ -566,9 +566,19 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		const float* bin  = mv.bins_src + (size_t) sbin * (kBin * NCH);
 		const float4* src = reinterpret_cast<const float4*>(bin + (sp & 63) * REC);
 		f.key			  = (rec >> key_shift) & 255;
+#ifdef MPM_NT_LOADS// A/B switch: streaming (non-temporal) record loads - every record is read once per step, it need not displace grid and list lines in L2
+		typedef float v4f_ __attribute__((ext_vector_type(4)));
+#pragma unroll
+		for(int d = 0; d < REC / 4; ++d) {
+			const v4f_ t = __builtin_nontemporal_load(reinterpret_cast<const v4f_*>(src) + d);
+			f.q[d]		 = make_float4(t.x, t.y, t.z, t.w);
+		}
+		if constexpr(NCH > REC) f.lj = __builtin_nontemporal_load(bin + kBin * REC + (sp & 63));
+#else
 #pragma unroll
 		for(int d = 0; d < REC / 4; ++d) f.q[d] = src[d];
 		if constexpr(NCH > REC) f.lj = bin[kBin * REC + (sp & 63)];
+#endif
 	};
 	Prefetch pf;
 	fetch(rec_cur, pf);
