@@ -278,7 +278,8 @@ int mpm_sync(mpm_ctx* ctx);
  * the caller only has to carry the 128-byte unique id from rank 0 to the other ranks (MPI, a file, torch.distributed ...).
  * mpm_group_create_local builds `world` handles in ONE process (contexts may share a device) on device-to-device copies:
  * single-GPU boxes, tests, and hosts that drive all GPUs from worker threads; its calls must be made concurrently, one
- * thread per rank.  HIP library only. */
+ * thread per rank.  The environment variable MPM_RCCL_LIBRARY names the collective library to load instead of the system's
+ * librccl.so (a differently built RCCL; the tests' in-process double, tests/rccl_double/).  HIP library only. */
 typedef struct mpm_group mpm_group;
 int mpm_group_unique_id(void* id128);
 int mpm_group_create(mpm_ctx* ctx, int rank, int world, const void* id128, mpm_group** out);
