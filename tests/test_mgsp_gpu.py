@@ -398,8 +398,9 @@ def test_group_substep_reports_this_ranks_max_velocity():
         assert all(3.9 < v < 4.2 for v in mv), mv                   # |v|^2 = 2^2 (+ a few mm/s of gravity)
 
 
-def _rccl_double_library(tmp_path_factory):
-    """Build tests/rccl_double/rccl_double.cpp (an in-process double of the RCCL calls the group driver binds) with hipcc."""
+@pytest.fixture(scope="session")
+def rccl_double_library(tmp_path_factory):
+    """Build tests/rccl_double/rccl_double.cpp (an in-process double of the RCCL calls the group driver binds) with hipcc, once per session."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -410,14 +411,13 @@ def _rccl_double_library(tmp_path_factory):
 
 
 @pytest.mark.parametrize("world,kind", [(2, "fixed"), (3, "substeps"), (4, "fixed"), (2, "adaptive")])
-def test_rccl_transport_with_several_ranks_through_the_rccl_double(world, kind, tmp_path_factory):
+def test_rccl_transport_with_several_ranks_through_the_rccl_double(world, kind, rccl_double_library):
     """The RCCL branch of the group driver with world > 1 (RCCL itself cannot host two ranks on one device, the box has one GPU):
     every rank a thread with its own context, mpm_group_create with a unique id, the grouped ncclSend / ncclRecv of the halo exchange,
     the ncclAllGather of the keys and the ncclAllReduce of the maximum velocity served by an in-process double loaded through
     MPM_RCCL_LIBRARY (tests/rccl_double/).  Runs in a subprocess (the library binds its collective library once per process)."""
     import subprocess
-    lib = _rccl_double_library(tmp_path_factory)
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, MPM_RCCL_LIBRARY=lib)
+    env = dict(os.environ, MPM_RCCL_LIBRARY=rccl_double_library)
     r = subprocess.run([sys.executable, os.path.join(here, "rccl_double", "run_group.py"), str(world), kind], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "OK world" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
