@@ -95,6 +95,7 @@ HALO = {
 SIGNATURES.update(HALO)
 # entry points only the HIP library has (stream plumbing + kernel timing)
 HIP_ONLY = {
+    "build_info": (C.c_char_p, []),
     "last_g2p2g_ms": (_i, [_vp, _fp]),
     "streams": (_i, [_vp, _P(_vp), _P(_vp)]),
     "sync": (_i, [_vp]),

@@ -17,6 +17,8 @@
 #include "mpm_kernels.hpp"
 
 using namespace mpm;
+#define MPM_STR_(x) #x
+#define MPM_STR(x) MPM_STR_(x)
 
 namespace {
 // ONE device block (and its pinned mirror) holds everything the host reads back at a synchronisation: the status words, the MGSP halo
@@ -340,7 +342,7 @@ int mpm_add_model(mpm_ctx* ctx, int material, const mpm_material_params* params,
 	m.material = material;
 	m.p		   = *params;
 	m.mc	   = make_material_const(*params);
-	m.nch	   = material == MPM_J_FLUID ? 4 : (material == MPM_FIXED_COROTATED ? 12 : 13);// floats per particle in a bin (mpm_g2p2g.hpp: 48-B records + a row of log Jp)
+	m.nch	   = material == MPM_J_FLUID ? 4 : (material == MPM_FIXED_COROTATED ? 9 : 10);// floats per particle in a bin (mpm_g2p2g.hpp: {x, y, z, J}, or a 32-B record {x, y, z, b...} + a row of b21 (+ log Jp))
 	m.n		   = n;
 	for(int d = 0; d < 3; ++d) m.v0[d] = v0 ? v0[d] : 0.f;
 	HIP_TRY(dalloc(&m.d_xyz, 3 * n));
@@ -598,11 +600,8 @@ static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, co
 	sk.pred = next_dt * g.dx_inv;
 	sk.am	= m.mc.mass * g.dx * g.dx * g.d_inv;
 	sk.cs	= next_dt * g.d_inv * g.dx;
-#ifdef MPM_G2P2G_NOLOOP
-	const int nwg = nblocks;
-#else
+	sk.refl_lim = sk.dts > 0.f ? (1.f / 3.f) / sk.dts : 3.0e38f;
 	const int nwg = nblocks_ptr ? hint_blocks(ctx, nblocks) : nblocks;
-#endif
 	switch(m.material) {
 		case MPM_J_FLUID: g2p2g_kernel<0><<<nwg, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, only_flag, nblocks_ptr, nblocks, dt, next_dt, sk, ctx->d_status); break;
 		case MPM_FIXED_COROTATED: g2p2g_kernel<1><<<nwg, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, only_flag, nblocks_ptr, nblocks, dt, next_dt, sk, ctx->d_status); break;
@@ -878,11 +877,7 @@ int mpm_run_fixed(mpm_ctx* ctx, int nsteps, float dt) {
 	if(!ctx || !ctx->ready) return MPM_ERR_NOT_READY;
 	HIP_TRY(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->s_compute;
-#ifdef MPM_G2P2G_NOLOOP
-	const int K = 1;
-#else
 	const int K = ctx->cfg.sync_interval > 0 ? std::min(ctx->cfg.sync_interval, 64) : 8;
-#endif
 	while((int) ctx->ev_ring.size() < 4 * K) {
 		hipEvent_t e = nullptr;
 		HIP_TRY(hipEventCreate(&e));
@@ -935,6 +930,43 @@ int mpm_run_fixed(mpm_ctx* ctx, int nsteps, float dt) {
 		ctx->timers.total_ms	   = (float) (acc_total / nsteps);
 	}
 	return MPM_OK;
+}
+
+const char* mpm_build_info(void) {
+	return "claymore_hip abi5 state=b"
+#ifdef MPM_EXPERIMENT
+		   " experiment=MPM_EXPERIMENT"
+#ifdef MPM_HACK_NOSHELL
+		   ",MPM_HACK_NOSHELL"
+#endif
+#ifdef MPM_HACK_NOSERIAL
+		   ",MPM_HACK_NOSERIAL"
+#endif
+#ifdef MPM_HACK_NOWB
+		   ",MPM_HACK_NOWB"
+#endif
+#ifdef MPM_HACK_UNDEF
+		   ",MPM_HACK_UNDEF"
+#endif
+#ifdef MPM_LDS_PAD
+		   ",MPM_LDS_PAD"
+#endif
+#ifdef MPM_G2P2G_STATS
+		   ",MPM_G2P2G_STATS"
+#endif
+#ifdef MPM_G2P2G_WAVES
+		   ",MPM_G2P2G_WAVES"
+#endif
+#ifdef MPM_G2P2G_WAVES_FLUID
+		   ",MPM_G2P2G_WAVES_FLUID"
+#endif
+#ifdef MPM_VARIANT
+		   ",MPM_VARIANT=" MPM_STR(MPM_VARIANT)
+#endif
+#else
+		   " experiment=none"
+#endif
+		;
 }
 
 int mpm_last_g2p2g_ms(mpm_ctx* ctx, float* ms) {
@@ -1116,7 +1148,7 @@ int mpm_test_stress(int material, const mpm_material_params* p, const float* F, 
 		HIP_TRY0(dL.alloc(n));
 		HIP_TRY0(hipMemcpy(dL.p, logjp, sizeof(float) * n, hipMemcpyHostToDevice));
 	}
-	test_stress_kernel<<<cdiv(n, 256), 256>>>(material, make_material_const(*p), n, dF.p, dL.p, dO.p);
+	test_stress_kernel<<<cdiv(n, 256), 256>>>(material, make_material_const(*p), n, dF.p, dL.p, dO.p, nullptr);
 	HIP_TRY0(hipGetLastError());
 	HIP_TRY0(hipMemcpy(out19, dO.p, sizeof(float) * 19 * n, hipMemcpyDeviceToHost));
 	return MPM_OK;

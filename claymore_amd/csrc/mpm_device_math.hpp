@@ -8,6 +8,19 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// ---- experiment switches ------------------------------------------------------------------------------------------
+// Every compile-time switch that changes what the kernels COMPUTE (timing hacks that leave a part of the physics out, A/B
+// variants of a formulation) is honoured only under -DMPM_EXPERIMENT, which no build of the product sets (__graft_entry__.build(),
+// tools/build_variant.sh without it); mpm_build_info() reports the switches a library was built with and tests/test_abi.py checks
+// that the shipped one has none.  A stray -DMPM_HACK_* without the guard does not compile.
+#if !defined(MPM_EXPERIMENT)
+#if defined(MPM_HACK_NOSHELL) || defined(MPM_HACK_NOSERIAL) || defined(MPM_HACK_NOWB) || defined(MPM_HACK_UNDEF) || defined(MPM_SCALAR_GS) || defined(MPM_GATHER_B96) || \
+	defined(MPM_NT_LOADS) || defined(MPM_LDS_PAD) || defined(MPM_G2P2G_NOLOOP) || defined(MPM_G2P2G_STATS) || defined(MPM_PRE_SITES) || defined(MPM_SERIAL_QUEUE) ||        \
+	defined(MPM_G2P2G_WAVES) || defined(MPM_G2P2G_WAVES_FLUID)
+#error "experiment switch without -DMPM_EXPERIMENT: a product library is built with none of them"
+#endif
+#endif
+
 namespace mpm {
 
 #define MPM_DEV __device__ __forceinline__
@@ -53,25 +66,52 @@ MPM_DEV void matmul3(const float (&a)[9], const float (&b)[9], float (&c)[9]) {
 		c[3 * j + 2]  = a[2] * b[3 * j] + a[5] * b[3 * j + 1] + a[8] * b[3 * j + 2];
 	}
 }
-// MatrixUtils.h:29-41: out = m1 * diag * m2^T
-MPM_DEV void mat_diag_matT(float (&out)[9], const float (&m1)[9], const float (&dg)[3], const float (&m2)[9]) {
-	const v2f_ c0 = {m1[0], m1[1]}, c1 = {m1[3], m1[4]}, c2 = {m1[6], m1[7]};
-#pragma unroll
-	for(int j = 0; j < 3; ++j) {
-		const float t0 = dg[0] * m2[j], t1 = dg[1] * m2[3 + j], t2 = dg[2] * m2[6 + j];
-		const v2f_ xy  = c0 * t0 + c1 * t1 + c2 * t2;
-		out[3 * j]	   = xy.x;
-		out[3 * j + 1] = xy.y;
-		out[3 * j + 2] = m1[2] * t0 + m1[5] * t1 + m1[8] * t2;
-	}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Particle state of the three solid models: the LEFT CAUCHY-GREEN tensor b = F F^T, not F.
+//
+// The reference carries the deformation gradient F (9 floats, particle_buffer.cuh:141-264) and every constitutive model on this
+// path starts with its SVD F = U S V^T (constitutive_models.cuh:36-335).  All of them are isotropic - elastic energy and yield
+// surface depend on the singular values only, the stress is P F^T = U diag(.) U^T, a projected F is U S_new V^T - so V never
+// reaches an output: positions, the grid and log Jp depend on F only through b = F F^T = U S^2 U^T, and b obeys its own update
+//     F <- (I + dt grad v) F            ==>   b <- G b G^T,  G = I + dt grad v          (:838-850 of mgmpm_kernels.cuh)
+//     F <- U S_new V^T  (projection)    ==>   b <- U diag(S_new^2) U^T
+// A particle therefore stores the six entries {b00, b11, b22, b10, b20, b21}: 24 B instead of 36 B, read and written once per
+// step in a launch whose time follows its bytes, and the per-particle arithmetic loses F F^T, the matrix product of
+// the projection and every branch that existed to recover V.  What b cannot carry is the SIGN of det F (a reflected F, which the
+// reference's SVD moves into the smallest singular value, svd.cuh:590-770): it is one bit, kept in the sign of b00 (> 0 otherwise)
+// and updated exactly - det(G F) = det G det F, and det G <= 0 needs an entry of dt grad v beyond 1/3 in magnitude (Gershgorin), which
+// a wave tests with one comparison per step.  The reference retrieves positions only (retrieve_particle_buffer, :1087-1122).
+// ---------------------------------------------------------------------------------------------------------------
+// b = F F^T of a column-major F (set-up of a model from given deformation gradients, the function-level tests)
+MPM_DEV void left_cauchy_green(const float (&F)[9], float (&b)[6]) {
+	b[0] = F[0] * F[0] + F[3] * F[3] + F[6] * F[6];
+	b[1] = F[1] * F[1] + F[4] * F[4] + F[7] * F[7];
+	b[2] = F[2] * F[2] + F[5] * F[5] + F[8] * F[8];
+	b[3] = F[1] * F[0] + F[4] * F[3] + F[7] * F[6];
+	b[4] = F[2] * F[0] + F[5] * F[3] + F[8] * F[6];
+	b[5] = F[2] * F[1] + F[5] * F[4] + F[8] * F[7];
 }
-// P F^T * volume (tail of constitutive_models.cuh:63-72)
-MPM_DEV void P_Ft_vol(const float (&P)[9], const float (&F)[9], float volume, float (&PF)[9]) {
-#pragma unroll
-	for(int j = 0; j < 3; ++j) {
-#pragma unroll
-		for(int i = 0; i < 3; ++i) PF[3 * j + i] = (P[i] * F[j] + P[3 + i] * F[3 + j] + P[6 + i] * F[6 + j]) * volume;
-	}
+MPM_DEV float det3(const float (&F)[9]) {
+	return F[0] * (F[4] * F[8] - F[7] * F[5]) + F[3] * (F[7] * F[2] - F[1] * F[8]) + F[6] * (F[1] * F[5] - F[4] * F[2]);
+}
+// o = G b G^T for a column-major G and a symmetric b: M = G b (rows 0 / 1 of a column packed), then the six entries of M G^T
+// (9 packed + 9 scalar, 3 packed + 12 scalar instructions: what F <- G F followed by F F^T cost before)
+MPM_DEV void push_forward(const float (&G)[9], const float (&b)[6], float (&o)[6]) {
+	const v2f_ g0 = {G[0], G[1]}, g1 = {G[3], G[4]}, g2 = {G[6], G[7]};
+	const v2f_ m0 = g0 * b[0] + g1 * b[3] + g2 * b[4];
+	const v2f_ m1 = g0 * b[3] + g1 * b[1] + g2 * b[5];
+	const v2f_ m2 = g0 * b[4] + g1 * b[5] + g2 * b[2];
+	const float z0 = G[2] * b[0] + G[5] * b[3] + G[8] * b[4];
+	const float z1 = G[2] * b[3] + G[5] * b[1] + G[8] * b[5];
+	const float z2 = G[2] * b[4] + G[5] * b[5] + G[8] * b[2];
+	const v2f_ c0 = m0 * G[0] + m1 * G[3] + m2 * G[6];// (00, 10)
+	o[0]		  = c0.x;
+	o[3]		  = c0.y;
+	o[4]		  = z0 * G[0] + z1 * G[3] + z2 * G[6];
+	o[1]		  = m0.y * G[1] + m1.y * G[4] + m2.y * G[7];
+	o[5]		  = z0 * G[1] + z1 * G[4] + z2 * G[7];
+	o[2]		  = z0 * G[2] + z1 * G[5] + z2 * G[8];
 }
 
 // v_rcp_f32 (1 ulp).  The reference binary is built with --use_fast_math (CMake-Utils/setup_cuda.cmake:50), i.e. with
@@ -84,18 +124,10 @@ MPM_DEV float rcp_fast(float x) {
 // (--use_fast_math turns logf / expf into lg2.approx / ex2.approx, CMake-Utils/setup_cuda.cmake:50).  Arguments on this
 // path are singular values in [1e-4, ~10] and log-strains of order 1: no denormals, no overflow.
 MPM_DEV float log_fast(float x) {
-#ifdef MPM_EXACT_LOGEXP
-	return logf(x);
-#else
 	return __builtin_amdgcn_logf(x) * 0.693147180559945f;
-#endif
 }
 MPM_DEV float exp_fast(float x) {
-#ifdef MPM_EXACT_LOGEXP
-	return expf(x);
-#else
 	return __builtin_amdgcn_exp2f(x * 1.442695040888963f);
-#endif
 }
 MPM_DEV float rsqrt_approx(float x) {
 	return __builtin_amdgcn_rsqf(x);// v_rsq_f32, ~1 ulp; the algorithm re-normalises (svd.cuh:210-215)
@@ -109,11 +141,11 @@ struct NoHook {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// Symmetric eigen-decomposition b = F F^T = U diag(lam) U^T by cyclic Jacobi with EXACT rotations.
+// Symmetric eigen-decomposition b = U diag(lam) U^T by cyclic Jacobi with EXACT rotations.
 //
 // Every constitutive model on this path only needs U and the singular values sigma_k = sqrt(lam_k) of F = U S V^T:
 //   * P F^T = U diag(P_hat_k sigma_k) U^T                                  (V cancels: V^T V = I)
-//   * a projected F_new = U S_new V^T = U diag(S_new_k / sigma_k) U^T F    (V^T = S^-1 U^T F)
+//   * a projected b_new = (U S_new V^T)(U S_new V^T)^T = U diag(S_new_k^2) U^T
 // so the reference's route (math::svd: Jacobi on F^T F for V, B = F V, Givens QR for U and S, svd.cuh:27-1123) is
 // replaced by the left-handed one, which skips B, the QR / column normalisation and the sort.  A rotation annihilates
 // s_pq exactly (t = tan(theta) from the stable quadratic root, one v_sqrt / v_rcp / v_rsq) instead of the reference's
@@ -149,30 +181,15 @@ MPM_DEV void jacobi_rot(float& spp, float& spq, float& sqq, float& srp, float& s
 	uq[2] = s * pz + c * qz;
 }
 
-#ifndef MPM_EIG_TOL
-#define MPM_EIG_TOL 1e-6f// sweeps stop once every off-diagonal entry of every lane is below this fraction of the smallest diagonal entry
-#endif
-#ifndef MPM_UNDEFORMED_EXIT
-#define MPM_UNDEFORMED_EXIT 1// A/B switch: 0 = the stress of an undeformed wave (F F^T = I) is computed like any other
-#endif
-#ifndef MPM_EIG_PRECHECK
-#define MPM_EIG_PRECHECK 1// A/B switch: 0 = always run the first sweep (round 2)
-#endif
+constexpr float kEigTol = 1e-6f;// sweeps stop once every off-diagonal entry of a lane is below this fraction of its smallest diagonal entry
 constexpr int kEigSites = 13;
-// undeformed (wave-uniform, out): F F^T is the identity for every lane of the wave - diagonal exactly 1, off-diagonals below the
-// tolerance - and F is a proper rotation near the identity (diagonal entries > 1/2, i.e. trace > 3/2: no reflection has that).  Such a
-// particle (free fall, rigid translation: the default window of the C3 bench) has zero stress in every model on this path, exactly,
-// and no plastic update: the stress functions return early.
+// b: {b00, b11, b22, b10, b20, b21}.
+// undeformed (wave-uniform, out): b is the identity for every lane of the wave - diagonal exactly 1, off-diagonals below the
+// tolerance.  Such a particle (free fall, rigid translation: the default window of the C3 bench) has zero stress in every model on
+// this path, exactly, and no plastic update: the stress functions return early (for lanes that carry no reflection).
 template<int BASE, class Hook>
-MPM_DEV void sym_eig3(const float (&F)[9], float (&lam)[3], float (&U)[9], Hook& hk, bool& undeformed) {
-	// b = F F^T (column-major F: F[3 j + i] = F_ij)
-	const v2f_ f01 = {F[0], F[1]}, f34 = {F[3], F[4]}, f67 = {F[6], F[7]};
-	const v2f_ f12 = {F[1], F[2]}, f45 = {F[4], F[5]}, f78 = {F[7], F[8]};
-	const v2f_ r0 = f01 * F[0] + f34 * F[3] + f67 * F[6];// (b11, b21)
-	const v2f_ r1 = f12 * F[1] + f45 * F[4] + f78 * F[7];// (b22, b32)
-	float s11 = r0.x, s21 = r0.y, s22 = r1.x, s32 = r1.y;
-	float s31 = F[2] * F[0] + F[5] * F[3] + F[8] * F[6];
-	float s33 = F[2] * F[2] + F[5] * F[5] + F[8] * F[8];
+MPM_DEV void sym_eig3(const float (&b)[6], float (&lam)[3], float (&U)[9], Hook& hk, bool& undeformed) {
+	float s11 = b[0], s22 = b[1], s33 = b[2], s21 = b[3], s31 = b[4], s32 = b[5];
 	float u1[3] = {1.f, 0.f, 0.f}, u2[3] = {0.f, 1.f, 0.f}, u3[3] = {0.f, 0.f, 1.f};
 	MPM_MARK("eig_jacobi");
 	hk.template at<BASE + 0>();
@@ -186,7 +203,7 @@ MPM_DEV void sym_eig3(const float (&F)[9], float (&lam)[3], float (&U)[9], Hook&
 	{                                                                                   \
 		const float off = fmaxf(fmaxf(fabsf(s21), fabsf(s31)), fabsf(s32));             \
 		const float dia = fminf(fminf(fabsf(s11), fabsf(s22)), fabsf(s33));             \
-		conv			= off <= MPM_EIG_TOL * dia;                                     \
+		conv			= off <= kEigTol * dia;                                         \
 		done			= __all(conv);                                                  \
 	}
 #define MPM_SWEEP(IT, LAST)                                                    \
@@ -204,15 +221,9 @@ MPM_DEV void sym_eig3(const float (&F)[9], float (&lam)[3], float (&U)[9], Hook&
 	}                                                                          \
 	hk.template at<BASE + 3 + 3 * IT>();
 	undeformed = false;
-#if MPM_EIG_PRECHECK
 	MPM_CONVERGED()
-#if MPM_UNDEFORMED_EXIT
-	if(done) undeformed = __all((s11 == 1.f) & (s22 == 1.f) & (s33 == 1.f) & (F[0] > 0.5f) & (F[4] > 0.5f) & (F[8] > 0.5f));
-#endif
-#else
-	done = conv = false;
-#endif
-#ifdef MPM_HACK_UNDEF// timing experiment only: every wave takes the undeformed exit (wrong physics)
+	if(done) undeformed = __all((s11 == 1.f) & (s22 == 1.f) & (s33 == 1.f));
+#if defined(MPM_EXPERIMENT) && defined(MPM_HACK_UNDEF)// timing experiment only: every wave takes the undeformed exit (wrong physics)
 	done = conv = undeformed = true;
 #endif
 	MPM_SWEEP(0, false)
@@ -233,87 +244,25 @@ MPM_DEV void sym_eig3(const float (&F)[9], float (&lam)[3], float (&U)[9], Hook&
 	}
 }
 
-MPM_DEV float det3(const float (&F)[9]) {
-	return F[0] * (F[4] * F[8] - F[7] * F[5]) + F[3] * (F[7] * F[2] - F[1] * F[8]) + F[6] * (F[1] * F[5] - F[4] * F[2]);
-}
-
-// The eigenvalues of F F^T carry an absolute error of ~1e-7 lam_max, i.e. no relative accuracy for a strongly compressed
-// direction.  Rare lanes with sigma_min < 1e-2 sigma_max recompute lam_k = |F^T u_k|^2 (accurate relative to lam_k itself)
-// and rebuild a projected F through V (rebuild_through_v) instead of dividing by sigma_k.
-MPM_DEV bool ill_conditioned(const float (&lam)[3]) {
-	return fminf(fminf(lam[0], lam[1]), lam[2]) < 1e-4f * fmaxf(fmaxf(lam[0], lam[1]), lam[2]);
-}
-MPM_DEV void refine_eigs(const float (&F)[9], const float (&U)[9], float (&lam)[3]) {
-#pragma unroll
-	for(int k = 0; k < 3; ++k) {
-		float n = 0.f;
-#pragma unroll
-		for(int j = 0; j < 3; ++j) {
-			const float g = F[3 * j] * U[3 * k] + F[3 * j + 1] * U[3 * k + 1] + F[3 * j + 2] * U[3 * k + 2];
-			n			  = fmaf(g, g, n);
-		}
-		lam[k] = n;
-	}
-}
-
-// out = U diag(d) U^T (symmetric): packed rows 0 / 1, 18 instructions
-MPM_DEV void sym_from_eig(const float (&U)[9], const float (&d)[3], float (&out)[9]) {
+// out = U diag(d) U^T as {00, 11, 22, 10, 20, 21}: packed rows 0 / 1, 18 instructions
+MPM_DEV void sym_from_eig(const float (&U)[9], const float (&d)[3], float (&out)[6]) {
 	const v2f_ u0 = {U[0], U[1]}, u1 = {U[3], U[4]}, u2 = {U[6], U[7]};
 	const v2f_ ud0 = u0 * d[0], ud1 = u1 * d[1], ud2 = u2 * d[2];
 	const float udz0 = U[2] * d[0], udz1 = U[5] * d[1], udz2 = U[8] * d[2];
 	const v2f_ c0 = ud0 * U[0] + ud1 * U[3] + ud2 * U[6];// (00, 10)
-	const v2f_ c1 = ud0 * U[1] + ud1 * U[4] + ud2 * U[7];// (01, 11)
-	const v2f_ c2 = ud0 * U[2] + ud1 * U[5] + ud2 * U[8];// (02, 12)
+	const v2f_ cz = u0 * udz0 + u1 * udz1 + u2 * udz2;	 // (20, 21)
 	out[0] = c0.x;
-	out[1] = c0.y;
 	out[3] = c0.y;
-	out[4] = c1.y;
-	out[6] = c2.x;
-	out[7] = c2.y;
-	out[2] = c2.x;
-	out[5] = c2.y;
-	out[8] = udz0 * U[2] + udz1 * U[5] + udz2 * U[8];
+	out[1] = ud0.y * U[1] + ud1.y * U[4] + ud2.y * U[7];
+	out[4] = cz.x;
+	out[5] = cz.y;
+	out[2] = udz0 * U[2] + udz1 * U[5] + udz2 * U[8];
 }
-
-// F <- U diag(S_new) V^T through V (reference form, matmul_mat_diag_mat_t_3d): the rare lanes where the multiplicative
-// form U diag(S_new / sigma) U^T F cannot be used - det F <= 0 (the reference's SVD moves the reflection into the
-// smallest singular value and the projected F comes out with det > 0) or a singular value below the models' clamp.
-// V: v_k = F^T u_k / sigma_k for the two larger singular values, the third column by the cross product (V a rotation).
-MPM_DEV void rebuild_through_v(float (&F)[9], const float (&U)[9], const float (&lam)[3], const float (&Snew)[3]) {
-	float g[3][3], n[3];
-#pragma unroll
-	for(int k = 0; k < 3; ++k) {
-#pragma unroll
-		for(int j = 0; j < 3; ++j) g[k][j] = F[3 * j] * U[3 * k] + F[3 * j + 1] * U[3 * k + 1] + F[3 * j + 2] * U[3 * k + 2];
-		n[k] = rsqrt_approx(fmaxf(g[k][0] * g[k][0] + g[k][1] * g[k][1] + g[k][2] * g[k][2], 1e-30f));
-#pragma unroll
-		for(int j = 0; j < 3; ++j) g[k][j] *= n[k];
-	}
-	const int kmin = (lam[0] <= lam[1] && lam[0] <= lam[2]) ? 0 : (lam[1] <= lam[2] ? 1 : 2);
-#pragma unroll
-	for(int k = 0; k < 3; ++k) {
-		if(k == kmin) {
-			const int a = (k + 1) % 3, b = (k + 2) % 3;
-			g[k][0] = g[a][1] * g[b][2] - g[a][2] * g[b][1];
-			g[k][1] = g[a][2] * g[b][0] - g[a][0] * g[b][2];
-			g[k][2] = g[a][0] * g[b][1] - g[a][1] * g[b][0];
-		}
-	}
-#pragma unroll
-	for(int j = 0; j < 3; ++j) {
-#pragma unroll
-		for(int i = 0; i < 3; ++i) F[3 * j + i] = Snew[0] * U[i] * g[0][j] + Snew[1] * U[3 + i] * g[1][j] + Snew[2] * U[6 + i] * g[2][j];
-	}
-}
-
-// F <- U diag(ratio) U^T F
-MPM_DEV void rescale_principal(float (&F)[9], const float (&U)[9], const float (&ratio)[3]) {
-	float M[9];
-	sym_from_eig(U, ratio, M);
-	float Fn[9];
-	matmul3(M, F, Fn);
-#pragma unroll
-	for(int d = 0; d < 9; ++d) F[d] = Fn[d];
+// the symmetric 3 x 3 matrix (column-major 9) of its six entries
+MPM_DEV void sym_expand(const float (&s)[6], float (&m)[9]) {
+	m[0] = s[0], m[1] = s[3], m[2] = s[4];
+	m[3] = s[3], m[4] = s[1], m[5] = s[5];
+	m[6] = s[4], m[7] = s[5], m[8] = s[2];
 }
 
 // Material constants passed by value to the kernels (Projects/GMPM/particle_buffer.cuh:141-264)
@@ -328,23 +277,23 @@ struct MaterialConst {
 
 // compute_stress<FIXED_COROTATED>, Projects/GMPM/constitutive_models.cuh:36-73.
 // P F^T = U diag(P_hat_k sigma_k) U^T with P_hat_k sigma_k = 2 mu (sigma_k - 1) sigma_k + lambda (J - 1) J.
+// refl: det F < 0 - the smallest singular value carries the sign (svd.cuh:590-770).
 constexpr int kFcSites = kEigSites + 1;
 template<int BASE, class Hook>
-MPM_DEV void stress_fixed_corotated(const MaterialConst& mc, const float (&F)[9], float (&PF)[9], Hook& hk) {
+MPM_DEV void stress_fixed_corotated(const MaterialConst& mc, const float (&b)[6], bool refl, float (&PF)[9], Hook& hk) {
 	float lam[3], U[9];
 	bool undeformed;
-	sym_eig3<BASE>(F, lam, U, hk, undeformed);
-	if(undeformed) {// sigma_k = 1, J = 1: P F^T = 0 exactly
+	sym_eig3<BASE>(b, lam, U, hk, undeformed);
+	if(undeformed && !__any(refl)) {// sigma_k = 1, J = 1: P F^T = 0 exactly
 #pragma unroll
 		for(int d = 0; d < 9; ++d) PF[d] = 0.f;
 		hk.template at<BASE + kEigSites>();
 		return;
 	}
-	if(ill_conditioned(lam)) refine_eigs(F, U, lam);
 	float sig[3];
 #pragma unroll
-	for(int k = 0; k < 3; ++k) sig[k] = __builtin_amdgcn_sqrtf(lam[k]);
-	if(det3(F) < 0.f) {// reflected F: the smallest singular value carries the sign (svd.cuh:590-770)
+	for(int k = 0; k < 3; ++k) sig[k] = __builtin_amdgcn_sqrtf(fmaxf(lam[k], 0.f));
+	if(refl) {
 		const bool m0 = lam[0] <= lam[1] && lam[0] <= lam[2], m1 = !m0 && lam[1] <= lam[2];
 		sig[0] = m0 ? -sig[0] : sig[0];
 		sig[1] = m1 ? -sig[1] : sig[1];
@@ -353,40 +302,39 @@ MPM_DEV void stress_fixed_corotated(const MaterialConst& mc, const float (&F)[9]
 	const float J  = sig[0] * sig[1] * sig[2];
 	const float vl = mc.volume * mc.lambda * (J - 1.0f) * J;
 	const float vm = 2.0f * mc.mu * mc.volume;
-	float d[3];
+	float d[3], pf[6];
 #pragma unroll
 	for(int k = 0; k < 3; ++k) d[k] = fmaf(vm, lam[k] - sig[k], vl);
-	sym_from_eig(U, d, PF);
+	sym_from_eig(U, d, pf);
+	sym_expand(pf, PF);
 	hk.template at<BASE + kEigSites>();
 }
-MPM_DEV void stress_fixed_corotated(const MaterialConst& mc, const float (&F)[9], float (&PF)[9]) {
+MPM_DEV void stress_fixed_corotated(const MaterialConst& mc, const float (&b)[6], bool refl, float (&PF)[9]) {
 	NoHook nh;
-	stress_fixed_corotated<0>(mc, F, PF, nh);
+	stress_fixed_corotated<0>(mc, b, refl, PF, nh);
 }
 
 // compute_stress<SAND>, constitutive_models.cuh:238-335 (Drucker-Prager return mapping, StVK-Hencky) in principal
-// log-strains ln sigma_k = 0.5 ln lam_k.  The return mapping moves ln sigma_k by dl_k, so the projected
-// F = U diag(exp(dl_k)) U^T F_trial, and P F^T vol = U diag((2 mu ln S_new_k + lambda tr ln S_new) vol) U^T.
+// log-strains ln sigma_k = 0.5 ln lam_k.  The return mapping moves ln sigma_k to ln S_new_k, so the projected
+// b = U diag(exp(2 ln S_new_k)) U^T, and P F^T vol = U diag((2 mu ln S_new_k + lambda tr ln S_new) vol) U^T.
+// A reflected F (refl) enters through |S| (:262) and leaves with det > 0 (the projection rebuilds U S_new V^T with S_new > 0).
 constexpr int kSandSites = kEigSites + 3;
 template<int BASE, class Hook>
-MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9], Hook& hk, float* __restrict__ Fdst = nullptr, int Fstride = 0) {
+MPM_DEV void stress_sand(const MaterialConst& mc, float (&b)[6], bool& refl, float& log_jp, float (&PF)[9], Hook& hk) {
 	float lam[3], U[9];
 	bool undeformed;
-	sym_eig3<BASE>(F, lam, U, hk, undeformed);
-	// undeformed, no cohesion, log Jp >= 0: ln sigma = 0 sits at the cone tip with zero strain (:282-289): F and log Jp stay, P F^T = 0.
+	sym_eig3<BASE>(b, lam, U, hk, undeformed);
+	// undeformed, no cohesion, log Jp >= 0: ln sigma = 0 sits at the cone tip with zero strain (:282-289): b and log Jp stay, P F^T = 0.
 	// (The three parts are skipped in place, around the hook sites, so that every site exists once in the code.)
-#ifdef MPM_HACK_UNDEF
+#if defined(MPM_EXPERIMENT) && defined(MPM_HACK_UNDEF)
 	const bool skip = undeformed;
 #else
-	const bool skip = undeformed && mc.cohesion == 0.f && __all(log_jp >= 0.f);
+	const bool skip = undeformed && mc.cohesion == 0.f && __all((log_jp >= 0.f) & !refl);
 #endif
 	const float scaled_mu = 2.0f * mc.mu;
-	bool ill = false;
-	float lns[3], epsilon[3], epsilon_hat[3], dl[3], lnS[3];
+	float lns[3], epsilon[3], epsilon_hat[3], lnS[3];
 	float sum_epsilon = 0.f, trace_epsilon = 0.f, epsilon_hat_norm = 0.f;
 	if(!skip) {
-		ill = ill_conditioned(lam);
-		if(ill) refine_eigs(F, U, lam);
 #pragma unroll
 		for(int i = 0; i < 3; i++) {
 			lns[i]	   = 0.5f * log_fast(fmaxf(lam[i], 1e-8f));// ln max(|S|, 1e-4) (:262)
@@ -407,88 +355,75 @@ MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, 
 		const bool dead = !tip && mc.mu == 0.f;// reference: logf(0) when mu == 0 (:298-300): P is NaN, F is left as it is
 		const float delta_gamma = epsilon_hat_norm + (3.0f * mc.lambda + scaled_mu) * rcp_fast(scaled_mu) * trace_epsilon * mc.yield_surface;
 		const float r			= fmaxf(delta_gamma, 0.f) * rcp_fast(fmaxf(epsilon_hat_norm, 1e-30f));
+		bool moved = false;
 #pragma unroll
 		for(int i = 0; i < 3; i++) {
-			dl[i]  = tip ? -epsilon[i] : -r * epsilon_hat[i];
-			lnS[i] = dead ? -__builtin_inff() : lns[i] + dl[i];
+			const float dl = tip ? -epsilon[i] : -r * epsilon_hat[i];
+			moved |= dl != 0.f;
+			lnS[i] = dead ? -__builtin_inff() : lns[i] + dl;
 		}
 		log_jp = tip ? (mc.volume_correction ? mc.beta * sum_epsilon + log_jp : log_jp) : (dead ? log_jp : 0.f);
-		// The projected F = U diag(exp(dl)) U^T F.  While every particle of the wave is inside the cone (dl = 0: elastic, the
-		// state of a column at rest) the factor is the identity and the rebuild is skipped for the whole wave; the reference
-		// rebuilds U S V^T there too, which only adds its rounding.  Reflected or collapsed F (rare) goes through V, as the
-		// reference's does, whether the strain changed or not (the rebuild removes the reflection).
-		const bool odd	   = !dead && (ill || !(det3(F) > 0.f));
-		// (dl == 0 exactly: inside the cone, or at the tip with zero strain - free fall; exp(0) = 1 would only add the rounding of U U^T)
-		const bool changed = !dead && !odd && ((dl[0] != 0.f) | (dl[1] != 0.f) | (dl[2] != 0.f));
+		// The projected b = U diag(exp(2 ln S_new)) U^T.  While every particle of the wave is inside the cone (dl = 0 exactly: elastic, the
+		// state of a column at rest; or at the tip with zero strain: free fall) the trial b stands and the rebuild is skipped for the
+		// whole wave; the reference rebuilds U S V^T there too, which only adds its rounding.  A reflected F is rebuilt whether the
+		// strain moved or not (the reference's projection removes the reflection).
+		const bool changed = !dead && (moved | refl);
 		if(__any(changed)) {
 			if(changed) {
-				float ratio[3];
+				float s2[3];
 #pragma unroll
-				for(int i = 0; i < 3; i++) ratio[i] = exp_fast(dl[i]);
-				rescale_principal(F, U, ratio);
-			}
-		}
-		if(__any(odd)) {
-			if(odd) {
-				float Sn[3];
-#pragma unroll
-				for(int i = 0; i < 3; i++) Sn[i] = exp_fast(lnS[i]);
-				rebuild_through_v(F, U, lam, Sn);
+				for(int i = 0; i < 3; i++) s2[i] = exp_fast(lnS[i] + lnS[i]);
+				sym_from_eig(U, s2, b);
+				refl = false;
 			}
 		}
 	}
 	hk.template at<BASE + kEigSites + 1>();
-	if(Fdst) {// the kernel has the projected F written out here: nine registers less while P F^T is formed
-#pragma unroll
-		for(int d = 0; d < 9; ++d) Fdst[d * Fstride] = F[d];
-	}
 	if(!skip) {
 		const float trace_log_S = lnS[0] + lnS[1] + lnS[2];
-		float d[3];
+		float d[3], pf[6];
 #pragma unroll
 		for(int k = 0; k < 3; ++k) d[k] = (scaled_mu * lnS[k] + mc.lambda * trace_log_S) * mc.volume;
-		sym_from_eig(U, d, PF);
+		sym_from_eig(U, d, pf);
+		sym_expand(pf, PF);
 	} else {
 #pragma unroll
 		for(int d = 0; d < 9; ++d) PF[d] = 0.f;
 	}
 	hk.template at<BASE + kEigSites + 2>();
 }
-MPM_DEV void stress_sand(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9]) {
+MPM_DEV void stress_sand(const MaterialConst& mc, float (&b)[6], bool& refl, float& log_jp, float (&PF)[9]) {
 	NoHook nh;
-	stress_sand<0>(mc, F, log_jp, PF, nh);
+	stress_sand<0>(mc, b, refl, log_jp, PF, nh);
 }
 
 // compute_stress<NACC>, constitutive_models.cuh:77-234 (USE_JOSH_FRACTURE_PAPER branch) in principal stretches:
-// B_hat_k = sigma_k^2 = lam_k, the projections return new squared stretches Bn_k; F_new = U diag(sqrt(Bn_k / lam_k)) U^T F,
-// b_new = F_new F_new^T = U diag(Bn) U^T, so dev(b) and P F^T are diagonal in U.  J^(+-2/3), cube roots and logs go
-// through one v_log_f32 / v_exp_f32 each instead of powf (the reference binary's --use_fast_math does the same).
+// B_hat_k = sigma_k^2 = lam_k, the projections return new squared stretches Bn_k, so the projected b = U diag(Bn) U^T and
+// dev(b) and P F^T are diagonal in U.  J^(+-2/3), cube roots and logs go through one v_log_f32 / v_exp_f32 each instead of powf
+// (the reference binary's --use_fast_math does the same).  refl = det F < 0.
 constexpr int kNaccSites = kEigSites + 2;
 template<int BASE, class Hook>
-MPM_DEV void stress_nacc(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9], Hook& hk) {
+MPM_DEV void stress_nacc(const MaterialConst& mc, float (&b)[6], bool& refl, float& log_jp, float (&PF)[9], Hook& hk) {
 	float lam[3], U[9];
 	bool undeformed;
-	sym_eig3<BASE>(F, lam, U, hk, undeformed);
+	sym_eig3<BASE>(b, lam, U, hk, undeformed);
 	// undeformed: p_trial = 0 lies strictly inside (p_min, p0) and y < 0 (:113-151): no projection, no hardening; dev(b) = 0, J = 1: P F^T = 0.
 	// (The two parts are skipped in place, around the hook site, so that every site exists once in the code.)
-	const bool skip = undeformed && mc.bm > 0.f && mc.beta > 0.f;
+	const bool skip = undeformed && mc.bm > 0.f && mc.beta > 0.f && !__any(refl);
 	const float bm = mc.bm;
-	bool ill = false, rebuild = false;
-	float p0 = 0.f, p_min = 0.f, detF = 1.f, lg2J = 0.f, trB3 = 0.f, sh0 = 0.f, sh1 = 0.f, sh2 = 0.f, p_trial = 0.f, y_s_half_coeff = 0.f, y_p_half = 0.f, s_sqrnorm = 0.f, y = 0.f;
+	bool rebuild = false;
+	float p0 = 0.f, p_min = 0.f, lg2J = 0.f, trB3 = 0.f, sh0 = 0.f, sh1 = 0.f, sh2 = 0.f, p_trial = 0.f, y_s_half_coeff = 0.f, y_p_half = 0.f, s_sqrnorm = 0.f, y = 0.f;
 	float Bn[3] = {lam[0], lam[1], lam[2]};// new squared stretches
 	if(!skip) {
-		ill = ill_conditioned(lam);
-		if(ill) refine_eigs(F, U, lam);
 		const float ex = exp_fast(mc.xi * fmaxf(-log_jp, 0.f));
 		p0 = bm * (0.00001f + 0.5f * (ex - rcp_fast(ex)));// sinh
 		p_min = -mc.beta * p0;
-		detF	 = det3(F);
 		lg2J	 = 0.5f * __builtin_amdgcn_logf(lam[0] * lam[1] * lam[2]);// log2 |Je_trial|
 		const float Je_abs	 = __builtin_amdgcn_exp2f(lg2J);
-		const float Je_trial = detF < 0.f ? -Je_abs : Je_abs;
+		const float Je_trial = refl ? -Je_abs : Je_abs;
 		trB3	 = (lam[0] + lam[1] + lam[2]) * (1.f / 3.f);
 		// a reflected F makes the reference's powf(Je_trial, -2/3) NaN (:96); the same happens here through the sign of Je
-		const float Jm23mu = detF < 0.f ? __builtin_nanf("") : mc.mu * __builtin_amdgcn_exp2f(lg2J * (-2.f / 3.f));
+		const float Jm23mu = refl ? __builtin_nanf("") : mc.mu * __builtin_amdgcn_exp2f(lg2J * (-2.f / 3.f));
 		sh0 = Jm23mu * (lam[0] - trB3), sh1 = Jm23mu * (lam[1] - trB3), sh2 = Jm23mu * (lam[2] - trB3);
 		p_trial		   = -bm * 0.5f * (Je_trial - rcp_fast(Je_trial)) * Je_trial;
 		y_s_half_coeff = 1.5f * (1.f + 2.f * mc.beta);
@@ -529,40 +464,32 @@ MPM_DEV void stress_nacc(const MaterialConst& mc, float (&F)[9], float& log_jp, 
 				if(Je_new_fake2 > 1e-8f) log_jp += (lg2J - 0.5f * __builtin_amdgcn_logf(Je_new_fake2)) * 0.693147180559945f;
 			}
 		}
-		if(rebuild) {
-			if(!ill && detF > 0.f) {
-				float ratio[3];
-	#pragma unroll
-				for(int i = 0; i < 3; i++) ratio[i] = __builtin_amdgcn_sqrtf(Bn[i] * rcp_fast(lam[i]));
-				rescale_principal(F, U, ratio);
-			} else {
-				float Sn[3];
-	#pragma unroll
-				for(int i = 0; i < 3; i++) Sn[i] = __builtin_amdgcn_sqrtf(Bn[i]);
-				rebuild_through_v(F, U, lam, Sn);
-			}
+		const bool neg = refl && !rebuild;
+		if(rebuild) {// (the reference rebuilds U S_new V^T with a proper rotation V: the reflection is gone)
+			sym_from_eig(U, Bn, b);
+			refl = false;
 		}
 		// elasticity (:206-230): J, dev(b) of the renewed F
 		const float lg2Jn	   = 0.5f * __builtin_amdgcn_logf(Bn[0] * Bn[1] * Bn[2]);
 		const float Jn_abs	   = __builtin_amdgcn_exp2f(lg2Jn);
-		const bool neg		   = detF < 0.f && !rebuild;
 		const float J2		   = Jn_abs * Jn_abs;
 		const float dev_b_coeff = neg ? __builtin_nanf("") : mc.mu * __builtin_amdgcn_exp2f(lg2Jn * (-2.f / 3.f));
 		const float i_coeff	   = bm * .5f * ((J2 - 1.f) * 0.5f - (neg ? __builtin_nanf("") : lg2Jn * 0.693147180559945f));
 		const float trBn3	   = (Bn[0] + Bn[1] + Bn[2]) * (1.f / 3.f);
-		float d[3];
+		float d[3], pf[6];
 	#pragma unroll
 		for(int k = 0; k < 3; ++k) d[k] = (dev_b_coeff * (Bn[k] - trBn3) + i_coeff) * mc.volume;
-		sym_from_eig(U, d, PF);
+		sym_from_eig(U, d, pf);
+		sym_expand(pf, PF);
 	} else {
 #pragma unroll
 		for(int d = 0; d < 9; ++d) PF[d] = 0.f;
 	}
 	hk.template at<BASE + kEigSites + 1>();
 }
-MPM_DEV void stress_nacc(const MaterialConst& mc, float (&F)[9], float& log_jp, float (&PF)[9]) {
+MPM_DEV void stress_nacc(const MaterialConst& mc, float (&b)[6], bool& refl, float& log_jp, float (&PF)[9]) {
 	NoHook nh;
-	stress_nacc<0>(mc, F, log_jp, PF, nh);
+	stress_nacc<0>(mc, b, refl, log_jp, PF, nh);
 }
 
 // J-fluid (weakly compressible, Tait EOS + Newtonian viscosity), Projects/GMPM/mgmpm_kernels.cuh:476-505

@@ -25,11 +25,11 @@
 
 namespace mpm {
 
-#ifndef MPM_G2P2G_WAVES_FLUID
+#if !(defined(MPM_EXPERIMENT) && defined(MPM_G2P2G_WAVES_FLUID))
 #define MPM_G2P2G_WAVES_FLUID 4// J-fluid instantiation: 128 VGPRs suffice, and with a material update of a handful of instructions the
 								// scatter chain has little to hide behind - occupancy does it (same-box: 0.36 ms against 0.40 at three waves)
 #endif
-#ifndef MPM_G2P2G_WAVES
+#if !(defined(MPM_EXPERIMENT) && defined(MPM_G2P2G_WAVES))
 #define MPM_G2P2G_WAVES 3// waves per SIMD the register allocation is held to (168 VGPRs)
 #endif
 
@@ -56,14 +56,18 @@ struct ModelView {
 	MaterialConst mc;
 };
 
-// Particle storage: bins of 64 particle RECORDS, a record = {x, y, z, state...} contiguous in memory (16 B for the J-fluid
-// {x, y, z, J}, 48 B {x, y, z, F[9]} for the other models), moved with 16-byte loads and stores; sand / NACC keep their 13th
-// float, log Jp, in a 64-float row behind the bin's 64 records (bin = 64 x 48 B + 256 B = 3328 B: `nch` = 13 floats per
-// particle, `rec` = 12 per record).  Round 2 padded those records to one 64-B sector: 24 of the 152 bytes a particle moved
-// per step were padding, and the launch pays for bytes: 1.39 -> 1.2x ms in the default window of C3.  The reference's (and round 1's) AoSoA bins [channel][slot] are ideal only while the sorted order of a
-// step equals the order the particles were written in; in a flow the 64 lanes of an iteration read 64 scattered slots, and
-// with one 256-B row per channel that is 13 x ~16 cache lines per wave-load and a 6x HBM read amplification
-// (profiles/r02_moving_window_pmc.txt).  A record is contiguous whatever the permutation.
+// Particle storage: bins of 64 particle RECORDS plus, for the solid models, one ROW of 64 entries behind them.
+//   J-fluid:          record {x, y, z, J}                                   16 B, no row                      bin = 1024 B
+//   fixed-corotated:  record {x, y, z, b00 | b11, b22, b10, b20}            32 B, row of b21          (4 B)   bin = 2304 B
+//   sand, NACC:       the same record,                                            row of {b21, log Jp} (8 B)   bin = 2560 B
+// b = F F^T is the state the solid models carry instead of F (mpm_device_math.hpp: 24 B instead of 36 B per particle); the sign
+// bit of b00 marks a reflected F.  A record is moved with 16-byte loads and stores and never straddles a 64-B sector; the row
+// is a coalesced 256 / 512-B access while the sorted order of a step equals the order the particles were written in.
+// History: the reference's (and round 1's) AoSoA bins [channel][slot] are ideal only while that holds; in a flow the 64 lanes of an
+// iteration read 64 scattered slots, and with one 256-B row per channel that is 13 x ~16 cache lines per wave-load and a 6x HBM
+// read amplification (profiles/r02_moving_window_pmc.txt).  Round 2: 64-B records {x, y, z, F[9], log Jp, pad}; round 3: 48-B
+// records + a row of log Jp (-11 % kernel time at rest for 16 % fewer bytes: the launch pays for bytes); round 4:
+// b instead of F.  `nch` = floats per particle in a bin, `rec` = floats per record, the rest per row entry.
 template<int MAT>
 struct MatTraits;
 template<>
@@ -72,16 +76,17 @@ struct MatTraits<0> {
 };
 template<>
 struct MatTraits<1> {
-	static constexpr int nch = 12, rec = 12;
+	static constexpr int nch = 9, rec = 8;
 };
 template<>
 struct MatTraits<2> {
-	static constexpr int nch = 13, rec = 12;
+	static constexpr int nch = 10, rec = 8;
 };
 template<>
 struct MatTraits<3> {
-	static constexpr int nch = 13, rec = 12;
+	static constexpr int nch = 10, rec = 8;
 };
+constexpr unsigned kReflBit = 0x80000000u;// sign bit of b00 (positive otherwise): det F < 0
 
 // P2G payload of one particle: everything the scatter needs after the material update.
 struct P2GPayload {
@@ -95,68 +100,6 @@ struct P2GPayload {
 // x / y components and the (w, w (x_i - x_p)) weight pairs go through packed fp32.  A node is {vx, vy, vz, vz}: the
 // duplicate makes the load a full ds_read_b128 (4.0 cycles per wave against 7.1 for ds_read_b96) and gives the z
 // accumulators a natural register pair.
-#ifndef MPM_SCALAR_GS
-#define MPM_SCALAR_GS 0// A/B switch: 1 = gather / scatter arithmetic in scalar VOP2 form (v_fmac_f32) instead of packed fp32.  The launch is power-bound and a
-					   // v_pk_fma_f32 costs 2.76x the energy of a v_fmac_f32 for twice the work (profiles/r03_energy_model.txt), which predicts -4 %; measured
-					   // (profiles/r03_ab_scalar_vs_packed.txt): sand -1..-2 % (inside the run-to-run noise), fixed-corotated +3 %: +230 instructions per
-					   // iteration cost what the cheaper encodings save.  Not the default.
-#endif
-#if MPM_SCALAR_GS
-// Same tensor-product contraction, one fused multiply-add per accumulator and node component: 27 x 6 + 9 x 9 + 3 x 12 v_fmac_f32
-// (4-byte VOP2 encodings, the accumulator is the destination).
-MPM_DEV void gather_apic(const float4* __restrict__ gbase, const float (&w)[3][3], const float (&fd)[3], float (&vel)[3], float (&A)[9]) {
-	float wz1[3], wy1[3], wx1[3];// w * (node - particle) per axis and stencil offset
-#pragma unroll
-	for(int t = 0; t < 3; ++t) {
-		wx1[t] = w[0][t] * ((float) t - fd[0]);
-		wy1[t] = w[1][t] * ((float) t - fd[1]);
-		wz1[t] = w[2][t] * ((float) t - fd[2]);
-	}
-#pragma unroll
-	for(int d = 0; d < 3; ++d) vel[d] = 0.f;
-#pragma unroll
-	for(int d = 0; d < 9; ++d) A[d] = 0.f;
-#pragma unroll
-	for(int i = 0; i < 3; ++i) {
-		float u0[3] = {0.f, 0.f, 0.f}, uy[3] = {0.f, 0.f, 0.f}, uz[3] = {0.f, 0.f, 0.f};// sum_jk W_j W_k v, ... (y_j - y_p), ... (z_k - z_p)
-#pragma unroll
-		for(int j = 0; j < 3; ++j) {
-			float t0[3] = {0.f, 0.f, 0.f}, t1[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-			for(int k = 0; k < 3; ++k) {
-				const float4 v	 = gbase[i * kG2PStrideX + j * kG2PStrideY + k];
-#ifndef MPM_GATHER_B96
-				__asm__ volatile("" ::"v"(v.w));// keep the load a full ds_read_b128 (4.0 cycles per wave against 7.1 for ds_read_b96)
-#endif
-				const float vc[3] = {v.x, v.y, v.z};
-#pragma unroll
-				for(int c = 0; c < 3; ++c) {
-					t0[c] = fmaf(vc[c], w[2][k], t0[c]);
-					t1[c] = fmaf(vc[c], wz1[k], t1[c]);
-				}
-			}
-			__builtin_amdgcn_sched_barrier(0);// at most one z-pencil (3 nodes) of loads in flight
-#pragma unroll
-			for(int c = 0; c < 3; ++c) {
-				u0[c] = fmaf(t0[c], w[1][j], u0[c]);
-				uy[c] = fmaf(t0[c], wy1[j], uy[c]);
-				uz[c] = fmaf(t1[c], w[1][j], uz[c]);
-			}
-		}
-#pragma unroll
-		for(int c = 0; c < 3; ++c) {
-			vel[c]	 = fmaf(u0[c], w[0][i], vel[c]);
-			A[c]	 = fmaf(u0[c], wx1[i], A[c]);	  // column 0: (x_i - x_p)
-			A[3 + c] = fmaf(uy[c], w[0][i], A[3 + c]);// column 1
-			A[6 + c] = fmaf(uz[c], w[0][i], A[6 + c]);// column 2
-		}
-	}
-#pragma unroll
-	for(int d = 0; d < 9; ++d) __asm__ volatile("" : "+v"(A[d]));
-#pragma unroll
-	for(int d = 0; d < 3; ++d) __asm__ volatile("" : "+v"(vel[d]));
-}
-#else
 MPM_DEV void gather_apic(const float4* __restrict__ gbase, const float (&w)[3][3], const float (&fd)[3], float (&vel)[3], float (&A)[9]) {
 	v2f_ wz[3], wy[3], wx[3];// {w, w * (node - particle)} per axis and stencil offset
 #pragma unroll
@@ -217,7 +160,6 @@ MPM_DEV void gather_apic(const float4* __restrict__ gbase, const float (&w)[3][3
 #pragma unroll
 	for(int d = 0; d < 3; ++d) __asm__ volatile("" : "+v"(vel[d]));
 }
-#endif
 
 // P2G of the particles the chain cannot take - lanes that lost the claim of their stencil base (another lane of the
 // iteration holds the same base) and edge lanes, whose stencil reaches cube nodes 0 or 7 (cells of the 2x2x2 grid blocks
@@ -293,9 +235,6 @@ MPM_DEV void p2g_serial(float4* __restrict__ arena, bool pending, int code, cons
 // ds_read_b128 (all lanes of a half read the same entry) instead of 17 ds_bpermute, and consecutive pairs are independent up to the
 // read-modify-write itself, so their loads and arithmetic overlap; issued inside the particle loop every pair was an exposed
 // bpermute -> arithmetic -> LDS round trip (0.28 of 2.15 ms in the flow window of C3 for 3.6 % of the particles).
-#ifndef MPM_SERIAL_QUEUE
-#define MPM_SERIAL_QUEUE 1
-#endif
 constexpr int kSerialQueue = 28;// entries of 64 B: 10.8 + 1.8 KB of LDS per wave, still 12 single-wave workgroups per CU
 MPM_DEV void serial_flush(float4* __restrict__ arena, const float4* __restrict__ queue, int qn, float mass, int lane, int info, float* __restrict__ next_grid) {
 	__asm__ volatile("" : "+v"(lane));
@@ -332,7 +271,7 @@ MPM_DEV void serial_flush(float4* __restrict__ arena, const float4* __restrict__
 				const float4 acc = *node;
 				*node			 = make_float4(acc.x + v0, acc.y + v1, acc.z + v2, acc.w + v3);
 			} else if(nb >= 0) {
-#ifdef MPM_HACK_NOSHELL// timing / traffic experiment only: the shell contributions of the serial path are dropped (wrong physics)
+#if defined(MPM_EXPERIMENT) && defined(MPM_HACK_NOSHELL)// timing / traffic experiment only: the shell contributions of the serial path are dropped (wrong physics)
 				if(size_t(next_grid) != 1) continue;
 #endif
 				float* g = next_grid + (size_t) nb * 256 + (gx & 3) * 16 + (gy & 3) * 4 + (gz & 3);
@@ -424,12 +363,6 @@ struct ScatterChain {
 			wij			   = pw[0][i] * pw[1][j];
 		}
 		const float W  = wij * pw[2][k];
-#if MPM_SCALAR_GS
-		const float c1 = b0 + cp6[k], c2 = b12.x + cp12[k].x, c3 = b12.y + cp12[k].y;
-		if(win) {
-			const float4 out = make_float4(fmaf(mass, W, acc.x), fmaf(c1, W, acc.y), fmaf(c2, W, acc.z), fmaf(c3, W, acc.w));
-			node0[i * kP2GStrideX + j * kP2GStrideY + k] = out;
-#else
 		const v2f_ m0  = {mass, b0 + cp6[k]};
 		const v2f_ t12 = b12 + cp12[k];
 		if(win) {// (letting the other lanes run the steps on a scratch stencil instead removes 81 exec-mask instructions per iteration and is slower: +1-4 % sand, +11 % J-fluid)
@@ -438,7 +371,6 @@ struct ScatterChain {
 			a01		 = m0 * W + a01;
 			a23		 = t12 * W + a23;
 			node0[i * kP2GStrideX + j * kP2GStrideY + k] = make_float4(a01.x, a01.y, a23.x, a23.y);
-#endif
 			__asm__ volatile("" ::: "memory");
 			if(o + 1 < 27) {
 				const int i1 = (o + 1) / 9, j1 = ((o + 1) / 3) % 3, k1 = (o + 1) % 3;
@@ -461,6 +393,7 @@ struct StepConst {
 	float pred;// new_dt / dx
 	float am;  // mass dx^2 D^-1
 	float cs;  // new_dt D^-1 dx
+	float refl_lim;// (1/3) / dts: an entry of A beyond it could make det(I + dt grad v) <= 0 (the reflection bit of b, mpm_device_math.hpp)
 };
 
 // packed stencil base in the node cube (x | y << 4 | z << 8), -1 = outside (contribution discarded, :877-885)
@@ -486,9 +419,9 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 										   // into neighbouring lanes, so both scatter in the same pass (summed in the write-back)
 	__shared__ unsigned char s_owner[2 * 216];
 	// (not for the J-fluid: its instantiation runs at four waves per SIMD and 14 workgroups per CU, which the queue's LDS would cost)
-	constexpr bool kQueue = MPM_SERIAL_QUEUE && MAT != 0;
+	constexpr bool kQueue = MAT != 0;
 	__shared__ float4 s_queue[kQueue ? 4 * kSerialQueue : 1];// payloads of the lanes that could not take the scatter chain (serial_push / serial_flush)
-#ifdef MPM_LDS_PAD
+#if defined(MPM_EXPERIMENT) && defined(MPM_LDS_PAD)
 	__shared__ float s_pad[MPM_LDS_PAD / 4];// experiment: lower the occupancy without touching the code
 	if(size_t(grid) == 1) s_pad[threadIdx.x] = 0.f;
 #endif
@@ -500,13 +433,8 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 	// The number of blocks is read from device memory when nblocks_ptr is given (the launch is then sized by the host's ESTIMATE
 	// of it - mpm_run_fixed does not wait for the rebuild's counts -, a multiple of 8): workgroup (xcd, q) takes the blocks
 	// q, q + gridDim.x / 8, ... of its XCD's range; one trip when the estimate holds.
-#ifdef MPM_G2P2G_NOLOOP// A/B switch: exact launch sizes from the host (needs sync_interval = 1), one block per workgroup
-	const int total = nblocks;
-	const int xcd = (int) (blockIdx.x & 7u), nq = 0x40000000;
-#else
 	const int total = nblocks_ptr ? min(*nblocks_ptr, cfg.cap) : nblocks;
 	const int xcd = (int) (blockIdx.x & 7u), nq = nblocks_ptr ? (int) (gridDim.x >> 3) : 0x40000000;
-#endif
 	const int share = (total >> 3) + (xcd < (total & 7) ? 1 : 0);// XCD r owns (total / 8) + (r < total % 8) consecutive numbers
 	const int first = xcd * (total >> 3) + min(xcd, total & 7);
 	for(int q = (int) (blockIdx.x >> 3); q < share; q += nq) {
@@ -554,9 +482,10 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 	// is 2-4 us).  The loads are unconditional - lanes past the end of the block re-read its last record - so that the
 	// compiler can count them in s_waitcnt; their arrival is implied by the list-append atomics' results being consumed
 	// at the end of the iteration (memory operations return in order).
+	constexpr int ROW = NCH - REC;// floats per row entry: 0 (J-fluid), 1 (b21), 2 ({b21, log Jp})
 	struct Prefetch {
 		float4 q[REC / 4];// the particle record
-		float lj;		  // log Jp (sand / NACC)
+		float row[ROW ? ROW : 1];
 		int key;		  // the stencil base this particle was predicted to have after this step (its sort key)
 	};
 	auto fetch = [&](int rec, Prefetch& f) {
@@ -566,19 +495,14 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		const float* bin  = mv.bins_src + (size_t) sbin * (kBin * NCH);
 		const float4* src = reinterpret_cast<const float4*>(bin + (sp & 63) * REC);
 		f.key			  = (rec >> key_shift) & 255;
-#ifdef MPM_NT_LOADS// A/B switch: streaming (non-temporal) record loads - every record is read once per step, it need not displace grid and list lines in L2
-		typedef float v4f_ __attribute__((ext_vector_type(4)));
-#pragma unroll
-		for(int d = 0; d < REC / 4; ++d) {
-			const v4f_ t = __builtin_nontemporal_load(reinterpret_cast<const v4f_*>(src) + d);
-			f.q[d]		 = make_float4(t.x, t.y, t.z, t.w);
-		}
-		if constexpr(NCH > REC) f.lj = __builtin_nontemporal_load(bin + kBin * REC + (sp & 63));
-#else
 #pragma unroll
 		for(int d = 0; d < REC / 4; ++d) f.q[d] = src[d];
-		if constexpr(NCH > REC) f.lj = bin[kBin * REC + (sp & 63)];
-#endif
+		if constexpr(ROW == 1) f.row[0] = bin[kBin * REC + (sp & 63)];
+		if constexpr(ROW == 2) {
+			const float2 t = reinterpret_cast<const float2*>(bin + kBin * REC)[sp & 63];
+			f.row[0]	   = t.x;
+			f.row[1]	   = t.y;
+		}
 	};
 	Prefetch pf;
 	fetch(rec_cur, pf);
@@ -615,18 +539,15 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		const int pidib	  = idx0 + lane;// slot in the destination bins == position in the sorted order
 		// ---- advection record -> source bin (:747-768): data was requested one iteration ago
 		float pos[3] = {pf.q[0].x, pf.q[0].y, pf.q[0].z};
-		float st[10];// J, or F[9] (+ logJp)
+		float st[7];// J, or b {00, 11, 22, 10, 20, 21} (+ log Jp)
 		st[0] = pf.q[0].w;
 		if constexpr(MAT != 0) {
 			st[1] = pf.q[1].x;
 			st[2] = pf.q[1].y;
 			st[3] = pf.q[1].z;
 			st[4] = pf.q[1].w;
-			st[5] = pf.q[2].x;
-			st[6] = pf.q[2].y;
-			st[7] = pf.q[2].z;
-			st[8] = pf.q[2].w;
-			if constexpr(NCH > REC) st[9] = pf.lj;
+			st[5] = pf.row[0];
+			if constexpr(ROW == 2) st[6] = pf.row[1];
 		}
 		const int slot_nn = idx0 + 128 < size ? idx0 + 128 : 0;
 		const int cnt_nn  = idx0 + 128 < size ? slice_records_at(size, idx0 + 128) : 1;
@@ -659,11 +580,8 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		// ---- claim the stencil bases of the payload in flight: lanes whose base is unique in the wave (`win`) scatter in the
 		//      chain threaded through this iteration's register-only arithmetic - re-bucketing (kPreSites call sites) and the
 		//      material update - the others (and the edge lanes) afterwards
-#ifndef MPM_PRE_SITES
-#define MPM_PRE_SITES 3
-#endif
 		MPM_MARK("L_claim");
-		constexpr int kPreSites	   = MPM_PRE_SITES;
+		constexpr int kPreSites	   = 3;// chain sites in the re-bucketing
 		constexpr int kStressSites = MAT == 0 ? 1 : (MAT == 1 ? kFcSites : (MAT == 2 ? kSandSites : kNaccSites));
 		constexpr int kSites	   = kPreSites + kStressSites + 2;
 		const int pv_key = (pv_in ? code_key(pv_code) : 0) + (lane & 1) * 216;// even / odd lanes: separate arenas, separate claims
@@ -733,28 +651,38 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 			chain.template at<kPreSites + 1>();
 			dst[0] = make_float4(pos[0], pos[1], pos[2], J);
 		} else {
-			float dws[9], Fold[9], F[9];
+			// b <- G b G^T, G = I + dt grad v (:838-850: F <- (I + dt grad v) F); A is accumulated in cell units: dx * D^-1 = 4 / dx, settings.h:66
+			float G[9], bo[6], bn[6];
 #pragma unroll
-			for(int d = 0; d < 9; ++d) {
-				dws[d]	= A[d] * sk.dts + ((d & 0x3) != 0 ? 0.f : 1.f);// I + dt grad v (A is accumulated in cell units: dx * D^-1 = 4 / dx, settings.h:66)
-				Fold[d] = st[d];
+			for(int d = 0; d < 9; ++d) G[d] = A[d] * sk.dts + ((d & 0x3) != 0 ? 0.f : 1.f);
+			bool refl = (__float_as_uint(st[0]) & kReflBit) != 0u;// det F < 0 (mpm_device_math.hpp)
+			bo[0]	  = fabsf(st[0]);
+#pragma unroll
+			for(int d = 1; d < 6; ++d) bo[d] = st[d];
+			{// det G <= 0 needs an entry of dt grad v beyond 1/3 (Gershgorin; a CFL-limited step stays orders of magnitude below)
+				const float amax = fmaxf(fmaxf(fmaxf(fabsf(A[0]), fabsf(A[1])), fmaxf(fabsf(A[2]), fabsf(A[3]))), fmaxf(fmaxf(fabsf(A[4]), fabsf(A[5])), fmaxf(fmaxf(fabsf(A[6]), fabsf(A[7])), fabsf(A[8]))));
+				const bool wild	 = !(amax < sk.refl_lim);
+				if(__any(wild)) {
+					if(wild) refl ^= det3(G) < 0.f;
+				}
 			}
-			matmul3(dws, Fold, F);
+			push_forward(G, bo, bn);
 			chain.template at<kPreSites + 0>();
 			float lj = 0.f;
 			if constexpr(MAT == 1) {
-				stress_fixed_corotated<kPreSites + 1>(mv.mc, F, pl.contrib, chain);
+				stress_fixed_corotated<kPreSites + 1>(mv.mc, bn, refl, pl.contrib, chain);
 			} else if constexpr(MAT == 2) {
-				lj = st[9];
-				stress_sand<kPreSites + 1>(mv.mc, F, lj, pl.contrib, chain);
+				lj = st[6];
+				stress_sand<kPreSites + 1>(mv.mc, bn, refl, lj, pl.contrib, chain);
 			} else {
-				lj = st[9];
-				stress_nacc<kPreSites + 1>(mv.mc, F, lj, pl.contrib, chain);
+				lj = st[6];
+				stress_nacc<kPreSites + 1>(mv.mc, bn, refl, lj, pl.contrib, chain);
 			}
-			dst[0] = make_float4(pos[0], pos[1], pos[2], F[0]);
-			dst[1] = make_float4(F[1], F[2], F[3], F[4]);
-			dst[2] = make_float4(F[5], F[6], F[7], F[8]);
-			if constexpr(NCH > REC) dbin[kBin * REC + (pidib & 63)] = lj;// (lane == slot: one 256-B row per wave)
+			dst[0] = make_float4(pos[0], pos[1], pos[2], refl ? -bn[0] : bn[0]);
+			dst[1] = make_float4(bn[1], bn[2], bn[3], bn[4]);
+			// (lane == slot: one 256-B / 512-B row per wave)
+			if constexpr(ROW == 1) dbin[kBin * REC + (pidib & 63)] = bn[5];
+			if constexpr(ROW == 2) reinterpret_cast<float2*>(dbin + kBin * REC)[pidib & 63] = make_float2(bn[5], lj);
 		}
 		MPM_MARK("L_contrib");
 		chain.template at<kSites - 1>();
@@ -792,7 +720,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 				st_retry_iters += __any(left) ? 1 : 0;
 			}
 #endif
-#ifdef MPM_HACK_NOSERIAL// timing experiment only: claim losers and edge lanes are dropped (wrong physics)
+#if defined(MPM_EXPERIMENT) && defined(MPM_HACK_NOSERIAL)// timing experiment only: claim losers and edge lanes are dropped (wrong physics)
 			if(false)
 #else
 			if(__any(left))
@@ -851,7 +779,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		const int n	  = in ? ax * kP2GStrideX + ay * kP2GStrideY + az : 0;
 		const float4 va = p2g[n], vb = p2g[kP2GNodes + n];
 		const float4 v	= make_float4(va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w);
-#ifdef MPM_HACK_NOWB// timing experiment only: no write-back of the arenas (wrong physics)
+#if defined(MPM_EXPERIMENT) && defined(MPM_HACK_NOWB)// timing experiment only: no write-back of the arenas (wrong physics)
 		if(size_t(next_grid) == 1)
 #else
 		if(in && nb >= 0)

@@ -2,8 +2,9 @@
 //
 // Design (MI355X-first, not a translation of the reference's CUDA):
 //   * wave64 everywhere: one wave == one 4x4x4 grid block (64 cells) in the grid kernels (every channel a 256-B row), one
-//     wave == one particle block in G2P2G (mpm_g2p2g.hpp); particles live in 64-slot bins of 16 / 48 / 64-B records, one
-//     record = one particle = one to four 16-B accesses of its lane;
+//     wave == one particle block in G2P2G (mpm_g2p2g.hpp); particles live in 64-slot bins of 16 / 32-B records (+ a row of one or
+//     two floats per particle for the solid models, whose state is b = F F^T: mpm_device_math.hpp), one record = one particle = one
+//     or two 16-B accesses of its lane;
 //   * the P2G scatter is atomic-free: gfx950 serialises ds_add_f32 (193 cycles per wave-instruction,
 //     profiles/r01_lds_microbench.txt), so the advection records of a block are counting-sorted by predicted stencil base
 //     and dealt to 64-record slices round-robin (prepare_blocks_kernel, once per substep): the 64 lanes of an iteration
@@ -715,23 +716,30 @@ __global__ void init_bins_kernel(int pbc, const int* __restrict__ counts, int* s
 	binoff_a[b]		= off;
 	binoff_b[b]		= off;
 }
-// array_to_buffer (:221-323) + init_adv_bucket (:96-104): one workgroup per block
+// array_to_buffer (:221-323) + init_adv_bucket (:96-104): one workgroup per block.  Record / row layout: mpm_g2p2g.hpp (nch = floats
+// per particle in a bin: 4 J-fluid, 9 fixed-corotated, 10 sand / NACC; the solid models start from b = F F^T = I).
+__device__ __forceinline__ int rec_floats(int nch) {
+	return nch == 4 ? 4 : 8;
+}
 __global__ __launch_bounds__(256) void fill_bins_kernel(GridCfg cfg, int nch, float log_jp0, const float* __restrict__ xyz, const int* __restrict__ ids, const int* __restrict__ size, const int* __restrict__ binoff, float* bins, int* list_in) {
 	const int b = blockIdx.x;
 	const int n = size[b];
 	for(int pidib = threadIdx.x; pidib < n; pidib += blockDim.x) {
 		const int pid = ids[(size_t) b * cfg.ppb + pidib];
-		const int rec = nch == 13 ? 12 : nch;// record layout: mpm_g2p2g.hpp (the 13th float, log Jp, sits in a row behind the bin's records)
+		const int rec = rec_floats(nch), row = nch - rec;
 		float* bin = bins + (size_t) (binoff[b] + (pidib >> 6)) * (kBin * nch);
 		float* dst = bin + (pidib & 63) * rec;
 		dst[0]	   = xyz[3 * (size_t) pid];
 		dst[1]	   = xyz[3 * (size_t) pid + 1];
 		dst[2]	   = xyz[3 * (size_t) pid + 2];
-		if(nch == 4) {
-			dst[3] = 1.f;
-		} else {
-			for(int d = 0; d < 9; ++d) dst[3 + d] = (d % 4 == 0) ? 1.f : 0.f;
-			if(nch == 13) bin[kBin * rec + (pidib & 63)] = log_jp0;
+		dst[3]	   = 1.f;// J, or b00
+		if(nch != 4) {
+			dst[4] = 1.f;// b11
+			dst[5] = 1.f;// b22
+			dst[6] = 0.f;// b10
+			dst[7] = 0.f;// b20
+			bin[kBin * rec + (pidib & 63) * row] = 0.f;// b21
+			if(row == 2) bin[kBin * rec + (pidib & 63) * row + 1] = log_jp0;
 		}
 		const int cx = node_index(xyz[3 * (size_t) pid], cfg.dx_inv) - 2, cy = node_index(xyz[3 * (size_t) pid + 1], cfg.dx_inv) - 2, cz = node_index(xyz[3 * (size_t) pid + 2], cfg.dx_inv) - 2;
 		const int key = (((cy & 3) + 1) * 6 + ((cx & 3) + 1)) * 6 + ((cz & 3) + 1);// stencil base in the block's node cube, y slowest (mpm_g2p2g.hpp); no motion predicted
@@ -780,9 +788,10 @@ __global__ __launch_bounds__(256) void retrieve_kernel(GridCfg cfg, int nch, con
 		dir_components((rec >> (cfg.pid_bits + kKeyBits)) & 31, ox, oy, oz);
 		const int sp	 = rec & (cfg.ppb - 1);
 		const int srcno	 = table_query(cfg, prev_table, kx + ox, ky + oy, kz + oz);
-		const int recf	 = nch == 13 ? 12 : nch;
+		const int recf = rec_floats(nch), rowf = nch - recf;
 		const float* bin = bins_src + (size_t) (binoff_src[srcno] + (sp >> 6)) * (kBin * nch);
 		const float* src = bin + (sp & 63) * recf;
+		const float* row = bin + kBin * recf + (sp & 63) * rowf;
 		const unsigned long long o = atomicAdd(counter, 1ull);
 		if(o >= capacity) continue;
 		xyz[3 * o]	   = src[0];
@@ -792,11 +801,14 @@ __global__ __launch_bounds__(256) void retrieve_kernel(GridCfg cfg, int nch, con
 			if(nch == 4) {
 				state9[9 * o] = src[3];
 				for(int d = 1; d < 9; ++d) state9[9 * o + d] = 0.f;
-			} else {
-				for(int d = 0; d < 9; ++d) state9[9 * o + d] = src[3 + d];
+			} else {// b = F F^T as a full symmetric matrix (the sign of b00 marks a reflected F: reported as it is stored)
+				const float s6[6] = {src[3], src[4], src[5], src[6], src[7], row[0]};
+				float m[9];
+				sym_expand(s6, m);
+				for(int d = 0; d < 9; ++d) state9[9 * o + d] = m[d];
 			}
 		}
-		if(logjp) logjp[o] = nch == 13 ? bin[kBin * recf + (sp & 63)] : 0.f;
+		if(logjp) logjp[o] = rowf == 2 ? row[1] : 0.f;
 	}
 }
 
@@ -817,33 +829,41 @@ __global__ void grid_totals_kernel(int nblocks, const float* __restrict__ grid, 
 // ------------------------------------------------------------------------------------------------------
 // Function-level test kernels (device math vs golden vectors)
 // ------------------------------------------------------------------------------------------------------
+// (inputs are deformation gradients F: the kernels form b = F F^T and the reflection flag the way a particle would carry them)
 __global__ void test_eig_kernel(size_t n, const float* __restrict__ Fin, float* __restrict__ out12) {
 	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
 	const size_t j = i < n ? i : n - 1;// every lane runs the decomposition (its sweep count is wave-uniform)
-	float F[9], lam[3], U[9];
+	float F[9], b[6], lam[3], U[9];
 	for(int d = 0; d < 9; ++d) F[d] = Fin[9 * j + d];
+	left_cauchy_green(F, b);
 	NoHook nh;
 	bool undeformed;
-	sym_eig3<0>(F, lam, U, nh, undeformed);
+	sym_eig3<0>(b, lam, U, nh, undeformed);
 	if(i >= n) return;
 	for(int d = 0; d < 9; ++d) out12[12 * i + d] = U[d];
 	for(int d = 0; d < 3; ++d) out12[12 * i + 9 + d] = lam[d];
 }
-__global__ void test_stress_kernel(int material, MaterialConst mc, size_t n, const float* __restrict__ Fin, const float* __restrict__ ljin, float* __restrict__ out19) {
+// out19: the updated b (full symmetric matrix), P F^T vol, log Jp; out_refl (may be null): the reflection flag after the update
+__global__ void test_stress_kernel(int material, MaterialConst mc, size_t n, const float* __restrict__ Fin, const float* __restrict__ ljin, float* __restrict__ out19, int* __restrict__ out_refl) {
 	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if(i >= n) return;
-	float F[9], PF[9];
-	for(int d = 0; d < 9; ++d) F[d] = Fin[9 * i + d];
-	float lj = ljin ? ljin[i] : 0.f;
+	const size_t j = i < n ? i : n - 1;// (the stress functions hold wave-level votes: every lane of a wave runs them)
+	float F[9], b[6], PF[9], bm[9];
+	for(int d = 0; d < 9; ++d) F[d] = Fin[9 * j + d];
+	left_cauchy_green(F, b);
+	bool refl = det3(F) < 0.f;
+	float lj  = ljin ? ljin[j] : 0.f;
 	if(material == 1)
-		stress_fixed_corotated(mc, F, PF);
+		stress_fixed_corotated(mc, b, refl, PF);
 	else if(material == 2)
-		stress_sand(mc, F, lj, PF);
+		stress_sand(mc, b, refl, lj, PF);
 	else
-		stress_nacc(mc, F, lj, PF);
-	for(int d = 0; d < 9; ++d) out19[19 * i + d] = F[d];
+		stress_nacc(mc, b, refl, lj, PF);
+	if(i >= n) return;
+	sym_expand(b, bm);
+	for(int d = 0; d < 9; ++d) out19[19 * i + d] = bm[d];
 	for(int d = 0; d < 9; ++d) out19[19 * i + 9 + d] = PF[d];
 	out19[19 * i + 18] = lj;
+	if(out_refl) out_refl[i] = refl ? 1 : 0;
 }
 
 }// namespace mpm

@@ -153,7 +153,10 @@ int mpm_run_fixed(mpm_ctx* ctx, int nsteps, float dt);
  * unspecified.  *n: in = capacity of xyz in particles, out = particles written. */
 int mpm_retrieve_positions(mpm_ctx* ctx, int model, float* xyz, size_t* n);
 /* Extension used by the parity tests: also the per-particle state, same order as xyz.
- * state9: F (column-major 9 floats) for FC/SAND/NACC, or J in state9[9*i] for J_FLUID; logjp may be NULL. */
+ * state9: for FC/SAND/NACC the left Cauchy-Green tensor b = F F^T (symmetric 3x3, 9 floats) - the state this engine carries
+ * instead of the reference's F: every model on the path is isotropic, so positions, grid and log Jp depend on F only through b
+ * (claymore_amd/csrc/mpm_device_math.hpp); a negative state9[9*i] marks a reflected F (det F < 0, |.| is b00) -, or J in
+ * state9[9*i] for J_FLUID; logjp may be NULL.  The reference itself retrieves positions only (mgmpm_kernels.cuh:1087-1122). */
 int mpm_retrieve_state(mpm_ctx* ctx, int model, float* xyz, float* state9, float* logjp, size_t* n);
 
 int mpm_get_counts(mpm_ctx* ctx, mpm_counts* counts);
@@ -213,6 +216,10 @@ int mpm_grid_totals(mpm_ctx* ctx, double out[4]);
 /* Dense dump of the current grid for parity tests: for every neighbor block, key (3 ints) and 256 floats
  * {mass[64], mvx[64], mvy[64], mvz[64]} (grid_buffer.cuh:12-14 layout). *nblocks in = capacity, out = count. */
 int mpm_dump_grid(mpm_ctx* ctx, int* keys, float* blocks, size_t* nblocks);
+/* How the library was built: "claymore_hip <abi> experiment=<none | list of -D switches>".  A product library reports
+ * experiment=none (claymore_amd/csrc/mpm_device_math.hpp: the switches that change what the kernels compute only exist under
+ * -DMPM_EXPERIMENT); tests/test_abi.py asserts it for the shipped library.  Needs no device. */
+const char* mpm_build_info(void);
 /* G2P2G kernel time of the last call as measured with HIP events on the compute stream. */
 int mpm_last_g2p2g_ms(mpm_ctx* ctx, float* ms);
 
@@ -221,7 +228,8 @@ int mpm_last_g2p2g_ms(mpm_ctx* ctx, float* ms);
  * values only, V cancels): the eigen-decomposition F F^T = U diag(lam) U^T, lam_k = sigma_k^2, U a rotation, columns in no
  * particular order.  F[n*9] column-major -> out[n*12] = U(9) lam(3). */
 int mpm_test_eig(const float* F, size_t n, float* out12, int device);
-/* compute_stress<M> (Projects/GMPM/constitutive_models.cuh): out19 = F'(9) PF(9) logjp'(1). */
+/* compute_stress<M> (Projects/GMPM/constitutive_models.cuh) on deformation gradients F[n*9]: out19 = b'(9) PF(9) logjp'(1), b' the
+ * left Cauchy-Green tensor F' F'^T of the model's (possibly projected) F' - what a particle of this engine stores. */
 int mpm_test_stress(int material, const mpm_material_params* p, const float* F, const float* logjp, size_t n, float* out19, int device);
 
 /* ---- multi-GPU (MGSP static particle partition, Projects/MGSP/mgsp_benchmark.cuh:661-776) ----

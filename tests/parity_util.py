@@ -41,6 +41,21 @@ def run_pair(scene, nsteps, dt=None, **kw):
     return {"hip": hip, "oracle": ora, "scene": scene}
 
 
+def to_b(state9, from_hip):
+    """The comparable per-particle state: the left Cauchy-Green tensor b = F F^T (n, 9).  The HIP engine carries b itself
+    (claymore_amd/csrc/mpm_device_math.hpp; the sign of its first entry marks a reflected F), the oracle carries the
+    reference's F; the J-fluid's state is J in column 0 on both sides."""
+    s = np.asarray(state9, dtype=np.float64)
+    if s.size == 0 or not np.any(s[:, 1:]):
+        return s
+    if from_hip:
+        s = s.copy()
+        s[:, 0] = np.abs(s[:, 0])
+        return s
+    F = s.reshape(-1, 3, 3).transpose(0, 2, 1)          # column-major 9 -> F[i, j]
+    return np.einsum("nij,nkj->nik", F, F).reshape(-1, 9)
+
+
 def match(xa, xb):
     """Index array idx with xb[idx[i]] the match of xa[i]; asserts a bijection."""
     tree = cKDTree(xb)
@@ -50,7 +65,7 @@ def match(xa, xb):
 
 
 def match_and_compare(res):
-    worst = {"pos_rel": 0.0, "pos_abs": 0.0, "F_rel": 0.0, "logjp_abs": 0.0, "n": 0}
+    worst = {"pos_rel": 0.0, "pos_abs": 0.0, "state_rel": 0.0, "logjp_abs": 0.0, "n": 0}
     for (xh, sh, lh), (xo, so, lo) in zip(res["hip"]["state"], res["oracle"]["state"]):
         assert xh.shape == xo.shape, (xh.shape, xo.shape)
         idx, d = match(xo.astype(np.float64), xh.astype(np.float64))
@@ -58,8 +73,9 @@ def match_and_compare(res):
         rel = dx / np.abs(xo).max(axis=1)
         worst["pos_rel"] = max(worst["pos_rel"], float(rel.max()))
         worst["pos_abs"] = max(worst["pos_abs"], float(dx.max()))
-        dF = np.abs(sh[idx].astype(np.float64) - so.astype(np.float64)).max(axis=1)
-        worst["F_rel"] = max(worst["F_rel"], float((dF / np.maximum(1.0, np.abs(so).max(axis=1))).max()))
+        bh, bo = to_b(sh, True), to_b(so, False)
+        dF = np.abs(bh[idx] - bo).max(axis=1)
+        worst["state_rel"] = max(worst["state_rel"], float((dF / np.maximum(1.0, np.abs(bo).max(axis=1))).max()))
         worst["logjp_abs"] = max(worst["logjp_abs"], float(np.abs(lh[idx] - lo).max()))
         worst["n"] += xh.shape[0]
     th, to = res["hip"]["totals"], res["oracle"]["totals"]

@@ -63,3 +63,26 @@ def test_no_cpu_fallback_without_gpu():
     from claymore_amd.engine import Engine, EngineError
     with pytest.raises(EngineError):
         Engine(domain_bits=7)
+
+
+def test_shipped_library_has_no_experiment_switch():
+    """Every switch that changes what the kernels compute (timing hacks that leave physics out, A/B variants) lives behind
+    -DMPM_EXPERIMENT; the library build() ships reports none, and build()'s flags contain no MPM_ define at all."""
+    hip = _ffi.load_hip()
+    info = hip.build_info().decode()
+    assert info.startswith("claymore_hip ") and info.endswith("experiment=none"), info
+    import __graft_entry__ as ge
+    assert not [f for f in ge.HIP_FLAGS if "MPM_" in f]
+
+
+def test_experiment_switch_without_the_guard_does_not_compile():
+    """A stray -DMPM_HACK_* (or any other experiment switch) without -DMPM_EXPERIMENT is a compile error (preprocessor only: fast)."""
+    import subprocess
+    import __graft_entry__ as ge
+    src = os.path.join(ROOT, "claymore_amd", "csrc", "mpm_device_math.hpp")
+    base = [ge.HIPCC, "--offload-arch=gfx950", "-std=c++17", "--cuda-device-only", "-x", "hip", "-E", "-o", os.devnull, src]
+    assert subprocess.run(base, capture_output=True).returncode == 0
+    for sw in ("MPM_HACK_NOSERIAL", "MPM_HACK_NOSHELL", "MPM_HACK_NOWB", "MPM_HACK_UNDEF", "MPM_G2P2G_WAVES=2"):
+        r = subprocess.run(base + ["-D" + sw], capture_output=True, text=True)
+        assert r.returncode != 0 and "MPM_EXPERIMENT" in r.stderr, (sw, r.stderr[-300:])
+        assert subprocess.run(base + ["-D" + sw, "-DMPM_EXPERIMENT"], capture_output=True).returncode == 0

@@ -12,7 +12,7 @@ import torch
 
 from claymore_amd import _ffi, scenes
 from claymore_amd.mgsp import LocalGroup, MgspGroupRank, MgspRank
-from parity_util import match, run_engine
+from parity_util import match, run_engine, to_b
 from oracle_ffi import oracle_api
 
 pytestmark = pytest.mark.gpu
@@ -115,7 +115,7 @@ def test_multi_context_equals_oracle(world, kind, phased):
         idx, _ = match(xo.astype(np.float64), xm.astype(np.float64))
         rel = np.abs(xm[idx].astype(np.float64) - xo).max(axis=1) / np.abs(xo).max(axis=1)
         assert rel.max() < 1e-5, rel.max()
-        assert np.abs(sm[idx] - so).max() < 1e-4
+        assert np.abs(to_b(sm, True)[idx] - to_b(so, False)).max() < 1e-4
 
 
 # ---- the C++ group driver (claymore_amd/csrc/mpm_group.inc) -----------------------------------------------------------
@@ -172,7 +172,7 @@ def _compare_with_oracle(sc, res, nsteps, dt, tol=1e-5):
         idx, _ = match(xo.astype(np.float64), xm.astype(np.float64))
         rel = np.abs(xm[idx].astype(np.float64) - xo).max(axis=1) / np.abs(xo).max(axis=1)
         assert rel.max() < tol, rel.max()
-        assert np.abs(sm[idx] - so).max() < 1e-4
+        assert np.abs(to_b(sm, True)[idx] - to_b(so, False)).max() < 1e-4
 
 
 @pytest.mark.parametrize("world,kind", [(2, "collide"), (4, "collide"), (3, "sand")])

@@ -22,8 +22,10 @@ from claymore_amd.engine import build_engine  # noqa: E402
 
 
 def load(path):
+    """(a library of an earlier round may lack entry points that were added since: those stay unbound)"""
     lib = C.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
-    return _ffi.bind(lib, "mpm_", hip=True)
+    names = {n: sig for n, sig in {**_ffi.SIGNATURES, **_ffi.HIP_ONLY}.items() if hasattr(lib, "mpm_" + n)}
+    return _ffi.Api(lib, "mpm_", names)
 
 
 def window(eng, warm, steps, dt):
