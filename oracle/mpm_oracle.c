@@ -1282,6 +1282,40 @@ void mpmo_fn_dir_components(int dir, int d[3]) {
 float mpmo_fn_compute_dt(float max_vel, float cur, float next, float dt_default, float dx, float cfl) {
 	return orc_compute_dt(max_vel, cur, next, dt_default, dx, cfl);
 }
+float mpmo_fn_compute_dt_mgsp(float max_vel, float cur, float next, float dt_default, float dx) {
+	return orc_compute_dt_mgsp(max_vel, cur, next, dt_default, dx);
+}
+/* the collision object's functions one by one (golden vectors G13-G15, Projects/MGSP/boundary_condition.cuh:67-248) */
+void mpmo_fn_rot_angle_to_matrix(float omega, int dim, float* out9) {
+	col_rot_angle_to_matrix(omega, dim, out9);
+}
+/* x[n*3] -> out6 = {inside the wall-free zone, query_sdf, sdis, normal[3]} (sdis / normal only where inside) */
+int mpmo_fn_query_sdf(const mpmo_ctx* c, const float* x, size_t n, float* out6) {
+	if(!c || !c->has_collision) return MPM_ERR_NOT_READY;
+	const float lo = (float) c->cfg.boundary_blocks * c->dx * 4.f;
+	const float hi = (float) (c->G - c->cfg.boundary_blocks) * 4.f * c->dx;
+	for(size_t i = 0; i < n; ++i) {
+		const float* p = x + 3 * i;
+		float* o	   = out6 + 6 * i;
+		float nq[3]	   = {0.f, 0.f, 0.f};
+		const int inside = !(p[0] < lo || p[0] >= hi || p[1] < lo || p[1] >= hi || p[2] < lo || p[2] >= hi);
+		o[0] = (float) inside;
+		o[1] = (float) col_query_sdf(c, nq, p);
+		o[2] = o[3] = o[4] = o[5] = 0.f;
+		if(inside) o[2] = col_signed_distance_and_normal(c, p, o + 3);
+	}
+	return MPM_OK;
+}
+/* nodes[n*3] (global node indices), vel[n*3] in place: detect_and_resolve_collision at `time` with the installed object */
+int mpmo_fn_collision_resolve(const mpmo_ctx* c, const int* nodes, size_t n, float time, float* vel) {
+	if(!c || !c->has_collision) return MPM_ERR_NOT_READY;
+	for(size_t i = 0; i < n; ++i) {
+		const int block_id[3] = {nodes[3 * i] / 4, nodes[3 * i + 1] / 4, nodes[3 * i + 2] / 4};
+		const int cell_id[3]  = {nodes[3 * i] - block_id[0] * 4, nodes[3 * i + 1] - block_id[1] * 4, nodes[3 * i + 2] - block_id[2] * 4};
+		col_detect_and_resolve(c, block_id, cell_id, time, vel + 3 * i);
+	}
+	return MPM_OK;
+}
 void mpmo_fn_mat(const float* a, const float* b, const float* diag, float* out36) {
 	float e[9];
 	orc_matmul3(a, b, out36);

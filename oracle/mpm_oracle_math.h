@@ -54,6 +54,24 @@ static inline float orc_compute_dt(float max_vel, float cur_time, float next_tim
 	return dt;
 }
 
+/* Projects/MGSP/utility_funcs.hpp:32-55 compute_dt of the MGSP project: CFL 0.3, the frame is never overshot, and a step that
+ * does not end the frame is at most 0.51 of what is left of it (pinned by tests/golden/g12_mgsp_dt_*.f32) */
+static inline float orc_compute_dt_mgsp(float max_vel, float cur, float next, float dt_default, float dx) {
+	if(next < cur) return 0.0f;
+	float dt = dt_default;
+	if(max_vel > 0.0f) {
+		max_vel = dx * 0.3f / max_vel;
+		if(max_vel < dt_default) dt = max_vel;
+	}
+	if(cur + dt >= next) {
+		dt = next - cur;
+	} else {
+		max_vel = (next - cur) * 0.51f;
+		if(max_vel < dt) dt = max_vel;
+	}
+	return dt;
+}
+
 /* ---- Library/MnBase/Math/Matrix/MatrixUtils.h (column-major 3x3) ---- */
 /* :147-157 */
 static inline void orc_matmul3(const float* a, const float* b, float* c) {

@@ -23,6 +23,13 @@ def oracle_api():
         lib.mpmo_fn_dir_components.argtypes = [i, ip]
         lib.mpmo_fn_compute_dt.argtypes = [f] * 6
         lib.mpmo_fn_compute_dt.restype = f
+        lib.mpmo_fn_compute_dt_mgsp.argtypes = [f] * 5
+        lib.mpmo_fn_compute_dt_mgsp.restype = f
+        lib.mpmo_fn_rot_angle_to_matrix.argtypes = [f, i, C.c_void_p]
+        lib.mpmo_fn_query_sdf.argtypes = [C.c_void_p, C.c_void_p, sz, C.c_void_p]
+        lib.mpmo_fn_query_sdf.restype = i
+        lib.mpmo_fn_collision_resolve.argtypes = [C.c_void_p, C.c_void_p, sz, f, C.c_void_p]
+        lib.mpmo_fn_collision_resolve.restype = i
         lib.mpmo_fn_mat.argtypes = [C.c_void_p] * 4
         lib.mpmo_fn_jfluid.argtypes = [C.c_void_p, C.c_void_p, sz, f, f, f, f, f, f, C.c_void_p]
         lib.mpmo_check_table.argtypes = [C.c_void_p]

@@ -4,6 +4,7 @@ import pytest
 
 from claymore_amd import _ffi, scenes
 from claymore_amd.engine import build_engine
+from oracle_ffi import oracle_api
 from parity_util import match
 
 pytestmark = pytest.mark.gpu
@@ -32,6 +33,15 @@ def test_restart_follows_the_uninterrupted_run(scene):
     ref.run_fixed(30, dt)
     want = [ref.retrieve_positions(m) for m in range(len(sc["models"]))]
     ref.close()
+    # the yardstick is the ORACLE's uninterrupted 60-substep run (the HIP run above only says what float-atomic noise to expect)
+    ora = build_engine(sc, api=oracle_api())
+    ora.initial_setup()
+    ora.run_fixed(60, dt)
+    want_oracle = [ora.retrieve_positions(m) for m in range(len(sc["models"]))]
+    ora.close()
+    for m, w in enumerate(want_oracle):
+        ok, err = _close(want[m], w, 1e-5)
+        assert ok, (scene, m, err)
 
     # (1) a fresh context: same models, initial_setup, then load
     eng = build_engine(sc)
@@ -41,13 +51,19 @@ def test_restart_follows_the_uninterrupted_run(scene):
     assert np.array_equal(k, keys_at_save) and np.array_equal(g, grid_at_save)     # the grid came back bit for bit
     eng.run_fixed(30, dt)
     for m, w in enumerate(want):
-        ok, err = _close(eng.retrieve_positions(m), w, 2e-6)     # float atomics make two runs differ in the last bits
+        got = eng.retrieve_positions(m)
+        ok, err = _close(got, w, 2e-6)     # float atomics make two runs differ in the last bits
+        assert ok, (scene, m, err)
+        ok, err = _close(got, want_oracle[m], 1e-5)              # the restarted run against the oracle's uninterrupted one
         assert ok, (scene, m, err)
     # (2) rewinding the same context
     eng.load_checkpoint(ckpt)
     eng.run_fixed(30, dt)
     for m, w in enumerate(want):
-        ok, err = _close(eng.retrieve_positions(m), w, 2e-6)
+        got = eng.retrieve_positions(m)
+        ok, err = _close(got, w, 2e-6)
+        assert ok, (scene, m, err)
+        ok, err = _close(got, want_oracle[m], 1e-5)
         assert ok, (scene, m, err)
     eng.close()
 

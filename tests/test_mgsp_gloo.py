@@ -82,13 +82,14 @@ def _single(kind, nsteps, adaptive=False):
     eng.initial_setup()
     dts = None
     if adaptive:
-        # one rank, phase by phase, with the MGSP project's own compute_dt (utility_funcs.hpp:32-55: CFL 0.3, 0.51 rule)
-        from claymore_amd.mgsp import MgspRank
-        rule = MgspRank.compute_dt_mgsp
+        # one rank, phase by phase, with the MGSP project's own compute_dt (utility_funcs.hpp:32-55: CFL 0.3, 0.51 rule) in the ORACLE's
+        # restatement, which tests/golden/g12_mgsp_dt_* pin to the reference's outputs (not the package's MgspRank.compute_dt_mgsp: that is
+        # what the ranks under test run)
+        rule = oracle_api().raw.mpmo_fn_compute_dt_mgsp
         t, cur, dts = 0.0, 1e-4, []
         for _ in range(nsteps):
             mv = float(np.sqrt(eng.grid_update(cur)))
-            nd = rule(type("E", (), {"eng": eng})(), mv, t + cur, 1.0 / 24.0, 2e-3)
+            nd = float(rule(mv, float(np.float32(t + cur)), float(np.float32(1.0 / 24.0)), 2e-3, float(eng.dx)))
             eng.g2p2g(cur, nd)
             eng.rebuild_partition()
             t += cur

@@ -228,6 +228,24 @@ def test_rccl_transport_single_rank_equals_plain_engine():
         assert np.abs(got[m][0][idx] - xo).max() < 2e-6
 
 
+def test_cpp_group_compute_dt_equals_the_reference_golden():
+    """mpm_group_compute_dt - the dt rule inside mpm_group_main_loop - against the outputs of the MGSP project's own compute_dt
+    (Projects/MGSP/utility_funcs.hpp:32-55; tests/golden/g12_mgsp_dt_*, generated by tests/golden/gen/gen_golden_mgsp.sh): bit for bit.
+    The reference's grid is 256^3 (Projects/MGSP/settings.h: DOMAIN_BITS = 8), so is the context's."""
+    import os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    rows = np.fromfile(os.path.join(g, "g12_mgsp_dt_in.f32"), dtype=np.float32).reshape(-1, 4)
+    want = np.fromfile(os.path.join(g, "g12_mgsp_dt_out.f32"), dtype=np.float32)
+    sc = scenes.two_spheres(bits=8, radius_cells=4.0, gap_cells=3.0)
+    sim = MgspGroupRank(sc, 0, 1, device=0)
+    try:
+        for (mv, cur, nxt, dtd), w in zip(rows, want):
+            got = np.float32(sim.api.group_compute_dt(sim.grp, float(mv), float(cur), float(nxt), float(dtd)))
+            assert got.view(np.uint32) == np.float32(w).view(np.uint32), (mv, cur, nxt, dtd, got, w)
+    finally:
+        sim.close()
+
+
 def test_cpp_group_adaptive_main_loop_matches_frames():
     """mpm_group_main_loop: MGSP's compute_dt (CFL 0.3, 0.51 rule) from the maximum velocity over all ranks; two frames."""
     sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=0.5, speed=2.0, youngs=2e4)
@@ -245,15 +263,20 @@ def _oracle_mgsp_main_loop(sc, frames, fps, dt_default, threads=8):
     """MgspBenchmark::main_loop (mgsp_benchmark.cuh:361-559) on the single-rank CPU oracle: the same adaptive loop the C++ group
     driver runs (MGSP's compute_dt - CFL 0.3, 0.51 frame-remainder rule, Projects/MGSP/utility_funcs.hpp:32-55 - from the maximum
     grid velocity, per-frame clock), phase by phase through the oracle's C ABI."""
-    import types
     from claymore_amd.engine import build_engine
     api = oracle_api()
     eng = build_engine(sc, api=api)
     eng.initial_setup()
     api.raw.mpmo_set_threads(eng.ctx, threads)
-    shim = types.SimpleNamespace(eng=types.SimpleNamespace(dx=eng.dx))
+    # the dt rule is the ORACLE's restatement of Projects/MGSP/utility_funcs.hpp:32-55 (pinned to the reference's outputs by
+    # tests/golden/g12_mgsp_dt_*), not the product package's: the C++ driver is compared with the checker, not with a sibling
+    dx = float(eng.dx)
+
+    def rule(mv, cur, nxt, dtd):
+        return float(api.raw.mpmo_fn_compute_dt_mgsp(float(mv), float(cur), float(nxt), float(dtd), dx))
+
     spf = float(np.float32(1.0) / np.float32(fps))
-    nd = MgspRank.compute_dt_mgsp(shim, 0.0, 0.0, spf, dt_default)
+    nd = rule(0.0, 0.0, spf, dt_default)
     steps = 0
     for _ in range(frames):
         t = np.float32(0.0)
@@ -261,9 +284,9 @@ def _oracle_mgsp_main_loop(sc, frames, fps, dt_default, threads=8):
             dt = nd
             assert dt > 0.0
             mv = float(np.sqrt(np.float32(eng.grid_update(dt))))
-            nd = MgspRank.compute_dt_mgsp(shim, mv, float(np.float32(t + np.float32(dt))), spf, dt_default)
+            nd = rule(mv, float(np.float32(t + np.float32(dt))), spf, dt_default)
             if not nd > 0.0:
-                nd = MgspRank.compute_dt_mgsp(shim, mv, 0.0, spf, dt_default)
+                nd = rule(mv, 0.0, spf, dt_default)
             eng.g2p2g(dt, nd)
             eng.rebuild_partition()
             t = np.float32(t + np.float32(dt))

@@ -196,3 +196,120 @@ def test_g7_jfluid_closed_form():
     # J^-gamma - 1 cancels near J = 1: allow an absolute slack of a few fp32 ulps of bulk * voln
     slack = (2e-6 * bulk * voln * gamma)[:, None]
     assert (np.abs(out[:, 1:] - want.reshape(n, 9)) <= 2e-5 * np.abs(want.reshape(n, 9)) + slack).all()
+
+
+# ---- the MGSP project's host-compilable functions (tests/golden/gen/gen_golden_mgsp.cpp) ---------------------------------------------
+def test_g12_mgsp_compute_dt_bit_exact():
+    """compute_dt of the MGSP project (Projects/MGSP/utility_funcs.hpp:32-55: CFL 0.3, 0.51 frame-remainder rule): the oracle's
+    restatement AND the product package's Python restatement (MgspRank.compute_dt_mgsp, the dt rule of the gloo / torch driver)
+    against the reference's own outputs.  (The C++ group driver's mpm_group_compute_dt needs a context: tests/test_mgsp_gpu.py.)"""
+    import types
+    from claymore_amd.mgsp import MgspRank
+    api = oracle_api()
+    rows = f32("g12_mgsp_dt_in.f32").reshape(-1, 4)
+    want = f32("g12_mgsp_dt_out.f32")
+    assert rows.shape[0] == want.size > 1000
+    dx = np.float32(1.0 / 256.0)                                  # Projects/MGSP/settings.h: DOMAIN_BITS = 8
+    shim = types.SimpleNamespace(eng=types.SimpleNamespace(dx=float(dx)))
+    for (mv, cur, nxt, dtd), w in zip(rows, want):
+        got = np.float32(api.raw.mpmo_fn_compute_dt_mgsp(float(mv), float(cur), float(nxt), float(dtd), float(dx)))
+        assert got.view(np.uint32) == np.float32(w).view(np.uint32), (mv, cur, nxt, dtd, got, w)
+        py = np.float32(MgspRank.compute_dt_mgsp(shim, float(mv), float(cur), float(nxt), float(dtd)))
+        assert py.view(np.uint32) == np.float32(w).view(np.uint32), (mv, cur, nxt, dtd, py, w)
+    assert (want == 0).any() and (want < rows[:, 3]).any() and (want == rows[:, 3]).any()      # every branch is represented
+
+
+def test_g13_rot_angle_to_matrix():
+    """SignedDistanceGrid::rot_angle_to_matrix (boundary_condition.cuh:67-91): cosf / sinf come from libm on both sides."""
+    api = oracle_api()
+    rows = f32("g13_rot_in.f32").reshape(-1, 2)
+    want = f32("g13_rot_out.f32").reshape(-1, 9)
+    got = np.empty(9, dtype=np.float32)
+    for (a, dim), w in zip(rows, want):
+        api.raw.mpmo_fn_rot_angle_to_matrix(float(a), int(dim), ptr(got))
+        assert np.abs(got - w).max() <= 2 * np.spacing(np.float32(1.0)), (a, dim, got, w)
+        assert np.array_equal((got == 0), (w == 0)) and np.array_equal(np.sign(got), np.sign(w))
+
+
+def hashed_sdf_field(n):
+    """The signed-distance field of the G14 / G15 goldens (gen_golden_mgsp.cpp: field_value): node (i, j, k), channel c -> a float in
+    [-1, 1) from integer hashing - exact in uint32 and float32, so numpy rebuilds the generator's 256^3 x 4 field bit for bit."""
+    i = (np.arange(n, dtype=np.uint32) * np.uint32(73856093))[:, None, None]
+    j = (np.arange(n, dtype=np.uint32) * np.uint32(19349663))[None, :, None]
+    k = (np.arange(n, dtype=np.uint32) * np.uint32(83492791))[None, None, :]
+    base = i ^ j ^ k
+    out = []
+    for c in range(4):
+        h = base ^ np.uint32((c * 0x9E3779B1) & 0xFFFFFFFF)
+        h = h * np.uint32(2654435761)
+        h ^= h >> np.uint32(15)
+        h = h * np.uint32(2246822519)
+        h ^= h >> np.uint32(13)
+        out.append(((h >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)) * np.float32(2.0) - np.float32(1.0))
+    return out
+
+
+@pytest.fixture(scope="module")
+def collision_oracle():
+    """An oracle context on the MGSP project's grid (256^3, wall zone of 2 blocks) with the hashed field installed."""
+    api = oracle_api()
+    cfg = _ffi.Config()
+    assert api.default_config(8, C.byref(cfg)) == 0
+    ctx = C.c_void_p()
+    assert api.create(C.byref(cfg), 0, C.byref(ctx)) == 0
+    field = hashed_sdf_field(256)
+
+    def install(obj):
+        assert api.set_collision_object(ctx, C.byref(obj), ptr(field[0]), ptr(field[1]), ptr(field[2]), ptr(field[3])) == 0
+
+    yield api, ctx, install
+    api.destroy(ctx)
+
+
+def test_g15_signed_distance_and_normal(collision_oracle):
+    """get_signed_distance_and_normal / query_sdf (boundary_condition.cuh:99-146) at 768 points, a part of them in the wall zone or on
+    a node plane: the wall-zone test and the hit flag exactly, the interpolated distance and the normal bit for bit."""
+    api, ctx, install = collision_oracle
+    obj = _ffi.CollisionObject()
+    api.default_collision_object(C.byref(obj))
+    install(obj)
+    x = f32("g15_sdf_x.f32")
+    want = f32("g15_sdf_out.f32").reshape(-1, 6)
+    got = np.empty_like(want)
+    assert api.raw.mpmo_fn_query_sdf(ctx, ptr(x), want.shape[0], ptr(got)) == 0
+    assert np.array_equal(got[:, 0], want[:, 0]) and np.array_equal(got[:, 1], want[:, 1])
+    assert 0.05 < want[:, 0].mean() < 0.98 and 0.2 < want[want[:, 0] == 1, 1].mean() < 0.8
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_g14_detect_and_resolve_collision(collision_oracle):
+    """detect_and_resolve_collision (boundary_condition.cuh:164-248): STICKY / SLIP / SEPARATE x friction 0 / 0.3 x (object at rest,
+    t = 0 | translating, rotating, growing object at t = 0.37 with a start orientation), 384 grid nodes each."""
+    api, ctx, install = collision_oracle
+    cfgs = f32("g14_col_cfg.f32").reshape(-1, 23)
+    nodes = i32("g14_col_nodes.i32")
+    vin = f32("g14_col_vel_in.f32")
+    want = f32("g14_col_vel_out.f32").reshape(cfgs.shape[0], -1)
+    m = nodes.size // 3
+    assert cfgs.shape[0] == 12
+    changed = 0
+    for cf, w in zip(cfgs, want):
+        obj = _ffi.CollisionObject()
+        api.default_collision_object(C.byref(obj))
+        obj.type, obj.friction, obj.scale, obj.dsdt = int(cf[0]), float(cf[1]), float(cf[2]), float(cf[3])
+        for d in range(3):
+            obj.trans[d], obj.trans_vel[d], obj.omega[d] = float(cf[4 + d]), float(cf[7 + d]), float(cf[10 + d])
+        for e in range(9):
+            obj.rot_mat[e] = float(cf[13 + e])
+        install(obj)
+        vel = vin.copy()
+        assert api.raw.mpmo_fn_collision_resolve(ctx, ptr(nodes), m, float(cf[22]), ptr(vel)) == 0
+        hit = (w.reshape(m, 3) != vin.reshape(m, 3)).any(axis=1)
+        changed += int(hit.sum())
+        assert 0.2 < hit.mean() < 0.8                       # the hashed field puts about half of the nodes inside the object
+        if cf[22] == 0.0:                                   # t = 0: only IEEE +, -, *, / and sqrt between the inputs and the result
+            assert np.array_equal(vel.view(np.uint32), w.view(np.uint32)), (cf[:4],)
+        else:                                               # t != 0: cosf / sinf of the rotation angles go through libm
+            assert np.array_equal(vel != vin, w != vin)
+            assert np.abs(vel - w).max() <= 4e-6 * max(1.0, np.abs(w).max()), (cf[:4], np.abs(vel - w).max())
+    assert changed > 12 * m // 4
