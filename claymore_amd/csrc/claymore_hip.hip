@@ -599,7 +599,8 @@ static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, co
 	sk.dts	= dt * (4.f * g.dx_inv);
 	sk.pred = next_dt * g.dx_inv;
 	sk.am	= m.mc.mass * g.dx * g.dx * g.d_inv;
-	sk.cs	= next_dt * g.d_inv * g.dx;
+	const float cs = -next_dt * g.d_inv * g.dx;// the stress enters the P2G payload as -P F^T vol new_dt D^-1 dx (:850)
+	sk.ss	= StressScale {2.f * m.mc.mu * m.mc.volume * cs, m.mc.lambda * m.mc.volume * cs, m.mc.volume * cs};
 	sk.refl_lim = sk.dts > 0.f ? (1.f / 3.f) / sk.dts : 3.0e38f;
 	const int nwg = nblocks_ptr ? hint_blocks(ctx, nblocks) : nblocks;
 	switch(m.material) {

@@ -265,6 +265,14 @@ MPM_DEV void sym_expand(const float (&s)[6], float (&m)[9]) {
 	m[6] = s[4], m[7] = s[5], m[8] = s[2];
 }
 
+// The scale the stress leaves a model with, as uniform factors formed on the host (gfx950 has no scalar float ALU: a uniform product
+// formed in the kernel costs a vector instruction per iteration or a vector register for the whole loop).  Function-level tests pass
+// {2 mu vol, lambda vol, vol}: P F^T vol as the reference returns it; G2P2G passes the same times -new_dt D^-1 dx, so that the P2G
+// payload is one fused multiply-add per entry, A m D^-1 dx^2 + stress (:850 of mgmpm_kernels.cuh), instead of two instructions.
+struct StressScale {
+	float mu2v, lamv, vol;
+};
+
 // Material constants passed by value to the kernels (Projects/GMPM/particle_buffer.cuh:141-264)
 struct MaterialConst {
 	float mass, volume, mu, lambda;
@@ -274,13 +282,16 @@ struct MaterialConst {
 	float log_jp0;
 	int volume_correction, hardening_on;
 };
+MPM_DEV StressScale stress_scale(const MaterialConst& mc) {
+	return StressScale {2.0f * mc.mu * mc.volume, mc.lambda * mc.volume, mc.volume};
+}
 
 // compute_stress<FIXED_COROTATED>, Projects/GMPM/constitutive_models.cuh:36-73.
 // P F^T = U diag(P_hat_k sigma_k) U^T with P_hat_k sigma_k = 2 mu (sigma_k - 1) sigma_k + lambda (J - 1) J.
 // refl: det F < 0 - the smallest singular value carries the sign (svd.cuh:590-770).
 constexpr int kFcSites = kEigSites + 1;
 template<int BASE, class Hook>
-MPM_DEV void stress_fixed_corotated(const MaterialConst& mc, const float (&b)[6], bool refl, float (&PF)[9], Hook& hk) {
+MPM_DEV void stress_fixed_corotated(const StressScale& ss, const float (&b)[6], bool refl, float (&PF)[9], Hook& hk) {
 	float lam[3], U[9];
 	bool undeformed;
 	sym_eig3<BASE>(b, lam, U, hk, undeformed);
@@ -300,8 +311,8 @@ MPM_DEV void stress_fixed_corotated(const MaterialConst& mc, const float (&b)[6]
 		sig[2] = (!m0 && !m1) ? -sig[2] : sig[2];
 	}
 	const float J  = sig[0] * sig[1] * sig[2];
-	const float vl = mc.volume * mc.lambda * (J - 1.0f) * J;
-	const float vm = 2.0f * mc.mu * mc.volume;
+	const float vl = ss.lamv * (J - 1.0f) * J;
+	const float vm = ss.mu2v;
 	float d[3], pf[6];
 #pragma unroll
 	for(int k = 0; k < 3; ++k) d[k] = fmaf(vm, lam[k] - sig[k], vl);
@@ -311,7 +322,7 @@ MPM_DEV void stress_fixed_corotated(const MaterialConst& mc, const float (&b)[6]
 }
 MPM_DEV void stress_fixed_corotated(const MaterialConst& mc, const float (&b)[6], bool refl, float (&PF)[9]) {
 	NoHook nh;
-	stress_fixed_corotated<0>(mc, b, refl, PF, nh);
+	stress_fixed_corotated<0>(stress_scale(mc), b, refl, PF, nh);
 }
 
 // compute_stress<SAND>, constitutive_models.cuh:238-335 (Drucker-Prager return mapping, StVK-Hencky) in principal
@@ -320,7 +331,7 @@ MPM_DEV void stress_fixed_corotated(const MaterialConst& mc, const float (&b)[6]
 // A reflected F (refl) enters through |S| (:262) and leaves with det > 0 (the projection rebuilds U S_new V^T with S_new > 0).
 constexpr int kSandSites = kEigSites + 3;
 template<int BASE, class Hook>
-MPM_DEV void stress_sand(const MaterialConst& mc, float (&b)[6], bool& refl, float& log_jp, float (&PF)[9], Hook& hk) {
+MPM_DEV void stress_sand(const MaterialConst& mc, const StressScale& ss, float (&b)[6], bool& refl, float& log_jp, float (&PF)[9], Hook& hk) {
 	float lam[3], U[9];
 	bool undeformed;
 	sym_eig3<BASE>(b, lam, U, hk, undeformed);
@@ -383,7 +394,7 @@ MPM_DEV void stress_sand(const MaterialConst& mc, float (&b)[6], bool& refl, flo
 		const float trace_log_S = lnS[0] + lnS[1] + lnS[2];
 		float d[3], pf[6];
 #pragma unroll
-		for(int k = 0; k < 3; ++k) d[k] = (scaled_mu * lnS[k] + mc.lambda * trace_log_S) * mc.volume;
+		for(int k = 0; k < 3; ++k) d[k] = ss.mu2v * lnS[k] + ss.lamv * trace_log_S;
 		sym_from_eig(U, d, pf);
 		sym_expand(pf, PF);
 	} else {
@@ -394,7 +405,7 @@ MPM_DEV void stress_sand(const MaterialConst& mc, float (&b)[6], bool& refl, flo
 }
 MPM_DEV void stress_sand(const MaterialConst& mc, float (&b)[6], bool& refl, float& log_jp, float (&PF)[9]) {
 	NoHook nh;
-	stress_sand<0>(mc, b, refl, log_jp, PF, nh);
+	stress_sand<0>(mc, stress_scale(mc), b, refl, log_jp, PF, nh);
 }
 
 // compute_stress<NACC>, constitutive_models.cuh:77-234 (USE_JOSH_FRACTURE_PAPER branch) in principal stretches:
@@ -403,7 +414,7 @@ MPM_DEV void stress_sand(const MaterialConst& mc, float (&b)[6], bool& refl, flo
 // (the reference binary's --use_fast_math does the same).  refl = det F < 0.
 constexpr int kNaccSites = kEigSites + 2;
 template<int BASE, class Hook>
-MPM_DEV void stress_nacc(const MaterialConst& mc, float (&b)[6], bool& refl, float& log_jp, float (&PF)[9], Hook& hk) {
+MPM_DEV void stress_nacc(const MaterialConst& mc, const StressScale& ss, float (&b)[6], bool& refl, float& log_jp, float (&PF)[9], Hook& hk) {
 	float lam[3], U[9];
 	bool undeformed;
 	sym_eig3<BASE>(b, lam, U, hk, undeformed);
@@ -478,7 +489,7 @@ MPM_DEV void stress_nacc(const MaterialConst& mc, float (&b)[6], bool& refl, flo
 		const float trBn3	   = (Bn[0] + Bn[1] + Bn[2]) * (1.f / 3.f);
 		float d[3], pf[6];
 	#pragma unroll
-		for(int k = 0; k < 3; ++k) d[k] = (dev_b_coeff * (Bn[k] - trBn3) + i_coeff) * mc.volume;
+		for(int k = 0; k < 3; ++k) d[k] = (dev_b_coeff * (Bn[k] - trBn3) + i_coeff) * ss.vol;
 		sym_from_eig(U, d, pf);
 		sym_expand(pf, PF);
 	} else {
@@ -489,14 +500,15 @@ MPM_DEV void stress_nacc(const MaterialConst& mc, float (&b)[6], bool& refl, flo
 }
 MPM_DEV void stress_nacc(const MaterialConst& mc, float (&b)[6], bool& refl, float& log_jp, float (&PF)[9]) {
 	NoHook nh;
-	stress_nacc<0>(mc, b, refl, log_jp, PF, nh);
+	stress_nacc<0>(mc, stress_scale(mc), b, refl, log_jp, PF, nh);
 }
 
 // J-fluid (weakly compressible, Tait EOS + Newtonian viscosity), Projects/GMPM/mgmpm_kernels.cuh:476-505
-MPM_DEV float stress_jfluid(const MaterialConst& mc, float J, const float (&A)[9], float dt, float d_inv, float (&contrib)[9]) {
+// vol: the model's volume, or (G2P2G) volume times -new_dt D^-1 dx: see StressScale
+MPM_DEV float stress_jfluid(const MaterialConst& mc, float vol, float J, const float (&A)[9], float dt, float d_inv, float (&contrib)[9]) {
 	J += (A[0] + A[4] + A[8]) * dt * d_inv * J;
 	if(J < 0.1f) J = 0.1f;// reference compares with the double literal 0.1; no float lies in (0.1, 0.1f), so this is identical
-	const float voln	 = J * mc.volume;
+	const float voln	 = J * vol;
 	const float pressure = mc.bulk * (__builtin_amdgcn_exp2f(-mc.gamma * __builtin_amdgcn_logf(J)) - 1.f);// J^-gamma (J >= 0.1)
 	const float k		 = d_inv * mc.viscosity;
 	contrib[0]			 = ((A[0] + A[0]) * k - pressure) * voln;

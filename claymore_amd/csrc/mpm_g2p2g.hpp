@@ -318,71 +318,70 @@ MPM_DEV void serial_push(float4* __restrict__ arena, float4* __restrict__ queue,
 template<int NSITES>
 struct ScatterChain {
 	float4* node0;
-	P2GPayload pp;// element-wise copy: a reference member or a struct copy keeps the payload in scratch memory
 	float mass;
 	int win;// (int, not bool: a 1-byte member makes the compiler slice its neighbours into bytes)
 	float pw[3][3];
-	float b0, wij, bx0;
-	v2f_ b12, bx12;
-	float cp6[3];// contrib[6] * (k - fd_z) and {contrib[7], contrib[8]} * (k - fd_z): the z part of the affine momentum term,
-	v2f_ cp12[3];// the same for the nine pencils (computed once, 9 registers, instead of per node)
+	// The momentum a node (i, j, k) of the stencil receives is W_ijk (m v + C (x_ijk - x_p)), x_ijk - x_p = (i, j, k) - fd in cells: the
+	// affine term is walked INCREMENTALLY - slab = m v - C fd + i C_x, pencil = slab + j C_y, node = pencil + k C_z - with one add per
+	// component and move (x component scalar, y / z packed), where forming (i, j, k) - fd and multiplying cost three per node
+	float cx0, cy0, cz0, cz0x2;	  // x row of C: contrib[0], [3], [6] (column-major), and twice the last
+	v2f_ cx12, cy12, cz12, cz12x2;// y / z rows
+	float slab0, pen0, wij;
+	v2f_ slab12, pen12;
 	float4 acc;
 	MPM_DEV ScatterChain(float4* n0, const P2GPayload& p, float m, bool w)
 		: node0(n0)
 		, mass(m)
 		, win(w) {
 #pragma unroll
-		for(int d = 0; d < 3; ++d) {
-			pp.fd[d] = p.fd[d];
-			pp.mv[d] = p.mv[d];
-		}
-#pragma unroll
-		for(int d = 0; d < 9; ++d) pp.contrib[d] = p.contrib[d];
-#pragma unroll
-		for(int d = 0; d < 3; ++d) bspline_weight_cells(pp.fd[d], pw[d]);
-		const v2f_ c12 = {pp.contrib[7], pp.contrib[8]};
-#pragma unroll
-		for(int k = 0; k < 3; ++k) {
-			const float pz = (float) k - pp.fd[2];
-			cp6[k]		   = pp.contrib[6] * pz;
-			cp12[k]		   = c12 * pz;
-		}
+		for(int d = 0; d < 3; ++d) bspline_weight_cells(p.fd[d], pw[d]);
+		cx0	 = p.contrib[0], cy0 = p.contrib[3], cz0 = p.contrib[6];
+		cx12 = (v2f_) {p.contrib[1], p.contrib[2]}, cy12 = (v2f_) {p.contrib[4], p.contrib[5]}, cz12 = (v2f_) {p.contrib[7], p.contrib[8]};
+		slab0	= p.mv[0] - cx0 * p.fd[0] - cy0 * p.fd[1] - cz0 * p.fd[2];
+		slab12	= (v2f_) {p.mv[1], p.mv[2]} - cx12 * p.fd[0] - cy12 * p.fd[1] - cz12 * p.fd[2];
+		cz0x2	= cz0 + cz0;
+		cz12x2	= cz12 + cz12;
 		if(win) acc = node0[0];
 	}
-	MPM_DEV void step(int o) {// o is a compile-time constant after unrolling
+	MPM_DEV void step(int o) {// o is a compile-time constant after unrolling; called under `win`
 		const int i = o / 9, j = (o / 3) % 3, k = o % 3;
 		if(k == 0) {
-			if(j == 0) {// x part of the affine term: once per slab of nine nodes
-				const float px = (float) i - pp.fd[0];
-				bx0			   = pp.mv[0] + pp.contrib[0] * px;
-				bx12		   = (v2f_) {pp.mv[1], pp.mv[2]} + (v2f_) {pp.contrib[1], pp.contrib[2]} * px;
+			if(j == 0) {
+				if(i != 0) {
+					slab0 += cx0;
+					slab12 += cx12;
+				}
+				pen0  = slab0;
+				pen12 = slab12;
+			} else {
+				pen0 += cy0;
+				pen12 += cy12;
 			}
-			const float py = (float) j - pp.fd[1];
-			b0			   = bx0 + pp.contrib[3] * py;
-			b12			   = bx12 + (v2f_) {pp.contrib[4], pp.contrib[5]} * py;
-			wij			   = pw[0][i] * pw[1][j];
+			wij = pw[0][i] * pw[1][j];
 		}
 		const float W  = wij * pw[2][k];
-		const v2f_ m0  = {mass, b0 + cp6[k]};
-		const v2f_ t12 = b12 + cp12[k];
-		if(win) {// (letting the other lanes run the steps on a scratch stencil instead removes 81 exec-mask instructions per iteration and is slower: +1-4 % sand, +11 % J-fluid)
-			v2f_ a01 = {acc.x, acc.y};
-			v2f_ a23 = {acc.z, acc.w};
-			a01		 = m0 * W + a01;
-			a23		 = t12 * W + a23;
-			node0[i * kP2GStrideX + j * kP2GStrideY + k] = make_float4(a01.x, a01.y, a23.x, a23.y);
-			__asm__ volatile("" ::: "memory");
-			if(o + 1 < 27) {
-				const int i1 = (o + 1) / 9, j1 = ((o + 1) / 3) % 3, k1 = (o + 1) % 3;
-				acc			 = node0[i1 * kP2GStrideX + j1 * kP2GStrideY + k1];
-			}
+		const v2f_ m0  = {mass, k == 0 ? pen0 : (k == 1 ? pen0 + cz0 : pen0 + cz0x2)};
+		const v2f_ t12 = k == 0 ? pen12 : (k == 1 ? pen12 + cz12 : pen12 + cz12x2);
+		v2f_ a01 = {acc.x, acc.y};
+		v2f_ a23 = {acc.z, acc.w};
+		a01		 = m0 * W + a01;
+		a23		 = t12 * W + a23;
+		node0[i * kP2GStrideX + j * kP2GStrideY + k] = make_float4(a01.x, a01.y, a23.x, a23.y);
+		__asm__ volatile("" ::: "memory");
+		if(o + 1 < 27) {
+			const int i1 = (o + 1) / 9, j1 = ((o + 1) / 3) % 3, k1 = (o + 1) % 3;
+			acc			 = node0[i1 * kP2GStrideX + j1 * kP2GStrideY + k1];
 		}
 	}
 	template<int SITE>
 	MPM_DEV void at() {
 		static_assert(SITE >= 0 && SITE < NSITES, "site out of range");
+		// one exec-mask bracket per site (a site holds one or two steps).  (Letting the other lanes run the steps on a scratch stencil
+		// instead removes the brackets altogether and is slower: +1-4 % sand, +11 % J-fluid.)
+		if(win) {
 #pragma unroll
-		for(int o = SITE * 27 / NSITES; o < (SITE + 1) * 27 / NSITES; ++o) step(o);
+			for(int o = SITE * 27 / NSITES; o < (SITE + 1) * 27 / NSITES; ++o) step(o);
+		}
 	}
 };
 
@@ -392,7 +391,7 @@ struct StepConst {
 	float dts; // dt * dx * D^-1 = dt * 4 / dx: A (cell units) -> dt grad v
 	float pred;// new_dt / dx
 	float am;  // mass dx^2 D^-1
-	float cs;  // new_dt D^-1 dx
+	StressScale ss;// {2 mu, lambda, 1} * volume * (-new_dt D^-1 dx): the stress arrives as its P2G term (mpm_device_math.hpp)
 	float refl_lim;// (1/3) / dts: an entry of A beyond it could make det(I + dt grad v) <= 0 (the reflection bit of b, mpm_device_math.hpp)
 };
 
@@ -526,7 +525,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		const bool drain = idx0 >= size;
 		bool win		 = false;
 		const bool pv_in = pv_code >= 0;
-		P2GPayload pl;// (only pl.contrib is used inside the iteration: the stress P F^T vol; the payload itself is formed at the hand-over)
+		P2GPayload pl;// (only pl.contrib is used inside the iteration: -P F^T vol new_dt D^-1 dx; the payload itself is formed at the hand-over)
 		float vel[3], A[9], nfd[3];
 		bool in_arena = false;
 		int ncode	  = -1;
@@ -647,7 +646,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 #pragma unroll
 			for(int d = 0; d < 9; ++d) Aw[d] = A[d] * cfg.dx;
 			chain.template at<kPreSites + 0>();
-			const float J = stress_jfluid(mv.mc, st[0], Aw, dt, cfg.d_inv, pl.contrib);
+			const float J = stress_jfluid(mv.mc, sk.ss.vol, st[0], Aw, dt, cfg.d_inv, pl.contrib);
 			chain.template at<kPreSites + 1>();
 			dst[0] = make_float4(pos[0], pos[1], pos[2], J);
 		} else {
@@ -660,7 +659,9 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 #pragma unroll
 			for(int d = 1; d < 6; ++d) bo[d] = st[d];
 			{// det G <= 0 needs an entry of dt grad v beyond 1/3 (Gershgorin; a CFL-limited step stays orders of magnitude below)
-				const float amax = fmaxf(fmaxf(fmaxf(fabsf(A[0]), fabsf(A[1])), fmaxf(fabsf(A[2]), fabsf(A[3]))), fmaxf(fmaxf(fabsf(A[4]), fabsf(A[5])), fmaxf(fmaxf(fabsf(A[6]), fabsf(A[7])), fabsf(A[8]))));
+				// (four v_max3_f32 with |.| source modifiers)
+				const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(fabsf(A[0]), fabsf(A[1])), fabsf(A[2])), __builtin_fmaxf(__builtin_fmaxf(fabsf(A[3]), fabsf(A[4])), fabsf(A[5]))),
+												   __builtin_fmaxf(__builtin_fmaxf(fabsf(A[6]), fabsf(A[7])), fabsf(A[8])));
 				const bool wild	 = !(amax < sk.refl_lim);
 				if(__any(wild)) {
 					if(wild) refl ^= det3(G) < 0.f;
@@ -670,13 +671,13 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 			chain.template at<kPreSites + 0>();
 			float lj = 0.f;
 			if constexpr(MAT == 1) {
-				stress_fixed_corotated<kPreSites + 1>(mv.mc, bn, refl, pl.contrib, chain);
+				stress_fixed_corotated<kPreSites + 1>(sk.ss, bn, refl, pl.contrib, chain);
 			} else if constexpr(MAT == 2) {
 				lj = st[6];
-				stress_sand<kPreSites + 1>(mv.mc, bn, refl, lj, pl.contrib, chain);
+				stress_sand<kPreSites + 1>(mv.mc, sk.ss, bn, refl, lj, pl.contrib, chain);
 			} else {
 				lj = st[6];
-				stress_nacc<kPreSites + 1>(mv.mc, bn, refl, lj, pl.contrib, chain);
+				stress_nacc<kPreSites + 1>(mv.mc, sk.ss, bn, refl, lj, pl.contrib, chain);
 			}
 			dst[0] = make_float4(pos[0], pos[1], pos[2], refl ? -bn[0] : bn[0]);
 			dst[1] = make_float4(bn[1], bn[2], bn[3], bn[4]);
@@ -696,7 +697,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 				if(slot >= cfg.ppb)
 					atomicOr(&status[ST_OVERFLOW], 2);// reference drops beyond 128 per cell (:122-130)
 				else
-					mv.list_out[(size_t) dno * cfg.ppb + slot] = rec;
+					mv.list_out[((size_t) dno << cfg.pid_bits) + slot] = rec;// (ppb is a power of two: a 64-bit shift where the product took two v_mad_u64_u32)
 			}
 		}
 		} else if(pv_in) {
@@ -738,14 +739,14 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		//      payload (chain, p2g_serial), so that it can be computed straight into the loop-carried registers (no copies).
 		//      (:850) contrib = (A m - stress new_dt) D^-1, pre-multiplied by dx so that P2G can stay in cell units
 		{
-			const float am = sk.am, cs = sk.cs;
+			const float am = sk.am;
 #pragma unroll
 			for(int d = 0; d < 3; ++d) {
 				pv.fd[d] = nfd[d];
 				pv.mv[d] = mass * vel[d];
 			}
 #pragma unroll
-			for(int d = 0; d < 9; ++d) pv.contrib[d] = A[d] * am - pl.contrib[d] * cs;
+			for(int d = 0; d < 9; ++d) pv.contrib[d] = fmaf(A[d], am, pl.contrib[d]);// (pl.contrib = -stress new_dt D^-1 dx: StressScale)
 		}
 		pv_code = ncode;
 	}

@@ -141,7 +141,11 @@ __device__ __forceinline__ int block_append(int* counter, int amount) {
 // ------------------------------------------------------------------------------------------------------
 constexpr int kListChunk = 512;
 __device__ __forceinline__ int div_small(int n, int d) {// n / d for 0 <= n <= 512, 1 <= d <= 8 (exact, checked exhaustively)
-	return (n * ((65536 + d - 1) / d)) >> 16;
+	// ceil(65536 / d) for d = 2..8 as 16-bit fields of two constants: a division by a run-time d, even a wave-uniform one, is ~40 scalar
+	// instructions of reciprocal refinement, and G2P2G forms a slice length in every iteration
+	const unsigned long long lo = 0x3334400055568000ull, hi = 0x200024932aabull;
+	const unsigned inv = d == 1 ? 65536u : (unsigned) ((d < 6 ? lo >> (16 * (d - 2)) : hi >> (16 * (d - 6))) & 0xffffull);
+	return (int) (((unsigned) n * inv) >> 16);
 }
 __device__ __forceinline__ int chunk_records(int size, int chunk) {
 	return min(kListChunk, size - chunk * kListChunk);
