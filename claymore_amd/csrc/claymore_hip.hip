@@ -23,7 +23,7 @@ using namespace mpm;
 namespace {
 // ONE device block (and its pinned mirror) holds everything the host reads back at a synchronisation: the status words, the MGSP halo
 // counters + the peers' key-list lengths, and the max |v|^2 slots - one device-to-host copy instead of three.
-constexpr int kHaloWords	 = 128;// 2 + 32 send counts + 32 peer list lengths, padded
+constexpr int kHaloWords	 = 128;// 2 + 32 send counts + 32 peer list lengths + 32 peer status words, padded
 constexpr int kStatusBlock = ST_WORDS + kHaloWords + kMaxVelSlots * kMaxVelStride;// in 4-byte words
 
 struct Partition {
@@ -62,6 +62,9 @@ struct mpm_ctx {
 	int device = 0;
 	hipStream_t s_compute = nullptr, s_comm = nullptr;
 	hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_g0 = nullptr, ev_g1 = nullptr, ev_comm = nullptr, ev_halo = nullptr;
+	// MGSP windowed loop: the status read-back of substep t is waited for AFTER the halo-first G2P2G of substep t + 1 has been enqueued,
+	// so the timing events exist twice (index = parity of the substep)
+	hipEvent_t ev_status = nullptr, ev2_a[2] = {nullptr, nullptr}, ev2_b[2] = {nullptr, nullptr}, ev2_g0[2] = {nullptr, nullptr}, ev2_g1[2] = {nullptr, nullptr};
 	// grid[0] already holds the velocities of the coming substep (the rebuild's carry-over applied the grid update for this dt):
 	// only inside mpm_run_fixed, never when a call returns
 	bool grid_preupdated = false;
@@ -99,11 +102,27 @@ struct mpm_ctx {
 	int* d_peer_rows   = nullptr;// key-list lengths exported by every rank (fused substep); lives behind d_halo_counts
 	int* h_peer_rows   = nullptr;// pinned, behind h_halo_counts
 	int mgsp_world	   = 0;
+	int mgsp_rank	   = -1;// this rank's number in the last fused tagging (-1: none yet)
 	bool halo_tagged   = false;
 	int* d_send_ids[32] = {nullptr};
 	int n_halo = 0, n_inner = 0;
 	int send_count[32] = {0};
 	std::string err;
+};
+
+// An interrupted call leaves no promise about the grid behind (a checkpoint load restores a canonical one): the three flags that span
+// kernels - grid already updated for the next dt, rebuild clear already issued, next dt known - are reset on EVERY error exit (HIP_TRY
+// returns included), by scope.
+struct FlagGuard {
+	mpm_ctx* ctx;
+	bool armed = true;
+	~FlagGuard() {
+		if(armed) {
+			ctx->grid_preupdated = false;
+			ctx->fuse_dt_once	 = 0.f;
+			ctx->rebuild_cleared = false;
+		}
+	}
 };
 
 #define HIP_TRY(expr)                                                                                            \
@@ -275,7 +294,8 @@ int mpm_create(const mpm_config* cfg, int device, mpm_ctx** out) {
 		return MPM_ERR_DEVICE;
 	}
 	if(hipEventCreate(&ctx->ev_a) != hipSuccess || hipEventCreate(&ctx->ev_b) != hipSuccess || hipEventCreate(&ctx->ev_g0) != hipSuccess || hipEventCreate(&ctx->ev_g1) != hipSuccess
-	   || hipEventCreateWithFlags(&ctx->ev_comm, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming) != hipSuccess) {
+	   || hipEventCreateWithFlags(&ctx->ev_comm, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming) != hipSuccess
+	   || hipEventCreateWithFlags(&ctx->ev_status, hipEventDisableTiming) != hipSuccess) {
 		mpm_destroy(ctx);// frees whatever was created (null handles are skipped)
 		return MPM_ERR_DEVICE;
 	}
@@ -320,6 +340,10 @@ void mpm_destroy(mpm_ctx* ctx) {
 	if(ctx->ev_g1) hipEventDestroy(ctx->ev_g1);
 	if(ctx->ev_comm) hipEventDestroy(ctx->ev_comm);
 	if(ctx->ev_halo) hipEventDestroy(ctx->ev_halo);
+	if(ctx->ev_status) hipEventDestroy(ctx->ev_status);
+	for(int i = 0; i < 2; ++i)
+		for(hipEvent_t e: {ctx->ev2_a[i], ctx->ev2_b[i], ctx->ev2_g0[i], ctx->ev2_g1[i]})
+			if(e) hipEventDestroy(e);
 	for(hipEvent_t e: ctx->ev_ring) hipEventDestroy(e);
 	if(ctx->s_compute) hipStreamDestroy(ctx->s_compute);
 	if(ctx->s_comm) hipStreamDestroy(ctx->s_comm);
@@ -630,12 +654,6 @@ static int launch_clear(mpm_ctx* ctx, int flags) {
 	a.old_table	   = Pn.table;
 	a.old_keys	   = Pn.keys;
 	a.old_count	   = Pn.count;
-	if((flags & kClearRebuild) && ctx->d_overlap) {// MGSP: the tagging that follows the rebuild starts from cleared marks and counters
-		a.overlap		= ctx->d_overlap;
-		a.overlap_n		= ctx->g.cap + 1;
-		a.halo_counts	= ctx->d_halo_counts;
-		a.halo_counts_n = 2 + 32;
-	}
 	substep_clear_kernel<<<1024, 256, 0, ctx->s_compute>>>(ctx->g, a);
 	return MPM_OK;
 }
@@ -795,10 +813,15 @@ static void roll_partition(mpm_ctx* ctx) {
 
 // Host synchronisation after one or more enqueued substeps (every one already rolled on the host): read the status block,
 // report what went wrong in the meantime (flags are sticky), take over the counts, grow capacities.
+static int apply_status(mpm_ctx* ctx, mpm_counts* counts);
 static int sync_counts(mpm_ctx* ctx, mpm_counts* counts) {
 	int rc = read_status(ctx);
 	if(rc) return rc;
-	rc = check_status(ctx);
+	return apply_status(ctx, counts);
+}
+// the host's half of a synchronisation, once the status block is in h_status
+static int apply_status(mpm_ctx* ctx, mpm_counts* counts) {
+	int rc = check_status(ctx);
 	if(rc) return rc;
 	ctx->pbc = ctx->h_status[ST_PBC];
 	ctx->nbc = ctx->h_status[ST_NBC];
@@ -839,6 +862,9 @@ int mpm_rebuild_partition(mpm_ctx* ctx, mpm_counts* counts) {
 }
 
 int mpm_substep(mpm_ctx* ctx, float dt, float step_time, float frame_time, float dt_default, float* next_dt, float* max_vel) {
+	if(!ctx || !ctx->ready) return MPM_ERR_NOT_READY;
+	FlagGuard guard {ctx};
+	ctx->fuse_dt_once = 0.f;// (this path keeps the grid update a kernel of its own: the rebuild below must not apply one)
 	float mv2 = 0.f;
 	int rc	  = mpm_grid_update(ctx, dt, &mv2);
 	if(rc) return rc;
@@ -861,6 +887,7 @@ int mpm_substep(mpm_ctx* ctx, float dt, float step_time, float frame_time, float
 	HIP_TRY(hipEventElapsedTime(&ctx->timers.partition_ms, ctx->ev_a, ctx->ev_b));
 	ctx->timers.g2p2g_ms = ctx->last_g2p2g_ms;
 	ctx->timers.total_ms = ctx->timers.grid_update_ms + ctx->timers.g2p2g_ms + ctx->timers.partition_ms;
+	guard.armed = false;
 	return MPM_OK;
 }
 
@@ -868,17 +895,12 @@ int mpm_substep(mpm_ctx* ctx, float dt, float step_time, float frame_time, float
 // then synchronises: every kernel reads its block counts from the status block, launches are sized by the counts of the last
 // synchronisation plus a margin (a kernel walks over what is beyond its launch), errors raised in between are sticky flags.
 // The reference synchronises the host six times per substep (gmpm_simulator.cuh:398,:470,:503,:518,:541,:564).
-static int run_fixed_fail(mpm_ctx* ctx, int rc) {
-	ctx->grid_preupdated = false;// an interrupted run leaves no promise about the grid behind (a checkpoint load restores a canonical one)
-	ctx->fuse_dt_once	 = 0.f;
-	ctx->rebuild_cleared = false;
-	return rc;
-}
 int mpm_run_fixed(mpm_ctx* ctx, int nsteps, float dt) {
 	if(!ctx || !ctx->ready) return MPM_ERR_NOT_READY;
 	HIP_TRY(hipSetDevice(ctx->device));
 	hipStream_t s = ctx->s_compute;
-	const int K = ctx->cfg.sync_interval > 0 ? std::min(ctx->cfg.sync_interval, 64) : 8;
+	const int K = ctx->cfg.sync_interval > 0 ? std::min(ctx->cfg.sync_interval, 64) : 8;// (clamped to 64: claymore_amd.h)
+	FlagGuard guard {ctx};
 	while((int) ctx->ev_ring.size() < 4 * K) {
 		hipEvent_t e = nullptr;
 		HIP_TRY(hipEventCreate(&e));
@@ -894,20 +916,24 @@ int mpm_run_fixed(mpm_ctx* ctx, int nsteps, float dt) {
 		hipEvent_t* ev = &ctx->ev_ring[4 * in_window];
 		HIP_TRY(hipEventRecord(ev[0], s));
 		int rc = launch_grid_update(ctx, dt);
-		if(rc) return run_fixed_fail(ctx, rc);
+		if(rc) return rc;
 		const bool fuse_next = it + 1 < nsteps;// the last substep leaves the canonical state behind
 		rc = launch_g2p2g(ctx, dt, dt, ev[1], ev[2], true, fuse_next && !ctx->has_collision);
-		if(rc) return run_fixed_fail(ctx, rc);
+		if(rc) return rc;
 		rc = launch_rebuild(ctx, fuse_next ? dt : 0.f);
-		if(rc) return run_fixed_fail(ctx, rc);
+		if(rc) return rc;
 		HIP_TRY(hipEventRecord(ev[3], s));
 		roll_partition(ctx);
 		++in_window;
-		if(in_window == K || it + 1 == nsteps) {
+		// Capacities grow only at a synchronisation (by 3/2 per look, at 3/4 fill): a context whose blocks fill more than 7/10 of the capacity
+		// (set-up sizes it to 2/3) looks after EVERY substep - what the reference's check_capacity does (gmpm_simulator.cuh:283-300) -,
+		// so that a burst of new blocks cannot outrun the growth inside a window
+		const bool tight = ctx->cfg.grow && (long long) ctx->ebc * 10 > (long long) ctx->g.cap * 7;
+		if(in_window == K || it + 1 == nsteps || tight) {
 			HIP_TRY(hipGetLastError());
 			rc = sync_counts(ctx, nullptr);// (one read-back: status, halo counters, max |v|^2 slots)
-			if(rc) return run_fixed_fail(ctx, rc);
-			if(std::isinf(host_maxvel(ctx))) return run_fixed_fail(ctx, fail(ctx, MPM_ERR_NONFINITE, "Maximum velocity is infinity"));
+			if(rc) return rc;
+			if(std::isinf(host_maxvel(ctx))) return fail(ctx, MPM_ERR_NONFINITE, "Maximum velocity is infinity");
 			for(int w = 0; w < in_window; ++w) {
 				hipEvent_t* e = &ctx->ev_ring[4 * w];
 				float t_grid = 0, t_g = 0, t_part = 0, t_tot = 0;
@@ -930,6 +956,7 @@ int mpm_run_fixed(mpm_ctx* ctx, int nsteps, float dt) {
 		ctx->timers.partition_ms   = (float) (acc_part / nsteps);
 		ctx->timers.total_ms	   = (float) (acc_total / nsteps);
 	}
+	guard.armed = false;
 	return MPM_OK;
 }
 

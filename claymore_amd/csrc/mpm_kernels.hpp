@@ -473,10 +473,6 @@ struct ClearArgs {
 	int* old_table;		  // table of the partition about to be rebuilt
 	const int* old_keys;  // its key list
 	const int* old_count; // its exterior block count
-	int* overlap;		  // MGSP (may be null): the overlap marks and the halo counters of the tagging that follows the rebuild
-	int overlap_n;
-	int* halo_counts;
-	int halo_counts_n;
 };
 __global__ __launch_bounds__(256) void substep_clear_kernel(GridCfg cfg, ClearArgs a) {
 	const int tid = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256;
@@ -490,10 +486,6 @@ __global__ __launch_bounds__(256) void substep_clear_kernel(GridCfg cfg, ClearAr
 	if(a.flags & kClearRebuild) {
 		const int n = min(*a.old_count, cfg.cap);
 		for(int i = tid; i < n; i += nthreads) a.old_table[key_index(cfg, a.old_keys[3 * i], a.old_keys[3 * i + 1], a.old_keys[3 * i + 2])] = -1;
-		if(a.overlap) {
-			for(int i = tid; i < a.overlap_n; i += nthreads) a.overlap[i] = 0;
-			for(int i = tid; i < a.halo_counts_n; i += nthreads) a.halo_counts[i] = 0;
-		}
 		if(blockIdx.x == gridDim.x - 1) {
 			if(threadIdx.x < kMaxModels) {
 				a.status[ST_BINSPREV + threadIdx.x] = a.status[ST_BINS0 + threadIdx.x];

@@ -6,7 +6,11 @@ served by the in-process double tests/rccl_double/rccl_double.cpp (MPM_RCCL_LIBR
 per run because the library loads its collective library once).  The union of the ranks' particles must follow the single-engine
 CPU oracle.  Prints "OK ..." on success.
 
-    MPM_RCCL_LIBRARY=/path/to/librccl_double.so python tests/rccl_double/run_group.py WORLD KIND   (KIND: fixed | substeps | adaptive)
+    MPM_RCCL_LIBRARY=/path/to/librccl_double.so python tests/rccl_double/run_group.py WORLD KIND   (KIND: fixed | substeps | adaptive | fail)
+
+KIND fail: rank 1 runs with a block capacity it outgrows after a few substeps (no growth): it must come back with MPM_ERR_CAPACITY, and so
+must EVERY other rank, in the same substep (its status word travels in row 0 of the key all-gather) - nobody may be left waiting in a
+collective.  Prints "OK ..." on success.
 """
 import os
 import sys
@@ -24,9 +28,64 @@ from oracle_ffi import oracle_api  # noqa: E402
 from parity_util import match  # noqa: E402
 
 
+def run_failing_rank(world):
+    """One rank outgrows its (fixed) block capacity in the middle of mpm_group_run_fixed: every rank returns MPM_ERR_CAPACITY, none hangs."""
+    import copy
+    from claymore_amd import _ffi
+    from claymore_amd.engine import EngineError
+    from claymore_amd.mgsp import partition_scene
+    # a sand ball thrown at the floor: its block count wobbles by a few while it falls and doubles once it splashes (400-600 substeps in)
+    sc = scenes.sphere_drop(bits=6, radius_cells=6.0, center=(0.5, 0.26, 0.5), material=_ffi.SAND)
+    sc["models"][0]["params"] = {}
+    sc["models"][0]["v0"] = (0.0, -4.0, 0.0)
+    locals_ = [copy.deepcopy(partition_scene(sc, r, world)) for r in range(world)]
+    probe = build_engine(locals_[1])                    # how many blocks does rank 1 start with?
+    probe.initial_setup()
+    ebc0 = probe.counts().exterior_blocks
+    probe.close()
+    locals_[1]["config"] = dict(locals_[1].get("config", {}), max_blocks=ebc0 + 8, grow=0)
+    ident, have_id = {}, threading.Event()
+
+    def bootstrap(raw):
+        if raw is not None:
+            ident["raw"] = raw
+            have_id.set()
+        else:
+            assert have_id.wait(120)
+        return ident["raw"]
+
+    outcome, sims = [None] * world, [None] * world
+
+    def work(rank):
+        try:
+            sim = sims[rank] = MgspGroupRank(locals_[rank], rank, world, device=0, bootstrap=bootstrap, prepartitioned=True)
+            sim.initial_setup()
+            sim.run_fixed(900, 1e-4)
+            outcome[rank] = ("finished", "")
+        except EngineError as e:
+            outcome[rank] = (e.code, str(e))
+        except Exception as e:  # noqa: BLE001
+            outcome[rank] = ("exception", repr(e))
+
+    threads = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), f"a rank is stuck in a collective: {outcome}"
+    assert all(o is not None and o[0] == _ffi.MPM_ERR_CAPACITY for o in outcome), outcome
+    assert "rank 1 reported" in outcome[0][1], outcome
+    for s in sims:
+        if s is not None:
+            s.close()
+    print(f"OK world {world} fail: every rank returned MPM_ERR_CAPACITY ({[o[1] for o in outcome]})")
+
+
 def main():
     world, kind = int(sys.argv[1]), sys.argv[2]
     assert os.environ.get("MPM_RCCL_LIBRARY"), "MPM_RCCL_LIBRARY is not set"
+    if kind == "fail":
+        return run_failing_rank(world)
     sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=0.5, speed=2.0, youngs=2e4)
     nsteps, dt = 60, 1e-4
     ident, have_id = {}, threading.Event()

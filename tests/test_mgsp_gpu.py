@@ -433,7 +433,7 @@ def rccl_double_library(tmp_path_factory):
     return str(out)
 
 
-@pytest.mark.parametrize("world,kind", [(2, "fixed"), (3, "substeps"), (4, "fixed"), (2, "adaptive")])
+@pytest.mark.parametrize("world,kind", [(2, "fixed"), (3, "substeps"), (4, "fixed"), (2, "adaptive"), (3, "fixed-nodefer")])
 def test_rccl_transport_with_several_ranks_through_the_rccl_double(world, kind, rccl_double_library):
     """The RCCL branch of the group driver with world > 1 (RCCL itself cannot host two ranks on one device, the box has one GPU):
     every rank a thread with its own context, mpm_group_create with a unique id, the grouped ncclSend / ncclRecv of the halo exchange,
@@ -442,5 +442,20 @@ def test_rccl_transport_with_several_ranks_through_the_rccl_double(world, kind, 
     import subprocess
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, MPM_RCCL_LIBRARY=rccl_double_library)
+    if kind == "fixed-nodefer":   # the same loop with the host waiting at the end of every substep (what "fixed" defers behind the next halo-first launch)
+        env["MPM_GROUP_DEFER"] = "0"
+        kind = "fixed"
     r = subprocess.run([sys.executable, os.path.join(here, "rccl_double", "run_group.py"), str(world), kind], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "OK world" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_failing_rank_fails_every_rank_and_nobody_hangs(world, rccl_double_library):
+    """Error propagation of the group driver on the RCCL branch: one rank outgrows its block capacity inside mpm_group_run_fixed.  Its
+    status word travels in row 0 of the padded key all-gather, so every rank sees it at the same read-back and returns MPM_ERR_CAPACITY;
+    without that the peers would sit in the next ncclRecv forever (the subprocess would hit its timeout)."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MPM_RCCL_LIBRARY=rccl_double_library)
+    r = subprocess.run([sys.executable, os.path.join(here, "rccl_double", "run_group.py"), str(world), "fail"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK world" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
