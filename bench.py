@@ -60,50 +60,59 @@ def make_scene(args):
     return sc, name
 
 
-def cpu_baseline(args):
-    """Serial CPU oracle on a bounded sample (about 10-30 s of CPU work)."""
+def cpu_baseline(args, scene=None):
+    """The CPU oracle (a port of the reference pipeline, oracle/mpm_oracle.c) timed on this host, outside the timed region of the GPU run:
+      * on the SAME input as the GPU run - for the default scene the full C3 column (40.1 M particles; set-up ~40 s serial, 11 GB, then
+        one warm + two timed substeps, OpenMP over particle blocks in G2P2G on all host cores), and
+      * single-threaded on the full C1 scene (BASELINE config 1: the reference's own CPU-runnable case).
+    A host with less than 24 GB of free memory falls back to a 1/64-scale column (same aspect ratio, same grid) and says so."""
     import __graft_entry__ as g
     g.build_oracle()
     from claymore_amd import scenes
     from claymore_amd.engine import build_engine
     from oracle_ffi import oracle_api
-    if args.scene == "sand40m":
-        frac = 1.0 / 64.0
-        sc = scenes.scaled_sand_column(9, frac)
-        sample = f"sand column scaled to {scenes.total_particles(sc)} particles (1/64 of C3, same aspect ratio, 512^3 grid)"
-    elif args.scene == "sphere5m":
-        sc = scenes.sphere_drop(radius_cells=20.0)
-        sample = f"elastic sphere R=20dx, {scenes.total_particles(sc)} particles, 256^3 grid"
-    else:
-        sc = scenes.two_spheres()
-        sample = "the full C1 scene"
-    n = scenes.total_particles(sc)
     api = oracle_api()
-    steps = max(2, min(20, int(12e6 / n)))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
 
-    def timed(threads):
+    def timed(sc, threads, steps, warm=1):
         eng = build_engine(sc, api=api)
+        t0 = time.perf_counter()
         eng.initial_setup()
+        setup = time.perf_counter() - t0
         api.raw.mpmo_set_threads(eng.ctx, threads)
-        eng.run_fixed(1, sc["dt"])  # warm
+        eng.run_fixed(warm, sc["dt"])
         t0 = time.perf_counter()
         eng.run_fixed(steps, sc["dt"])
         dt = time.perf_counter() - t0
         eng.close()
-        return n * steps / dt, dt
+        return scenes.total_particles(sc) * steps / dt, dt, setup
 
-    serial, t1 = timed(1)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 64))
-    out = {"value": serial, "unit": "particles*steps/s", "cores": 1, "kind": "port",
-           "sample": f"{sample}, {steps} substeps, serial C oracle (oracle/mpm_oracle.c), {t1:.1f} s"}
-    if cores > 1:
-        # all host cores: G2P2G (>= 90 % of the oracle's time) over particle blocks with OpenMP, the rest stays serial
-        par, tp = timed(cores)
-        if par > serial:
-            out = {"value": par, "unit": "particles*steps/s", "cores": cores, "kind": "port",
-                   "sample": f"{sample}, {steps} substeps, C oracle with OpenMP over particle blocks in G2P2G ({cores} threads), {tp:.1f} s",
-                   "serial_value": serial}
+    try:
+        import psutil
+        free_gb = psutil.virtual_memory().available / 2 ** 30
+    except Exception:  # noqa: BLE001
+        free_gb = 0.0
+    if args.scene == "sand40m":
+        full = args.fraction >= 1.0 and free_gb >= 24.0 and scene is not None
+        sc = scene if full else scenes.scaled_sand_column(9, 1.0 / 64.0)
+        steps = 2 if full else 19
+        what = (f"the full C3 scene ({scenes.total_particles(sc)} particles, 512^3)" if full else
+                f"sand column scaled to {scenes.total_particles(sc)} particles (1/64 of C3, same aspect ratio, 512^3 grid; the host has {free_gb:.0f} GB free, the full scene needs 24)")
+    elif args.scene == "sphere5m":
+        sc, steps = (scene if scene is not None else scenes.sphere_drop()), 4
+        what = f"the full C2 scene ({scenes.total_particles(sc)} particles, 256^3)"
+    else:
+        sc, steps = scenes.two_spheres(), 20
+        what = "the full C1 scene"
+    rate, dt, setup = timed(sc, cores, steps)
+    out = {"value": rate, "unit": "particles*steps/s", "cores": cores, "kind": "port",
+           "sample": f"{what}: the same input as the GPU run, {steps} substeps after one warm-up substep, C oracle (oracle/mpm_oracle.c) with OpenMP over particle "
+                     f"blocks in G2P2G ({cores} threads; the rest of the pipeline is serial), {dt:.1f} s (+ {setup:.0f} s of serial set-up, not counted)"}
+    c1 = scenes.two_spheres()
+    r1, t1, _ = timed(c1, 1, 100, warm=2)
+    out["c1_single_thread"] = {"value": r1, "unit": "particles*steps/s", "cores": 1,
+                               "sample": f"the full C1 scene (BASELINE config 1: two elastic spheres, {scenes.total_particles(c1)} particles, 128^3), 100 substeps, one thread, {t1:.1f} s"}
     return out
 
 
@@ -126,6 +135,9 @@ def main():
                     help="N = 1, default scene: after the timed window the run goes on to this substep and a second short window is timed "
                          "inside the flow (reported as roofline.flow; 0 = skip)")
     ap.add_argument("--sync-interval", type=int, default=0, help="debug: mpm_config.sync_interval (0 = library default)")
+    ap.add_argument("--watchdog", type=float, default=900.0,
+                    help="seconds after which a run that has not finished prints a JSON error line and exits (a rank stuck in a collective "
+                         "would otherwise sit there until the caller's own timeout); 0 = off")
     args = ap.parse_args()
 
     # stdout carries exactly one line, the JSON record: libraries that print banners there (gloo's "connected to N peer ranks",
@@ -138,6 +150,33 @@ def main():
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
+    # ---- watchdog: one JSON line whatever happens.  `stage` says where the run was; the thread fires once, from any rank (a rank that
+    #      hangs in a collective cannot report for itself: its peers, which wait for it, do)
+    import threading
+    stage = {"at": "start", "ranks_seen": None}
+
+    def error_line(reason):
+        rec = {"metric": "particles*steps/sec", "value": None, "unit": "particles*steps/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+               "error": reason, "stage": stage["at"], "rank": rank, "ranks_seen": stage["ranks_seen"]}
+        os.write(json_fd, (json.dumps(rec) + "\n").encode())
+
+    def watchdog():
+        if not finished.wait(args.watchdog):
+            sys.stderr.write(f"bench.py[rank {rank}]: watchdog after {args.watchdog:.0f} s at stage '{stage['at']}'\n")
+            error_line(f"watchdog: no result after {args.watchdog:.0f} s")
+            os._exit(3)
+
+    finished = threading.Event()
+    if args.watchdog > 0:
+        threading.Thread(target=watchdog, daemon=True).start()
+    prev_hook = sys.excepthook
+
+    def hook(tp, val, tb):          # an exception (an engine error that every rank returns, a failed self-check) also leaves a JSON line
+        finished.set()
+        error_line(f"{tp.__name__}: {val}")
+        prev_hook(tp, val, tb)
+
+    sys.excepthook = hook
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
@@ -151,7 +190,14 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1")
         # host-side rendez-vous only (RCCL unique id, barriers, the max over ranks of the elapsed time): the data path is RCCL
         # inside the library (claymore_amd/csrc/mpm_group.inc), one communicator per rank on the engine's own streams
+        stage["at"] = "gloo rendez-vous"
+        os.environ.setdefault("MPM_GROUP_VERBOSE", "1")   # the library logs which collective library it loaded and ncclCommCount
         dist.init_process_group("gloo")
+        seen = [None] * dist.get_world_size()
+        dist.all_gather_object(seen, (rank, local_rank, os.uname().nodename))
+        stage["ranks_seen"] = len(seen)
+        if rank == 0:
+            sys.stderr.write(f"bench.py: gloo rendez-vous complete, {len(seen)} ranks: {seen}\n")
 
     import __graft_entry__ as g
     if rank == 0:
@@ -233,8 +279,13 @@ def main():
             dist.broadcast_object_list(objs, src=0)
             return objs[0]
 
+        stage["at"] = "ncclCommInitRank"
         sim = MgspGroupRank(sc, rank, world, device=local_rank, bootstrap=bootstrap, prepartitioned=weak)
+        if rank == 0:
+            sys.stderr.write(f"bench.py: RCCL communicator up, world {world} (this rank {rank})\n")
+        stage["at"] = "mgsp initial setup (first tagging, first halo exchange)"
         sim.initial_setup()
+        stage["at"] = "mgsp substeps"
         if args.start_step:
             sim.run_fixed(args.start_step, dt)
         sim.run_fixed(args.warmup, dt)
@@ -323,9 +374,11 @@ def main():
                                        "frac": fa / HBM_PEAK_GBS, "ms_per_step": flow["ms_per_step"], "blocks": flow["blocks"], "traffic": None}
             attach(out["roofline"]["flow"], "flow", flow["kernel_ms"])
         if world == 1 and not args.no_cpu_baseline and not args.mgsp:
-            out["cpu_baseline"] = cpu_baseline(args)
+            stage["at"] = "cpu baseline (oracle on the host cores)"
+            out["cpu_baseline"] = cpu_baseline(args, sc)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    finished.set()
     if use_mgsp:
         dist.destroy_process_group()
 

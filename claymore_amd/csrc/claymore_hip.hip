@@ -47,6 +47,7 @@ struct Model {
 	int* size		 = nullptr;
 	int* row_of		 = nullptr;
 	int* out_count	 = nullptr;
+	int* keep		 = nullptr;// per block of the numbering G2P2G ran in: its particle count if every particle stayed with an unchanged sort key, else -1
 	int* blockinfo	 = nullptr;// [block][kInfoRow], written by prepare_blocks_kernel
 	int64_t bincount = 0;
 	int64_t bincount_src = 0;// bins in use in bins[rollid] (the source of the next g2p2g): the previous bincount
@@ -325,6 +326,7 @@ void mpm_destroy(mpm_ctx* ctx) {
 		hipFree(m.size);
 		hipFree(m.row_of);
 		hipFree(m.out_count);
+		hipFree(m.keep);
 	}
 	hipFree(ctx->d_status);
 	hipFree(ctx->d_totals);
@@ -507,6 +509,8 @@ int mpm_initial_setup(mpm_ctx* ctx) {
 		HIP_TRY(dalloc(&m.size, cap + 1));
 		HIP_TRY(dalloc(&m.row_of, cap + 1));
 		HIP_TRY(dalloc(&m.out_count, cap + 1));
+		HIP_TRY(dalloc(&m.keep, cap + 1));
+		HIP_TRY(hipMemsetAsync(m.keep, 0xff, sizeof(int) * (cap + 1), s));
 		HIP_TRY(dalloc(&m.blockinfo, cap * (size_t) kInfoRow));
 		HIP_TRY(hipMemsetAsync(m.out_count, 0, sizeof(int) * (cap + 1), s));
 		HIP_TRY(hipMemsetAsync(m.size, 0, sizeof(int) * (cap + 1), s));
@@ -601,6 +605,7 @@ static ModelView make_view(mpm_ctx* ctx, Model& m) {
 	v.size		 = m.size;
 	v.row_of	 = m.row_of;
 	v.out_count	 = m.out_count;
+	v.keep		 = m.keep;
 	v.blockinfo	 = m.blockinfo;
 	v.mc		 = m.mc;
 	return v;
@@ -646,7 +651,7 @@ static int launch_clear(mpm_ctx* ctx, int flags) {
 	ClearArgs a {};
 	a.flags	  = flags;
 	a.nmodels = (int) ctx->models.size();
-	for(int mi = 0; mi < a.nmodels; ++mi) a.out_count[mi] = ctx->models[mi].out_count;
+	for(int mi = 0; mi < a.nmodels; ++mi) a.out_count[mi] = ctx->models[mi].out_count, a.keep[mi] = ctx->models[mi].keep;
 	a.p2g_grid	   = ctx->grid[1];
 	a.status	   = ctx->d_status;
 	a.max_vel_bits = ctx->d_maxvel;
@@ -704,6 +709,7 @@ static int launch_prepare(mpm_ctx* ctx, int cur, int prev, bool list_is_out, int
 		pm.row_of[mi]	  = m.row_of;
 		pm.binoff_src[mi] = m.binoff[binoff_sel];
 		pm.blockinfo[mi]  = m.blockinfo;
+		pm.keep[mi]		  = sort && list_is_out ? m.keep : nullptr;// (only the rebuild's call sorts lists G2P2G has just written)
 	}
 	const int nwg = std::max(1, std::min(ctx->g.cap, nblocks_est + nblocks_est / 16 + 64));
 	int* pub	  = publish ? ctx->d_status : nullptr;
@@ -779,6 +785,7 @@ static int grow_capacity(mpm_ctx* ctx) {
 			HIP_TRY(regrow(&m.size, cap + 1, ncap + 1, s));
 			HIP_TRY(regrow(&m.row_of, cap + 1, ncap + 1, s));
 			HIP_TRY(regrow(&m.out_count, cap + 1, ncap + 1, s));
+			HIP_TRY(regrow(&m.keep, cap + 1, ncap + 1, s));
 			HIP_TRY(regrow(&m.blockinfo, cap * (size_t) kInfoRow, ncap * (size_t) kInfoRow, s));
 		}
 		if(ctx->d_overlap) {

@@ -52,6 +52,7 @@ struct ModelView {
 	const int* size;	  // particles per current block
 	const int* row_of;	  // row of list_in that belongs to current block b
 	int* out_count;		  // append counters of list_out
+	int* keep;			  // per block: its size if every particle stayed with an unchanged sort key, else -1 (prepare_blocks_kernel skips the sort)
 	const int* blockinfo; // [block][kInfoRow]: source bin offsets, destination / grid block numbers (prepare_blocks_kernel)
 	MaterialConst mc;
 };
@@ -243,35 +244,28 @@ MPM_DEV void serial_flush(float4* __restrict__ arena, const float4* __restrict__
 	const int oi = l / 9, oj = (l / 3) % 3, ok = l % 3;
 	const float fi = (float) oi, fj = (float) oj, fk = (float) ok;
 	float4* const my_arena = arena + half * kP2GNodes;
-	// this lane's B-spline weight as a (fd - c)^2 + b0: offset 0: 0.5 (1.5 - fd)^2, 1: 0.75 - (fd - 1)^2, 2: 0.5 (fd - 0.5)^2 (utility_funcs.hpp:10-19) -
-	// three instructions per axis where forming all three weights and selecting one took seven
-	const float ax = oi == 1 ? -1.f : 0.5f, bx = oi == 1 ? 0.75f : 0.f, cx = 1.5f - 0.5f * fi;
-	const float ay = oj == 1 ? -1.f : 0.5f, by = oj == 1 ? 0.75f : 0.f, cy = 1.5f - 0.5f * fj;
-	const float az = ok == 1 ? -1.f : 0.5f, bz = ok == 1 ? 0.75f : 0.f, cz = 1.5f - 0.5f * fk;
-	// Software pipeline: the entry of the NEXT pair is requested before this pair's arithmetic and read-modify-write (all lanes of a half
-	// read the same entry: four broadcast ds_read_b128), so a pair costs the read-modify-write round trip only.
-	auto entry = [&](int e) { return queue + 4 * (e + half < qn ? e + half : e); };
-	const float4* en = entry(0);
-	float4 q0 = en[0], q1 = en[1], q2 = en[2], q3 = en[3];
 	for(int e = 0; e < qn; e += 2) {
-		const bool live = e + half < qn;
-		const float4 c0 = q0, c1 = q1, c2 = q2, c3 = q3;
-		if(e + 2 < qn) {
-			en = entry(e + 2);
-			q0 = en[0], q1 = en[1], q2 = en[2], q3 = en[3];
-		}
-		const int cd = __float_as_int(c0.w);
+		const bool live	 = e + half < qn;
+		const float4* en = queue + 4 * (live ? e + half : e);
+		const float4 q0 = en[0], q1 = en[1], q2 = en[2], q3 = en[3];
+		const float fd[3] = {q0.x, q0.y, q0.z};
+		const int cd	  = __float_as_int(q0.w);
 		const int nx = cd & 15, ny = (cd >> 4) & 15, nz = cd >> 8;
+		float w[3][3];
+#pragma unroll
+		for(int d = 0; d < 3; ++d) bspline_weight_cells(fd[d], w[d]);
+		const float wx = oi == 0 ? w[0][0] : (oi == 1 ? w[0][1] : w[0][2]);
+		const float wy = oj == 0 ? w[1][0] : (oj == 1 ? w[1][1] : w[1][2]);
+		const float wz = ok == 0 ? w[2][0] : (ok == 1 ? w[2][1] : w[2][2]);
+		const float W  = wx * wy * wz;
+		const float px = fi - fd[0], py = fj - fd[1], pz = fk - fd[2];
+		const float v0 = mass * W;
+		const float v1 = (q1.x + q1.w * px + q2.z * py + q3.y * pz) * W;// mv[0] + c[0] px + c[3] py + c[6] pz
+		const float v2 = (q1.y + q2.x * px + q2.w * py + q3.z * pz) * W;// mv[1] + c[1] px + c[4] py + c[7] pz
+		const float v3 = (q1.z + q2.y * px + q3.x * py + q3.w * pz) * W;// mv[2] + c[2] px + c[5] py + c[8] pz
 		const int gx = nx + oi, gy = ny + oj, gz = nz + ok;// cube coordinates 0..7
 		const bool inside = ((unsigned) (gx - 1) < 6u) & ((unsigned) (gy - 1) < 6u) & ((unsigned) (gz - 1) < 6u);
 		const int nb	  = __shfl(info, 54 + ((gx >> 2) & 1) * 4 + ((gy >> 2) & 1) * 2 + ((gz >> 2) & 1));
-		const float dx_ = c0.x - cx, dy_ = c0.y - cy, dz_ = c0.z - cz;
-		const float W	= fmaf(ax * dx_, dx_, bx) * fmaf(ay * dy_, dy_, by) * fmaf(az * dz_, dz_, bz);
-		const float px = fi - c0.x, py = fj - c0.y, pz = fk - c0.z;
-		const float v0 = mass * W;
-		const float v1 = (c1.x + c1.w * px + c2.z * py + c3.y * pz) * W;// mv[0] + c[0] px + c[3] py + c[6] pz
-		const float v2 = (c1.y + c2.x * px + c2.w * py + c3.z * pz) * W;// mv[1] + c[1] px + c[4] py + c[7] pz
-		const float v3 = (c1.z + c2.y * px + c3.x * py + c3.w * pz) * W;// mv[2] + c[2] px + c[5] py + c[8] pz
 		if(l < 27 && live) {
 			if(inside) {
 				float4* node	 = my_arena + (gx - 1) * kP2GStrideX + (gy - 1) * kP2GStrideY + (gz - 1);
@@ -524,6 +518,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 	P2GPayload pv;
 	int pv_code = -1;
 	int qn = 0;// entries in s_queue (wave-uniform)
+	bool settled = true;// (wave-uniform) every particle so far stays in this block with the sort key it came with
 #ifdef MPM_G2P2G_STATS
 	int st_iter = 0, st_losers = 0, st_edge = 0, st_retry_iters = 0, st_partial = 0;
 #endif
@@ -555,6 +550,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 			st[5] = pf.row[0];
 			if constexpr(ROW == 2) st[6] = pf.row[1];
 		}
+		const int okey	  = pf.key;// the sort key this particle was processed under
 		const int slot_nn = idx0 + 128 < size ? idx0 + 128 : 0;
 		const int cnt_nn  = idx0 + 128 < size ? slice_records_at(size, idx0 + 128) : 1;
 		const int rec_nn  = list[slot_nn + min(lane, cnt_nn - 1)];
@@ -629,6 +625,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		const int pkey	= pk[1] * 36 + pk[0] * 6 + pk[2];
 		const int rec	= (ntag << tag_shift) | (pkey << key_shift) | pidib;
 		const bool stay = dno >= 0 && ntag == kStay;
+		settled = settled && __all(!active || (stay && pkey == okey));
 		// particles that stay in this block share one wave-aggregated atomic
 		const unsigned long long stay_m = __ballot(stay);
 		const int stay_leader			= stay_m ? __ffsll((long long) stay_m) - 1 : 0;
@@ -768,6 +765,9 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 #endif
 	if constexpr(kQueue) {
 		if(qn) serial_flush(p2g, s_queue, qn, mass, lane, info, next_grid);
+	}
+	{
+		if(lane == 0) mv.keep[b] = settled ? size : -1;
 	}
 	__syncthreads();
 	// ---- arena -> next grid: one hardware f32 atomic per touched node and channel (:907-936).  Lane = cell of one of the

@@ -328,6 +328,7 @@ struct PrepareModels {
 	const int* row_of[kMaxModels];
 	const int* binoff_src[kMaxModels];	// bin offsets in the numbering the particle data is laid out in (previous partition)
 	int* blockinfo[kMaxModels];
+	const int* keep[kMaxModels];// (may be null) G2P2G's verdict per block of the PREVIOUS numbering: see prepare_blocks_kernel
 };
 // The launch is sized by a host-side ESTIMATE of the particle block count (the host does not wait for the rebuild's counts,
 // mpm_run_fixed); the true count is read from device memory and a workgroup walks over blocks b, b + gridDim.x, ... (one trip
@@ -369,14 +370,21 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 		int info = other;
 		if constexpr(SORT) {
 		const int size = pm.size[m][b];
-		int* list	   = pm.list[m] + (size_t) pm.row_of[m][b] * cfg.ppb;
+		const int row  = pm.row_of[m][b];
+		int* list	   = pm.list[m] + (size_t) row * cfg.ppb;
+		// The sort is the identity - and is skipped: 8 B of list traffic per particle and the LDS work - when G2P2G has found that every
+		// particle of the block stayed with an unchanged sort key (keep[row] = their number), nobody arrived (the block's new size is that
+		// number), and the order G2P2G appended them in IS the sliced layout: slice after slice without holes, i.e. full chunks and a last
+		// chunk of full slices or of a single one.  A column at rest is all such blocks but its surface.
+		const int tail	= size & (kPrepChunk - 1);
+		const bool same = pm.keep[m] && size > 0 && pm.keep[m][row] == size && (tail <= 64 || (tail & 63) == 0);
 		constexpr int NIT = kPrepChunk / 64;
 		unsigned recs[NIT];
 		auto load_chunk = [&](int chunk0, int nrec) {// unconditional, clamped: all loads of a chunk are in flight together
 #pragma unroll
 			for(int it = 0; it < NIT; ++it) recs[it] = (unsigned) list[chunk0 + min(it * 64 + lane, nrec - 1)];
 		};
-		if(size > 0) load_chunk(0, min(kPrepChunk, size));
+		if(size > 0 && !same) load_chunk(0, min(kPrepChunk, size));
 		// the bin offsets of the 27 source blocks: the look-up issued at the top has arrived by now, this dependent load
 		// overlaps the LDS-only sort below
 		if(lane < 27) info = srcno >= 0 ? pm.binoff_src[m][srcno] : -1;
@@ -424,7 +432,7 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 				if(it < S && lane < slice_records(nrec, it)) list[chunk0 + it * 64 + lane] = s_sorted[it * 64 + lane];
 			__syncthreads();
 		};
-		for(int chunk0 = 0; chunk0 < size; chunk0 += kPrepChunk) {
+		for(int chunk0 = 0; chunk0 < size && !same; chunk0 += kPrepChunk) {
 			if(chunk0) load_chunk(chunk0, min(kPrepChunk, size - chunk0));
 			sort_chunk(chunk0, min(kPrepChunk, size - chunk0));
 		}
@@ -467,6 +475,7 @@ struct ClearArgs {
 	int flags;
 	int nmodels;
 	int* out_count[kMaxModels];
+	int* keep[kMaxModels];
 	float* p2g_grid;
 	int* status;
 	unsigned* max_vel_bits;
@@ -481,7 +490,7 @@ __global__ __launch_bounds__(256) void substep_clear_kernel(GridCfg cfg, ClearAr
 		float4* g	  = reinterpret_cast<float4*>(a.p2g_grid);
 		for(int i = tid; i < nbc * 64; i += nthreads) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 		for(int m = 0; m < a.nmodels; ++m)
-			for(int i = tid; i <= ebc; i += nthreads) a.out_count[m][i] = 0;
+			for(int i = tid; i <= ebc; i += nthreads) a.out_count[m][i] = 0, a.keep[m][i] = -1;
 	}
 	if(a.flags & kClearRebuild) {
 		const int n = min(*a.old_count, cfg.cap);

@@ -366,6 +366,53 @@ def test_full_size_c4_two_spheres_4_ranks():
         assert abs((mean[1] - x0[m][1]) - fall) < 5e-2 * abs(fall) + 1e-7
 
 
+def test_full_size_c5_fluid_dam_8_ranks():
+    """BASELINE config 5 at size: the weakly compressible J-fluid dam of 256 x 192 x 256 cells (100.7 M particles) on the 1024^3 grid,
+    MGSP static particle partition over 8 ranks - here 8 engine contexts on the one GPU, the C++ group driver on its in-process
+    transport.  12 substeps at the scene's acoustic-CFL time step; every particle accounted for on its rank, nothing lost or discarded,
+    every rank shares a slab interface and exchanges halo blocks, positions finite, and the dam - four cells above the wall zone - falls
+    freely: y by g t^2 / 2 (symplectic Euler), no net motion in x and z."""
+    sc = scenes.fluid_dam(10, (256, 192, 256))
+    n_total = scenes.total_particles(sc)
+    assert n_total == 256 * 192 * 256 * 8
+    world, nsteps, dt = 8, 12, sc["dt"]
+    lg = LocalGroup(world)
+    ranks = [MgspGroupRank(sc, r, world, device=0, local_group=lg) for r in range(world)]
+    com0 = sc["models"][0]["xyz"].mean(axis=0, dtype=np.float64)
+    del sc
+    lg.create()
+    out, errors = [None] * world, []
+
+    def work(r):
+        try:
+            sim = ranks[r]
+            sim.initial_setup()
+            sim.run_fixed(nsteps, dt)
+            c, d = sim.eng.counts(), sim.eng.diagnostics()
+            x = sim.eng.retrieve_positions(0)
+            assert np.isfinite(x).all()
+            out[r] = dict(particles=int(c.particles[0]), lost=int(d.lost_particles), disc=int(d.discarded_p2g), flags=int(d.overflow_flags),
+                          sent=sum(sim.send_counts), halo=sim.n_halo_blocks, n_local=sim.n_local, n=x.shape[0], s=x.astype(np.float64).sum(axis=0))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=1200)
+    for r in ranks:
+        r.close()
+    assert not errors, errors
+    assert sum(o["lost"] for o in out) == 0 and sum(o["disc"] for o in out) == 0 and all(o["flags"] == 0 for o in out)
+    assert all(o["particles"] == o["n_local"] == o["n"] for o in out) and sum(o["n"] for o in out) == n_total
+    assert min(o["sent"] for o in out) > 0 and min(o["halo"] for o in out) > 0      # every rank shares a slab interface
+    com = sum(o["s"] for o in out) / n_total
+    fall = -9.8 * dt * dt * nsteps * (nsteps + 1) / 2                                  # symplectic Euler: v_k = -g k dt, x += v_k dt
+    assert abs((com[1] - com0[1]) - fall) < 5e-2 * abs(fall) + 2e-8, (com - com0, fall)
+    assert abs(com[0] - com0[0]) < 2e-8 and abs(com[2] - com0[2]) < 2e-8
+
+
 @pytest.mark.parametrize("material", [_ffi.SAND, _ffi.FIXED_COROTATED])
 def test_cpp_group_equals_single_engine(material):
     """N ranks against ONE rank of the same engine: the static particle partition changes block numbering, sort order and the

@@ -394,6 +394,51 @@ def test_full_size_invariants_c5_rank_share_12m():
     eng.close()
 
 
+def test_full_size_flow_invariants_c3_40m():
+    """BASELINE config 3 at full size IN THE FLOW (the regime "sand column collapse" means; the 20-substep test below sees free fall
+    only): 3 000 substeps to get the collapse going, then the size-independent properties over the next 40 - every particle still
+    bucketed, nothing lost / discarded / dropped, the grid carries the whole mass, all particles inside the walls, the pile is lower
+    and wider than the column was, the fastest particle is no faster than a free fall from the column's top, and between the two
+    looks the centre of mass keeps sinking while the total momentum stays below weight x time (the floor pushes back)."""
+    sc = scenes.sand_column(9)
+    n = scenes.total_particles(sc)
+    x0 = sc["models"][0]["xyz"]
+    lo0, hi0 = x0.min(axis=0).astype(np.float64), x0.max(axis=0).astype(np.float64)
+    com0 = x0.mean(axis=0, dtype=np.float64)
+    del x0
+    eng = build_engine(sc)
+    eng.initial_setup()
+    mass = n * eng.model_mass(0)
+    dt = 1e-4
+    eng.run_fixed(3000, dt)
+
+    def look():
+        c, d = eng.counts(), eng.diagnostics()
+        assert c.particles[0] == n and d.lost_particles == 0 and d.discarded_p2g == 0 and d.overflow_flags == 0 and d.dropped_particles == 0
+        tot = eng.grid_totals()
+        assert np.isfinite(tot).all() and abs(tot[0] - mass) / mass < 1e-4
+        x = eng.retrieve_positions(0)
+        assert x.shape[0] == n and np.isfinite(x).all()
+        wall = 8.0 / 512.0                                       # two blocks of slip wall: the grid velocity normal to it is zero in the whole zone,
+        assert x.min() >= wall - 2.0 / 512.0 and x.max() <= 1.0 - wall + 2.0 / 512.0   # a particle gets a cell or so into it before it stops
+        return tot, x.mean(axis=0, dtype=np.float64), x.min(axis=0).astype(np.float64), x.max(axis=0).astype(np.float64)
+
+    tot_a, com_a, lo_a, hi_a = look()
+    assert com_a[1] < com0[1] - 0.02                             # it has collapsed: the centre of mass came down by > 10 cells
+    assert hi_a[1] < hi0[1] - 0.02                               # ... the top too
+    assert lo_a[0] < lo0[0] - 0.02 and hi_a[0] > hi0[0] + 0.02   # ... and the pile spreads in x
+    assert lo_a[2] < lo0[2] - 0.02 and hi_a[2] > hi0[2] + 0.02   # ... and in z
+    eng.run_fixed(40, dt)
+    tot_b, com_b, _, _ = look()
+    assert com_b[1] < com_a[1]                                   # still sinking
+    vcom = (com_b - com_a) / (40 * dt)
+    vmax = np.sqrt(2 * 9.8 * (hi0[1] - 8.0 / 512.0))             # free fall from the top of the column
+    assert np.abs(vcom).max() < vmax
+    assert abs(vcom[0]) < 0.05 and abs(vcom[2]) < 0.05           # the column is symmetric in x and z: no net sideways drift
+    assert abs(tot_b[2]) < mass * 9.8 * 0.304                    # |momentum_y| far below weight x elapsed time: the floor carries the pile
+    eng.close()
+
+
 def test_full_size_invariants_c3_40m():
     """BASELINE config 3 at full size (40.1 M Drucker-Prager particles, 512^3), 20 substeps: the size-independent
     properties the 1e-5 parity tests cannot reach - particle count (gmpm_simulator.cuh:617), nothing lost or discarded,
