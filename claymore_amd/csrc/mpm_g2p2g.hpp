@@ -39,8 +39,16 @@ namespace mpm {
 // beyond the hardware's b128 pass structure (tools/valu_microbench3: 4.0 cycles per ds_read_b128 on the gather arena,
 // 8.8 per read-modify-write instruction on the scatter arena, against 4.0 / 8.3 for a linear address pattern).
 constexpr int kP2GStrideX = 36, kP2GStrideY = 6, kP2GNodes = 216;// scatter arenas (two): (x-1)*36 + (y-1)*6 + (z-1)
-constexpr int kG2PStrideX = 36, kG2PStrideY = 6, kG2PNodes = 216;// gather arena, same dense layout (a padded y-major 52 / 8 layout reads
-																 // without bank conflicts in the micro-benchmark but gains < 1 % in the kernel)
+// The second scatter arena starts 228 nodes behind the first (12 nodes = 3/4 of a bank row further than back to back): of 600 linear
+// layouts x arena offsets timed on the chip under rest-like and flow-like lane -> node patterns (tools/lds_bank_probe.hip,
+// profiles/r04_lds_bank_probe.txt) the dense x-major layout is among the best in both regimes, and this offset is its best (flow-like
+// patterns: 27 x (gather read + scatter read-modify-write) 1245 against 1274 cycles back to back; rest: the same).
+constexpr int kP2GArena2 = 228;
+// Gather arena: the same 216 nodes, x / y / z strides 6 / 1 / 36.  Timed on the chip with all twelve waves of a CU reading
+// (tools/lds_bank_probe.hip, profiles/r04_lds_bank_probe.txt), a ds_read_b128 of the rest pattern costs 7.4-8.0 periods per wave-instruction
+// per CU with this layout and 9.9 with the scatter arenas' 36 / 6 / 1 (flow-like patterns: 10.5 against 10.8) - and the launch is bound by
+// LDS throughput: the gather's 27 reads are a quarter of an iteration's LDS time.
+constexpr int kG2PStrideX = 6, kG2PStrideY = 1, kG2PStrideZ = 36, kG2PNodes = 216;
 
 struct ModelView {
 	const float* bins_src;// [bin][64 records][nch floats], laid out by the previous block numbering
@@ -121,7 +129,7 @@ MPM_DEV void gather_apic(const float4* __restrict__ gbase, const float (&w)[3][3
 			v2f_ t0_xy = {0.f, 0.f}, t1_xy = {0.f, 0.f}, t0z_t1z = {0.f, 0.f};
 #pragma unroll
 			for(int k = 0; k < 3; ++k) {
-				const float4 v = gbase[i * kG2PStrideX + j * kG2PStrideY + k];
+				const float4 v = gbase[i * kG2PStrideX + j * kG2PStrideY + k * kG2PStrideZ];
 				const v2f_ vxy = {v.x, v.y}, vzz = {v.z, v.w};
 				t0_xy		   = vxy * wz[k].x + t0_xy;
 				t1_xy		   = vxy * wz[k].y + t1_xy;
@@ -177,7 +185,7 @@ MPM_DEV void p2g_serial(float4* __restrict__ arena, bool pending, int code, cons
 	const int half = lane >> 5;
 	const int oi = l / 9, oj = (l / 3) % 3, ok = l % 3;// this lane's stencil offset (lanes 0..26 of each half)
 	const float fi = (float) oi, fj = (float) oj, fk = (float) ok;
-	float4* const my_arena = arena + half * kP2GNodes;
+	float4* const my_arena = arena + half * kP2GArena2;
 	unsigned long long todo = __ballot(pending);
 	while(todo) {
 		const int src_a = __ffsll((long long) todo) - 1;
@@ -236,14 +244,18 @@ MPM_DEV void p2g_serial(float4* __restrict__ arena, bool pending, int code, cons
 // ds_read_b128 (all lanes of a half read the same entry) instead of 17 ds_bpermute, and consecutive pairs are independent up to the
 // read-modify-write itself, so their loads and arithmetic overlap; issued inside the particle loop every pair was an exposed
 // bpermute -> arithmetic -> LDS round trip (0.28 of 2.15 ms in the flow window of C3 for 3.6 % of the particles).
+#if defined(MPM_EXPERIMENT) && defined(MPM_QUEUE_ENTRIES)
+constexpr int kSerialQueue = MPM_QUEUE_ENTRIES;// (0: no queue, the lanes that cannot take the chain scatter inside the particle loop)
+#else
 constexpr int kSerialQueue = 28;// entries of 64 B: 10.8 + 1.8 KB of LDS per wave, still 12 single-wave workgroups per CU
+#endif
 MPM_DEV void serial_flush(float4* __restrict__ arena, const float4* __restrict__ queue, int qn, float mass, int lane, int info, float* __restrict__ next_grid) {
 	__asm__ volatile("" : "+v"(lane));
 	const int l	   = lane & 31;
 	const int half = lane >> 5;
 	const int oi = l / 9, oj = (l / 3) % 3, ok = l % 3;
 	const float fi = (float) oi, fj = (float) oj, fk = (float) ok;
-	float4* const my_arena = arena + half * kP2GNodes;
+	float4* const my_arena = arena + half * kP2GArena2;
 	for(int e = 0; e < qn; e += 2) {
 		const bool live	 = e + half < qn;
 		const float4* en = queue + 4 * (live ? e + half : e);
@@ -414,12 +426,12 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 	constexpr int REC = MatTraits<MAT>::rec;// floats per record (the rest: one 64-float row per channel behind the records)
 	// 10.8 KB of LDS per wave: 15 single-wave workgroups per CU.
 	__shared__ float4 g2p[kG2PNodes];	   // node velocities {vx, vy, vz, vz} of cube nodes 1..6 per axis
-	__shared__ float4 p2g[2 * kP2GNodes];  // {mass, momentum} accumulators of cube nodes 1..6 per axis; even lanes use the first
+	__shared__ float4 p2g[kP2GArena2 + kP2GNodes];  // {mass, momentum} accumulators of cube nodes 1..6 per axis; even lanes use the first
 										   // copy, odd lanes the second: the sort puts two particles of one key that share a slice
 										   // into neighbouring lanes, so both scatter in the same pass (summed in the write-back)
 	__shared__ unsigned char s_owner[2 * 216];
 	// (not for the J-fluid: its instantiation runs at four waves per SIMD and 14 workgroups per CU, which the queue's LDS would cost)
-	constexpr bool kQueue = MAT != 0;
+	constexpr bool kQueue = MAT != 0 && kSerialQueue > 0;
 	__shared__ float4 s_queue[kQueue ? 4 * kSerialQueue : 1];// payloads of the lanes that could not take the scatter chain (serial_push / serial_flush)
 #if defined(MPM_EXPERIMENT) && defined(MPM_LDS_PAD)
 	__shared__ float s_pad[MPM_LDS_PAD / 4];// experiment: lower the occupancy without touching the code
@@ -464,7 +476,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 	int rec_next   = list[(64 < size ? 64 : 0) + min(lane, cnt_next - 1)];
 	// (`info` stays in its register: lane l < 27 holds the bin offset of source block l, lanes 27..53 the destination block
 	//  numbers, lanes 54..61 the eight grid blocks; they are read with __shfl = ds_bpermute, which costs no LDS space)
-	for(int i = lane; i < 2 * kP2GNodes; i += 64) p2g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+	for(int i = lane; i < kP2GArena2 + kP2GNodes; i += 64) p2g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 	__syncthreads();
 	// ---- round trip 3: the 8 grid blocks (lane = cell -> 256-B rows per channel, :699-727) and the first 64 particles
 	float4 gv[8];
@@ -510,7 +522,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 	for(int lb = 0; lb < 8; ++lb) {
 		const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;// lane == cell of a 4x4x4 block
 		const int ax = cx + ((lb & 4) ? 4 : 0) - 1, ay = cy + ((lb & 2) ? 4 : 0) - 1, az = cz + ((lb & 1) ? 4 : 0) - 1;
-		if(((unsigned) ax < 6u) & ((unsigned) ay < 6u) & ((unsigned) az < 6u)) g2p[ax * kG2PStrideX + ay * kG2PStrideY + az] = gv[lb];
+		if(((unsigned) ax < 6u) & ((unsigned) ay < 6u) & ((unsigned) az < 6u)) g2p[ax * kG2PStrideX + ay * kG2PStrideY + az * kG2PStrideZ] = gv[lb];
 	}
 	__syncthreads();
 	// Software pipeline: the scatter of iteration i-1 (an ordered chain of 27 LDS round trips) is issued inside the material
@@ -574,7 +586,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 				bspline_weight_cells(fd[d], w[d]);
 				arena[d] = ((base[d] - 1) & 3) + 1;
 			}
-			gather_apic(g2p + (arena[0] - 1) * kG2PStrideX + (arena[1] - 1) * kG2PStrideY + (arena[2] - 1), w, fd, vel, A);
+			gather_apic(g2p + (arena[0] - 1) * kG2PStrideX + (arena[1] - 1) * kG2PStrideY + (arena[2] - 1) * kG2PStrideZ, w, fd, vel, A);
 		}
 		// Every lane runs the whole body: the idle lanes of a last partial iteration carry a dummy particle and write it into
 		// the padding slots of the block's last bin (slot == pidib < 64 * ceil(size / 64), allocated but never read), which
@@ -590,7 +602,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		if(pv_in) s_owner[pv_key] = (unsigned char) lane;
 		__asm__ volatile("" ::: "memory");// another lane may have written the same byte: no store-to-load forwarding
 		win = pv_in && !code_edge(pv_code) && (int) s_owner[pv_key] == lane;
-		ScatterChain<kSites> chain(p2g + (win ? code_off(pv_code) + (lane & 1) * kP2GNodes : 0), pv, mass, win);
+		ScatterChain<kSites> chain(p2g + (win ? code_off(pv_code) + (lane & 1) * kP2GArena2 : 0), pv, mass, win);
 		MPM_MARK("L_rebucket");
 		// ---- advect (:838)
 #pragma unroll
@@ -710,7 +722,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 			s_owner[pv_key]	 = (unsigned char) lane;
 			__asm__ volatile("" ::: "memory");
 			win = !code_edge(pv_code) && (int) s_owner[pv_key] == lane;
-			ScatterChain<1> chain(p2g + (win ? code_off(pv_code) + (lane & 1) * kP2GNodes : 0), pv, mass, win);
+			ScatterChain<1> chain(p2g + (win ? code_off(pv_code) + (lane & 1) * kP2GArena2 : 0), pv, mass, win);
 			chain.template at<0>();
 		}
 		MPM_MARK("L_serial");
@@ -785,7 +797,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		const int ax = cx + ((lb & 4) ? 4 : 0) - 1, ay = cy + ((lb & 2) ? 4 : 0) - 1, az = cz + ((lb & 1) ? 4 : 0) - 1;
 		const bool in = ((unsigned) ax < 6u) & ((unsigned) ay < 6u) & ((unsigned) az < 6u);
 		const int n	  = in ? ax * kP2GStrideX + ay * kP2GStrideY + az : 0;
-		const float4 va = p2g[n], vb = p2g[kP2GNodes + n];
+		const float4 va = p2g[n], vb = p2g[kP2GArena2 + n];
 		const float4 v	= make_float4(va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w);
 #if defined(MPM_EXPERIMENT) && defined(MPM_HACK_NOWB)// timing experiment only: no write-back of the arenas (wrong physics)
 		if(size_t(next_grid) == 1)
