@@ -344,8 +344,11 @@ def main():
             out["config"]["self_check"] = check
         # measured HBM traffic and executed instructions of the same kernel on the same workload and WINDOW (PMC passes are separate
         # runs, see profiles/): "rest" = the default window, "flow" = a window that starts after >= 2000 substeps
-        tf = os.path.join(ROOT, "profiles", "r03_pmc.json")
-        pmc = json.load(open(tf)) if os.path.exists(tf) else {}
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))      # the newest round's counter passes
+        tf = cands[-1] if cands else ""
+        pmc_name = os.path.join("profiles", os.path.basename(tf)) if tf else "profiles/(none)"
+        pmc = json.load(open(tf)) if tf else {}
         c3 = world == 1 and args.scene == "sand40m" and args.fraction >= 1.0
 
         def attach(dst, window, kernel_ms):
@@ -353,9 +356,9 @@ def main():
             if not (c3 and w):
                 return
             dst["traffic"] = w["traffic_bytes"]
-            dst["traffic_source"] = f"profiles/r03_pmc.json[{window}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of g2p2g_kernel<2>, corrected as MI355X_MICROARCH.md prescribes)"
+            dst["traffic_source"] = f"{pmc_name}[{window}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of g2p2g_kernel<2>, corrected as MI355X_MICROARCH.md prescribes; {pmc.get('stamp', 'unstamped')})"
             if window == "flow" and "traffic_bytes_low" in w:
-                # the x1.8 fetch calibration is that of a streaming kernel; the flow window reads scattered 48-B records, whose requests the counter tallies in full
+                # the fetch calibration is that of a streaming kernel; the flow window reads scattered 32-B records, whose requests the counter tallies in full
                 dst["traffic_range"] = [w["traffic_bytes_low"], w["traffic_bytes"]]
             dst["algorithmic_bytes"] = n_rank * bpp
             if "valu_insts" in w:

@@ -631,6 +631,8 @@ static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, co
 	const float cs = -next_dt * g.d_inv * g.dx;// the stress enters the P2G payload as -P F^T vol new_dt D^-1 dx (:850)
 	sk.ss	= StressScale {2.f * m.mc.mu * m.mc.volume * cs, m.mc.lambda * m.mc.volume * cs, m.mc.volume * cs};
 	sk.refl_lim = sk.dts > 0.f ? (1.f / 3.f) / sk.dts : 3.0e38f;
+	sk.jdiv		= g.dx * dt * g.d_inv;
+	sk.jvisc	= g.dx * g.d_inv * m.mc.viscosity;
 	const int nwg = nblocks_ptr ? hint_blocks(ctx, nblocks) : nblocks;
 	switch(m.material) {
 		case MPM_J_FLUID: g2p2g_kernel<0><<<nwg, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, only_flag, nblocks_ptr, nblocks, dt, next_dt, sk, ctx->d_status); break;

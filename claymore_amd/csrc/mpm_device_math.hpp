@@ -504,22 +504,21 @@ MPM_DEV void stress_nacc(const MaterialConst& mc, float (&b)[6], bool& refl, flo
 }
 
 // J-fluid (weakly compressible, Tait EOS + Newtonian viscosity), Projects/GMPM/mgmpm_kernels.cuh:476-505
-// vol: the model's volume, or (G2P2G) volume times -new_dt D^-1 dx: see StressScale
-MPM_DEV float stress_jfluid(const MaterialConst& mc, float vol, float J, const float (&A)[9], float dt, float d_inv, float (&contrib)[9]) {
-	J += (A[0] + A[4] + A[8]) * dt * d_inv * J;
+// A: the gathered velocity gradient in CELL units; jdiv = dx dt D^-1 and jvisc = dx D^-1 viscosity are formed on the host (the dx that turns
+// A into world units rides in them: nine multiplications less); vol: the model's volume times -new_dt D^-1 dx (StressScale: the stress
+// arrives as its P2G term).  The result is symmetric: six entries are computed.
+MPM_DEV float stress_jfluid(const MaterialConst& mc, float vol, float jdiv, float jvisc, float J, const float (&A)[9], float (&contrib)[9]) {
+	J = fmaf((A[0] + A[4] + A[8]) * jdiv, J, J);
 	if(J < 0.1f) J = 0.1f;// reference compares with the double literal 0.1; no float lies in (0.1, 0.1f), so this is identical
 	const float voln	 = J * vol;
 	const float pressure = mc.bulk * (__builtin_amdgcn_exp2f(-mc.gamma * __builtin_amdgcn_logf(J)) - 1.f);// J^-gamma (J >= 0.1)
-	const float k		 = d_inv * mc.viscosity;
-	contrib[0]			 = ((A[0] + A[0]) * k - pressure) * voln;
-	contrib[1]			 = (A[1] + A[3]) * k * voln;
-	contrib[2]			 = (A[2] + A[6]) * k * voln;
-	contrib[3]			 = (A[3] + A[1]) * k * voln;
-	contrib[4]			 = ((A[4] + A[4]) * k - pressure) * voln;
-	contrib[5]			 = (A[5] + A[7]) * k * voln;
-	contrib[6]			 = (A[6] + A[2]) * k * voln;
-	contrib[7]			 = (A[7] + A[5]) * k * voln;
-	contrib[8]			 = ((A[8] + A[8]) * k - pressure) * voln;
+	const float kv = jvisc * voln, pv = pressure * voln;
+	contrib[0] = fmaf(A[0] + A[0], kv, -pv);
+	contrib[4] = fmaf(A[4] + A[4], kv, -pv);
+	contrib[8] = fmaf(A[8] + A[8], kv, -pv);
+	contrib[1] = contrib[3] = (A[1] + A[3]) * kv;
+	contrib[2] = contrib[6] = (A[2] + A[6]) * kv;
+	contrib[5] = contrib[7] = (A[5] + A[7]) * kv;
 	return J;
 }
 

@@ -405,6 +405,7 @@ struct StepConst {
 	float pred;// new_dt / dx
 	float am;  // mass dx^2 D^-1
 	StressScale ss;// {2 mu, lambda, 1} * volume * (-new_dt D^-1 dx): the stress arrives as its P2G term (mpm_device_math.hpp)
+	float jdiv, jvisc;// J-fluid: dx dt D^-1, dx D^-1 viscosity (stress_jfluid)
 	float refl_lim;// (1/3) / dts: an entry of A beyond it could make det(I + dt grad v) <= 0 (the reflection bit of b, mpm_device_math.hpp)
 };
 
@@ -658,11 +659,8 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		float* dbin = mv.bins_dst + (size_t) (binoff_dst + (pidib >> 6)) * (kBin * NCH);
 		float4* dst = reinterpret_cast<float4*>(dbin + (pidib & 63) * REC);
 		if constexpr(MAT == 0) {
-			float Aw[9];
-#pragma unroll
-			for(int d = 0; d < 9; ++d) Aw[d] = A[d] * cfg.dx;
 			chain.template at<kPreSites + 0>();
-			const float J = stress_jfluid(mv.mc, sk.ss.vol, st[0], Aw, dt, cfg.d_inv, pl.contrib);
+			const float J = stress_jfluid(mv.mc, sk.ss.vol, sk.jdiv, sk.jvisc, st[0], A, pl.contrib);
 			chain.template at<kPreSites + 1>();
 			dst[0] = make_float4(pos[0], pos[1], pos[2], J);
 		} else {

@@ -14,8 +14,9 @@
 //   G6 compute_stress<NACC>               Projects/GMPM/constitutive_models.cuh:77-234
 //   G8 compute_dt                         Projects/GMPM/utility_funcs.hpp:36-49
 //   G9 matrix_*_3d helpers                Library/MnBase/Math/Matrix/MatrixUtils.h:29-41,147-157,257-286
-// (G7, the J-fluid update, is inline in the g2p2g __global__ kernel and cannot be host-compiled;
-//  it is pinned by hand-derived closed-form cases in tests/test_oracle_golden.py instead.)
+//   G7 the J-fluid update of calculate_contribution_and_store_particle_data<J_FLUID>   Projects/GMPM/mgmpm_kernels.cuh:473-504
+//      (its header cannot be host-compiled - it holds every CUDA kernel of the project -: gen_golden.sh cuts the statements out as text
+//       into jfluid_block.inc, which is compiled below inside a function whose locals carry the names the text uses)
 #include "cuda_host_shim.h"
 
 #include <chrono>
@@ -27,6 +28,18 @@
 
 #include "constitutive_models.cuh"
 #include "utility_funcs.hpp"
+
+// G7: the reference's own statements (jfluid_block.inc, cut out by gen_golden.sh) between locals of the names they use
+struct JfluidData {
+	float J;
+};
+struct JfluidParams {
+	float volume, bulk, gamma, viscosity;
+};
+static void jfluid_reference_block(JfluidData& data, const JfluidParams& particle_buffer, mn::Duration dt, const std::array<float, 9>& A, std::array<float, 9>& contrib) {
+	using namespace mn;
+#include "jfluid_block.inc"
+}
 
 static uint64_t g_state = 0x9E3779B97F4A7C15ull;
 static inline uint32_t rnd_u32() {
@@ -276,6 +289,28 @@ int main(int argc, char** argv) {
 		}
 		dump("g6_nacc_logjp_in.f32", ljp);
 		dump("g6_nacc_out.f32", out);
+	}
+	// ---- G7 J-fluid block: rows (J, A[9]) -> (J', contrib[9]) with the reference's default fluid parameters and dt = 1e-4
+	{
+		const int n = 512;
+		std::vector<float> in(10 * n), out(10 * n), par;
+		const JfluidParams pb {vol, 4e4f, 7.15f, 0.01f};// particle_buffer.cuh:148-153 (volume: the generator's, as for G4-G6)
+		const float dtv = 1e-4f;
+		par = {pb.volume, pb.bulk, pb.gamma, pb.viscosity, dtv, config::G_D_INV};
+		for(int i = 0; i < n; ++i) {
+			JfluidData d {i < 16 ? 0.1f + 0.01f * (float) i : 0.6f + 0.8f * rnd01()};
+			std::array<float, 9> A {}, c {};
+			for(int k = 0; k < 9; ++k) A[k] = (i < 16 ? -3e-3f : 1e-3f) * rnd_sym() * (i % 5 == 0 ? 10.f : 1.f);
+			if(i < 8) A[0] = A[4] = A[8] = -1e-2f;// drives J below the 0.1 clamp
+			in[10 * i] = d.J;
+			for(int k = 0; k < 9; ++k) in[10 * i + 1 + k] = A[k];
+			jfluid_reference_block(d, pb, Duration(dtv), A, c);
+			out[10 * i] = d.J;
+			for(int k = 0; k < 9; ++k) out[10 * i + 1 + k] = c[k];
+		}
+		dump("g7_jfluid_params.f32", par);
+		dump("g7_jfluid_in.f32", in);
+		dump("g7_jfluid_out.f32", out);
 	}
 	// ---- G8 compute_dt: rows (max_vel, cur, next, dt_default) -> dt
 	{

@@ -198,6 +198,23 @@ def test_g7_jfluid_closed_form():
     assert (np.abs(out[:, 1:] - want.reshape(n, 9)) <= 2e-5 * np.abs(want.reshape(n, 9)) + slack).all()
 
 
+def test_g7_jfluid_reference_statements():
+    """G7 against the reference's own statements: the J update, the 0.1 clamp, the Tait pressure and the nine contrib[] lines of
+    calculate_contribution_and_store_particle_data<J_FLUID> (Projects/GMPM/mgmpm_kernels.cuh:473-504), cut out of the file as text by
+    tests/golden/gen/gen_golden.sh and compiled between locals of the names they use.  powf comes from the same libm on both sides."""
+    api = oracle_api()
+    vol, bulk, gamma, visc, dt, d_inv = (float(v) for v in f32("g7_jfluid_params.f32"))
+    rows = f32("g7_jfluid_in.f32").reshape(-1, 10)
+    want = f32("g7_jfluid_out.f32").reshape(-1, 10)
+    n = rows.shape[0]
+    J, A = np.ascontiguousarray(rows[:, 0]), np.ascontiguousarray(rows[:, 1:])
+    out = np.empty((n, 10), dtype=np.float32)
+    api.raw.mpmo_fn_jfluid(ptr(J), ptr(A), n, dt, d_inv, vol, bulk, gamma, visc, ptr(out))
+    assert (want[:, 0] == np.float32(0.1)).sum() >= 8 and (want[:, 0] > 0.5).sum() > 400        # the clamp and the regular branch
+    assert np.array_equal(out[:, 0].view(np.uint32), want[:, 0].view(np.uint32))
+    assert _close_ulp(out[:, 1:], want[:, 1:], 5e-7, 0).all(), np.abs(out[:, 1:] - want[:, 1:]).max()
+
+
 # ---- the MGSP project's host-compilable functions (tests/golden/gen/gen_golden_mgsp.cpp) ---------------------------------------------
 def test_g12_mgsp_compute_dt_bit_exact():
     """compute_dt of the MGSP project (Projects/MGSP/utility_funcs.hpp:32-55: CFL 0.3, 0.51 frame-remainder rule): the oracle's
