@@ -1,25 +1,26 @@
 // mpm_g2p2g.hpp — the fused G2P + particle update + P2G kernel (g2p2g, Projects/GMPM/mgmpm_kernels.cuh:665-937 with the
-// per-material bodies :422-663), round-2 design.
+// per-material bodies :422-663), round-2 design with the round-3 / round-4 refinements.
 //
-// Cost model (tools/valu_rate.hip, profiles/r02_valu_rate.txt): with the whole chip busy a SIMD issues one VALU
-// instruction of this kernel's mix every ~3.9 periods of the nominal clock (VOP2 2.75, three-source VOP3 4-5, packed fp32 5.5,
-// transcendentals 8.6) and reaches that rate with two waves; a single wave gets one in only every 8-10.  The kernel is
-// bound by that issue rate (vector ALUs ~60 % busy), so the design minimises instructions per particle and keeps three
-// waves per SIMD for the LDS / memory latencies in between:
-//   * <= 168 VGPRs: the P2G scatter chain of the previous particle is threaded through the re-bucketing and the material
-//     update only (the round-1 pipeline through the gather as well cost ~40 more live registers), the gather keeps one
-//     z-pencil of loads in flight, its results are pinned where they are produced;
-//   * 10.8 KiB of LDS per wave: the advection records are read straight from global memory (prepare_blocks_kernel left them
+// Cost model (tools/valu_rate.hip, tools/lds_bank_probe.hip, profiles/r04_*): the launch runs at the socket's power
+// limit with the vector pipe as its most loaded unit (789 vector instructions per 64 particles at rest, 1 325 in a flow) and the LDS
+// pipe right behind it (27 gather reads + 27 scatter read-modify-write pairs per iteration); leave-one-out experiments say it is
+// neither bound by bytes (the solid models carry b = F F^T: 100 B of HBM traffic per particle), nor by the LDS pipe alone, nor by
+// occupancy.  What has paid is executing less.  The design:
+//   * <= 168 VGPRs (three waves per SIMD; the solid instantiations use 147-164): the P2G scatter chain of the previous particle is
+//     threaded through the re-bucketing and the material update only (the round-1 pipeline through the gather as well cost ~40 more
+//     live registers), the gather keeps one z-pencil of loads in flight, its results are pinned where they are produced;
+//   * 12.5 KiB of LDS per wave: the advection records are read straight from global memory (prepare_blocks_kernel left them
 //     sorted), the block's look-up row stays in a register (ds_bpermute), and ALL arenas hold only nodes 1..6 of the 8^3
 //     node cube around the block.  The gather never touches nodes 0 and 7; the scatter does only for particles that have
-//     just crossed into a neighbouring block (2 % in a collapsing column, none at rest): those lanes go through
-//     p2g_serial, which sends the shell part of a stencil to the grid with global atomics;
-//   * the per-particle math needs only U and sigma (sym_eig3 in mpm_device_math.hpp), not a full SVD.
+//     just crossed into a neighbouring block (2 % in a collapsing column, none at rest): those lanes go through the serial
+//     path (an LDS queue worked off once per block), which sends the shell part of a stencil to the grid with global atomics;
+//   * the per-particle math needs only U and sigma of b = F F^T (sym_eig3 in mpm_device_math.hpp), not a full SVD, and b is the
+//     state a particle carries.
 // One workgroup = ONE wave = one particle block: LDS operations of a single wave execute in order, which is what makes the
 // atomic-free read-modify-write scatter legal.  Lanes of an iteration hold distinct stencil bases: prepare_blocks_kernel
 // sorts the records by predicted base and deals them to the block's slices round-robin (a key's particles land in
 // consecutive slices); the two particles of a key that still share a slice sit in neighbouring lanes and scatter into
-// separate arenas (lane parity); what is left is decided by an owner table and goes through p2g_serial.
+// separate arenas (lane parity); what is left is decided by an owner table and goes through the serial path.
 #pragma once
 #include "mpm_device_math.hpp"
 
