@@ -625,6 +625,7 @@ static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, co
 	const int* cur_keys	  = ctx->part[r].keys;
 	const GridCfg& g = ctx->g;
 	StepConst sk;
+	sk.dtp	= dt * g.dx_inv;
 	sk.dts	= dt * (4.f * g.dx_inv);
 	sk.pred = next_dt * g.dx_inv;
 	sk.am	= m.mc.mass * g.dx * g.dx * g.d_inv;

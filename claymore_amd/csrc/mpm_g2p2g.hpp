@@ -402,6 +402,7 @@ struct ScatterChain {
 // Uniform per-launch factors, formed on the host: gfx950 has no scalar float ALU, so a uniform product computed in the kernel lives in
 // a vector register for the whole particle loop.
 struct StepConst {
+	float dtp; // dt / dx: advection in cell units (particle positions are stored as x / dx)
 	float dts; // dt * dx * D^-1 = dt * 4 / dx: A (cell units) -> dt grad v
 	float pred;// new_dt / dx
 	float am;  // mass dx^2 D^-1
@@ -465,7 +466,6 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 	const int flag = only_flag ? only_flag[b] : 1;
 	if(size == 0 || flag == 0) continue;// (:692-697)
 	const int* list		= mv.list_in + (size_t) row * cfg.ppb;
-	const float dx_inv	= cfg.dx_inv;
 	const float mass	= mv.mc.mass;
 	const int key_shift = cfg.pid_bits;
 	const int tag_shift = cfg.pid_bits + kKeyBits;
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 			float fd[3], w[3][3];
 #pragma unroll
 			for(int d = 0; d < 3; ++d) {
-				const float p = pos[d] * dx_inv;
+				const float p = pos[d];// (positions are stored in cell units: x / dx, exact for dx a power of two)
 				base[d]		  = lround_pos(p) - 1;
 				fd[d]		  = p - (float) base[d];
 				bspline_weight_cells(fd[d], w[d]);
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		MPM_MARK("L_rebucket");
 		// ---- advect (:838)
 #pragma unroll
-		for(int d = 0; d < 3; ++d) pos[d] += vel[d] * dt;
+		for(int d = 0; d < 3; ++d) pos[d] = fmaf(vel[d], sk.dtp, pos[d]);// x += v dt, in cell units: the same bits as fma(v, dt, x) scaled by 2^bits
 		// ---- new base, re-bucket (:852-866, add_advection particle_buffer.cuh:100-135).  The list-append atomics are
 		//      issued BEFORE the stress computation, which hides their round trip to L2.
 		int narena[3], dirv[3], pk[3];
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		const float pred = sk.pred;
 #pragma unroll
 		for(int d = 0; d < 3; ++d) {
-			const float p	= pos[d] * dx_inv;
+			const float p	= pos[d];
 			const int nbase = lround_pos(p) - 1;
 			nfd[d]			= p - (float) nbase;
 			narena[d]		= arena[d] + (nbase - base[d]);// new stencil base in the node cube of the block the particle came from

@@ -734,9 +734,9 @@ __global__ __launch_bounds__(256) void fill_bins_kernel(GridCfg cfg, int nch, fl
 		const int rec = rec_floats(nch), row = nch - rec;
 		float* bin = bins + (size_t) (binoff[b] + (pidib >> 6)) * (kBin * nch);
 		float* dst = bin + (pidib & 63) * rec;
-		dst[0]	   = xyz[3 * (size_t) pid];
-		dst[1]	   = xyz[3 * (size_t) pid + 1];
-		dst[2]	   = xyz[3 * (size_t) pid + 2];
+		dst[0]	   = xyz[3 * (size_t) pid] * cfg.dx_inv;// positions live in cell units (x / dx: exact, dx is a power of two) - G2P2G's index and
+		dst[1]	   = xyz[3 * (size_t) pid + 1] * cfg.dx_inv;// weight arithmetic is in cell units anyway
+		dst[2]	   = xyz[3 * (size_t) pid + 2] * cfg.dx_inv;
 		dst[3]	   = 1.f;// J, or b00
 		if(nch != 4) {
 			dst[4] = 1.f;// b11
@@ -799,9 +799,9 @@ __global__ __launch_bounds__(256) void retrieve_kernel(GridCfg cfg, int nch, con
 		const float* row = bin + kBin * recf + (sp & 63) * rowf;
 		const unsigned long long o = atomicAdd(counter, 1ull);
 		if(o >= capacity) continue;
-		xyz[3 * o]	   = src[0];
-		xyz[3 * o + 1] = src[1];
-		xyz[3 * o + 2] = src[2];
+		xyz[3 * o]	   = src[0] * cfg.dx;// (stored in cell units)
+		xyz[3 * o + 1] = src[1] * cfg.dx;
+		xyz[3 * o + 2] = src[2] * cfg.dx;
 		if(state9) {
 			if(nch == 4) {
 				state9[9 * o] = src[3];
