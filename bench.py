@@ -55,6 +55,12 @@ def make_scene(args):
     elif args.scene == "fluid12m":
         sc = scenes.fluid_dam(10, (32, 192, 256))
         name = "C5 per-rank share (1/8): weakly compressible J-fluid slab 32x192x256 cells, 1024^3 sparse grid"
+    elif args.scene == "spheres40m":
+        sc = scenes.two_spheres_c4()
+        name = "C4 on one GPU: two fixed-corotated spheres of R = 84 dx (2 x 19.9 M particles), 512^3 sparse grid"
+    elif args.scene == "fluid100m":
+        sc = scenes.fluid_dam(10)
+        name = "C5 on one GPU: weakly compressible J-fluid box 256x192x256 cells (100.7 M particles), 1024^3 sparse grid"
     else:
         raise SystemExit(f"unknown scene {args.scene}")
     return sc, name
@@ -121,7 +127,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)   # warm-up 10 substeps, time the next 100
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--scene", default="sand40m", choices=["sand40m", "sphere5m", "spheres50k", "fluid12m"])
+    ap.add_argument("--scene", default="sand40m", choices=["sand40m", "sphere5m", "spheres50k", "fluid12m", "spheres40m", "fluid100m"])
     ap.add_argument("--start-step", type=int, default=0,
                     help="untimed substeps before the warm-up: moves the timed window into the flow (the default window of C3 "
                          "starts at rest; after ~3000 substeps the column is collapsing: block churn, mispredicted sort keys)")

@@ -45,5 +45,8 @@ if [ "$1" = "all" ]; then
   pmc c2_fc "$SQA" --scene sphere5m --steps 3 --warmup 2
   trace c5_fluid --scene fluid12m
   pmc c5_fluid "$SQA" --scene fluid12m --steps 3 --warmup 2
+  # the two multi-GPU configurations whole on ONE GPU (they fit: 288 GB): the per-particle rate of FC / the J-fluid without C2's launch tail
+  trace c4_fc_one_gpu --scene spheres40m --steps 40 --warmup 10
+  trace c5_fluid_one_gpu --scene fluid100m --steps 40 --warmup 10
 fi
 ls -la $O
