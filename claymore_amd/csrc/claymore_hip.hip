@@ -974,6 +974,9 @@ const char* mpm_build_info(void) {
 	return "claymore_hip abi5 state=b"
 #ifdef MPM_EXPERIMENT
 		   " experiment=MPM_EXPERIMENT"
+#ifdef MPM_HACK_EDGEWIN
+		   ",MPM_HACK_EDGEWIN"
+#endif
 #ifdef MPM_HACK_NOSHELL
 		   ",MPM_HACK_NOSHELL"
 #endif

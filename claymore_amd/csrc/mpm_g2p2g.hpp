@@ -703,6 +703,9 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		MPM_MARK("L_contrib");
 		chain.template at<kSites - 1>();
 		ncode = in_arena ? (narena[0] | (narena[1] << 4) | (narena[2] << 8)) : -1;
+#if defined(MPM_EXPERIMENT) && defined(MPM_HACK_EDGEWIN)// timing experiment only: stencil bases on the cube's edge are moved inside, so no lane takes the serial path for that reason (wrong physics)
+		if(in_arena) ncode = min(max(narena[0], 1), 4) | (min(max(narena[1], 1), 4) << 4) | (min(max(narena[2], 1), 4) << 8);
+#endif
 		MPM_MARK("L_append");
 		// ---- list append: the atomics' results are in by now (and with them the next iteration's particle data)
 		{

@@ -99,6 +99,21 @@ def main():
                 g, p, w = window(eng, 10, 50, sc5["dt"])
                 row.append(f"| C5 fluid: g2p2g {g:.4f} step {w:.4f}")
                 eng.close()
+            if "c4" in want:       # one of C4's two spheres, translating at 1 m/s: every ~10th substep half of the particles change their stencil base at once
+                sc4 = scenes.two_spheres_c4()
+                sc4["models"] = sc4["models"][:1]
+                eng = build_engine(sc4, api=api)
+                eng.initial_setup()
+                g, p, w = window(eng, 10, 40, sc4["dt"])
+                row.append(f"| C4 one sphere: g2p2g {g:.4f} step {w:.4f}")
+                eng.close()
+            if "c5flow" in want:   # the dam break under way
+                sc5f = scenes.fluid_dam(10, (32, 192, 256))
+                eng = build_engine(sc5f, api=api)
+                eng.initial_setup()
+                g, p, w = window(eng, 3000, 30, sc5f["dt"])
+                row.append(f"| C5 fluid after 3000: g2p2g {g:.4f} step {w:.4f}")
+                eng.close()
             emit(" ".join(row))
 
 
