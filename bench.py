@@ -141,6 +141,10 @@ def main():
                     help="N = 1, default scene: after the timed window the run goes on to this substep and a second short window is timed "
                          "inside the flow (reported as roofline.flow; 0 = skip)")
     ap.add_argument("--sync-interval", type=int, default=0, help="debug: mpm_config.sync_interval (0 = library default)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="debug: rank r uses device r %% (devices present) instead of device LOCAL_RANK - several ranks per GPU.  RCCL refuses "
+                         "that; with a stand-in collective library (MPM_RCCL_LIBRARY, tests/rccl_double/rccl_double_mp.cpp) it is how the "
+                         "N-process launch is exercised on a one-GPU box.  Never a measurement.")
     ap.add_argument("--watchdog", type=float, default=900.0,
                     help="seconds after which a run that has not finished prints a JSON error line and exits (a rank stuck in a collective "
                          "would otherwise sit there until the caller's own timeout); 0 = off")
@@ -189,6 +193,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
+    if args.oversubscribe:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     use_mgsp = world > 1 or args.mgsp
     if use_mgsp:
@@ -331,7 +337,7 @@ def main():
             "config": {"workload": workload, "particles": n_total, "dt": dt,
                        "parallelism": "single GPU" if not use_mgsp else
                        f"mgsp static particle partition x{world} ({'one column per rank' if weak else 'equal-count slabs of the one column'}), C++ driver on RCCL",
-                       "blocks": blocks, "phases_ms": phases},
+                       "blocks": blocks, "phases_ms": phases, **({"oversubscribed": "ranks share GPUs (debug launch, not a measurement)"} if args.oversubscribe else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "g2p2g_kernel", "bytes_per_particle": bpp, "particles_per_launch": n_rank,

@@ -506,3 +506,45 @@ def test_a_failing_rank_fails_every_rank_and_nobody_hangs(world, rccl_double_lib
     env = dict(os.environ, MPM_RCCL_LIBRARY=rccl_double_library)
     r = subprocess.run([sys.executable, os.path.join(here, "rccl_double", "run_group.py"), str(world), "fail"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK world" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.fixture(scope="session")
+def rccl_double_mp_library(tmp_path_factory):
+    """Build tests/rccl_double/rccl_double_mp.cpp (the MULTI-PROCESS double of the RCCL calls: data staged through a shared mapping) once per session."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = tmp_path_factory.mktemp("rccl_double_mp") / "librccl_double_mp.so"
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_double", "rccl_double_mp.cpp")
+    subprocess.run([hipcc, "-O1", "-std=c++17", "-fPIC", "-shared", "-o", str(out), src, "-lpthread"], check=True, capture_output=True, timeout=600)
+    return str(out)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_the_drivers_multi_process_bench_launch_on_one_gpu(world, rccl_double_mp_library, tmp_path):
+    """The launch the driver uses for its scaling curve - python -m torch.distributed.run --nproc-per-node N bench.py --gpus N - with N
+    PROCESSES sharing the one GPU (bench.py --oversubscribe) and the collectives served by the multi-process double (MPM_RCCL_LIBRARY):
+    gloo rendez-vous, the unique id broadcast from rank 0, ncclCommInitRank in every process, the rank's slab of the column, the C++ group
+    loop, bench.py's self-check over all ranks (every particle bucketed, nothing lost or discarded), the max over ranks and the ONE JSON
+    line on rank 0's stdout.  What it cannot show is RCCL itself and the timing."""
+    import json
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    frac = 1.0 / 32.0
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "3", "--oversubscribe", "--watchdog", "500"]
+    cmd += ["--fraction", str(frac)]   # (strong scaling, BASELINE's metric: the one column cut into `world` equal-count slabs)
+    env = dict(os.environ, MPM_RCCL_LIBRARY=rccl_double_mp_library, RCCL_DOUBLE_DIR=str(tmp_path), RCCL_DOUBLE_TIMEOUT_S="200", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-6000:])
+    rec = json.loads(lines[0])
+    assert rec.get("error") is None, rec
+    assert rec["n_gpus"] == world and rec["steps"] == 6 and rec["warmup"] == 3 and rec["scaling"] == "strong" and rec["value"] > 0
+    assert f"x{world}" in rec["config"]["parallelism"] and "oversubscribed" in rec["config"]
+    assert rec["roofline"]["particles_per_launch"] * world == pytest.approx(rec["config"]["particles"], rel=0.02)   # equal-count slabs
+    assert "collective library" in r.stderr and "rccl_double_mp" in r.stderr                                        # the library says what it loaded
