@@ -3,13 +3,18 @@
 // ncclGroupEnd).  RCCL cannot host two ranks on one device, and the build box has one GPU: with this library (loaded through
 // MPM_RCCL_LIBRARY) every rank is a thread of one process with its own engine context on the same GPU, and the RCCL branch of the
 // group driver - the grouped send / receive of the halo exchange with its offsets and counts, the padded key all-gather, the
-// all-reduce of the maximum velocity, their order on the streams - runs with world sizes > 1.  Data moves with device-to-device copies;
-// every call synchronises the host (simple and obviously correct: nothing here is timed).  What it checks beyond moving the bytes:
-// a receive whose size differs from the matching send fails, as does a collective entered with different sizes.
+// all-reduce of the maximum velocity, their order on the streams - runs with world sizes > 1.  Data moves with device-to-device copies.
+// Default mode: STREAM-ORDERED like the real library - a send / receive / all-gather is complete in the order of the stream it was
+// given and asynchronous to the host: the copies are enqueued behind the peer's event, nothing waits for the GPU (the ranks' host threads
+// only meet to hand over pointers and events).  A dependency the product forgot - a kernel that reads a receive buffer from another stream
+// without waiting for the exchange's event, a send buffer overwritten while the peer still copies from it - is then a real race on the
+// GPU, as it would be with RCCL.  RCCL_DOUBLE_SYNC=1 restores the old behaviour (every call synchronises the host).  What it checks beyond
+// moving the bytes: a receive whose size differs from the matching send fails, as does a collective entered with different sizes.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -21,6 +26,9 @@ struct Msg {
 	const void* ptr = nullptr;
 	size_t bytes	= 0;
 	bool full		= false;
+	hipEvent_t ready = nullptr;// (stream-ordered mode) recorded by the sender where the data is complete
+	hipEvent_t done	 = nullptr;// recorded by the receiver behind its copy
+	bool done_posted = false;
 };
 struct Group {
 	int n = 0, joined = 0, refs = 0;
@@ -31,6 +39,7 @@ struct Group {
 	const void* cptr[64] = {};
 	size_t cbytes[64]	 = {};
 	float cval[64]		 = {};
+	hipEvent_t cready[64] = {}, cdone[64] = {};
 	void barrier() {
 		std::unique_lock<std::mutex> lk(m);
 		const int g = gen;
@@ -45,7 +54,16 @@ struct Group {
 struct Comm {
 	Group* g;
 	int rank;
+	std::vector<hipEvent_t> ev_send, ev_done;// per peer
+	hipEvent_t ev_cready = nullptr, ev_cdone = nullptr;
 };
+bool sync_mode() {
+	static const bool v = [] {
+		const char* e = getenv("RCCL_DOUBLE_SYNC");
+		return e && e[0] && e[0] != '0';
+	}();
+	return v;
+}
 struct Op {
 	bool send;
 	const void* sbuf;
@@ -80,7 +98,67 @@ size_t type_size(ncclDataType_t t) {
 		if((e) != hipSuccess) return ncclUnhandledCudaError; \
 	} while(0)
 
+ncclResult_t run_ops_stream_ordered(std::vector<Op>& ops) {
+	// 1. every send: an event where the data is complete (in stream order), announced with the pointer
+	for(Op& o: ops)
+		if(o.send) {
+			Comm* c = o.comm;
+			HIPOK(hipEventRecord(c->ev_send[o.peer], o.stream));
+			Group* g = c->g;
+			std::unique_lock<std::mutex> lk(g->m);
+			Msg& b = g->box[(size_t) c->rank * g->n + o.peer];
+			g->cv.wait(lk, [&] { return !b.full; });
+			b.ptr = o.sbuf, b.bytes = o.bytes, b.ready = c->ev_send[o.peer], b.done_posted = false, b.full = true;
+			g->cv.notify_all();
+		}
+	// 2. every receive: the copy waits (on the GPU) for the sender's event; an event behind the copy goes back
+	ncclResult_t rc = ncclSuccess;
+	for(Op& o: ops)
+		if(!o.send) {
+			Comm* c	 = o.comm;
+			Group* g = c->g;
+			const void* src;
+			size_t bytes;
+			hipEvent_t ready;
+			{
+				std::unique_lock<std::mutex> lk(g->m);
+				Msg& b = g->box[(size_t) o.peer * g->n + c->rank];
+				g->cv.wait(lk, [&] { return b.full && !b.done_posted; });
+				src = b.ptr, bytes = b.bytes, ready = b.ready;
+			}
+			if(bytes != o.bytes)
+				rc = ncclInvalidArgument;
+			else {
+				HIPOK(hipStreamWaitEvent(o.stream, ready, 0));
+				HIPOK(hipMemcpyAsync(o.rbuf, src, bytes, hipMemcpyDeviceToDevice, o.stream));
+			}
+			HIPOK(hipEventRecord(c->ev_done[o.peer], o.stream));
+			std::unique_lock<std::mutex> lk(g->m);
+			Msg& b = g->box[(size_t) o.peer * g->n + c->rank];
+			b.done = c->ev_done[o.peer], b.done_posted = true;
+			g->cv.notify_all();
+		}
+	// 3. every send: what follows on the sender's stream (it may overwrite the buffer) waits for the peer's copy
+	for(Op& o: ops)
+		if(o.send) {
+			Comm* c	 = o.comm;
+			Group* g = c->g;
+			hipEvent_t done;
+			{
+				std::unique_lock<std::mutex> lk(g->m);
+				Msg& b = g->box[(size_t) c->rank * g->n + o.peer];
+				g->cv.wait(lk, [&] { return b.done_posted; });
+				done   = b.done;
+				b.full = false, b.done_posted = false;
+				g->cv.notify_all();
+			}
+			HIPOK(hipStreamWaitEvent(o.stream, done, 0));
+		}
+	return rc;
+}
+
 ncclResult_t run_ops(std::vector<Op>& ops) {
+	if(!sync_mode()) return run_ops_stream_ordered(ops);
 	// 1. every send: data complete, then announced
 	for(Op& o: ops)
 		if(o.send) {
@@ -156,12 +234,25 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
 		g->cv.notify_all();
 		g->cv.wait(lk, [&] { return g->joined >= g->n; });
 	}
-	*comm = reinterpret_cast<ncclComm_t>(new Comm {g, rank});
+	Comm* c = new Comm {g, rank, {}, {}, nullptr, nullptr};
+	c->ev_send.resize(nranks, nullptr), c->ev_done.resize(nranks, nullptr);
+	for(int p = 0; p < nranks; ++p) {
+		HIPOK(hipEventCreateWithFlags(&c->ev_send[p], hipEventDisableTiming));
+		HIPOK(hipEventCreateWithFlags(&c->ev_done[p], hipEventDisableTiming));
+	}
+	HIPOK(hipEventCreateWithFlags(&c->ev_cready, hipEventDisableTiming));
+	HIPOK(hipEventCreateWithFlags(&c->ev_cdone, hipEventDisableTiming));
+	*comm = reinterpret_cast<ncclComm_t>(c);
 	return ncclSuccess;
 }
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
 	Comm* c = reinterpret_cast<Comm*>(comm);
 	if(!c) return ncclSuccess;
+	(void) hipDeviceSynchronize();// (no copy of a peer may still wait on one of these events)
+	for(hipEvent_t e: c->ev_send) (void) hipEventDestroy(e);
+	for(hipEvent_t e: c->ev_done) (void) hipEventDestroy(e);
+	(void) hipEventDestroy(c->ev_cready);
+	(void) hipEventDestroy(c->ev_cdone);
 	bool last;
 	{
 		std::lock_guard<std::mutex> lk(c->g->m);
@@ -217,6 +308,27 @@ ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcoun
 	if(!c || !type_size(type)) return ncclInvalidArgument;
 	Group* g		   = c->g;
 	const size_t bytes = sendcount * type_size(type);
+	if(!sync_mode()) {
+		HIPOK(hipEventRecord(c->ev_cready, stream));
+		g->cptr[c->rank] = sendbuff, g->cbytes[c->rank] = bytes, g->cready[c->rank] = c->ev_cready;
+		g->barrier();
+		ncclResult_t rc = ncclSuccess;
+		for(int p = 0; p < g->n; ++p) {
+			if(g->cbytes[p] != bytes) {
+				rc = ncclInvalidArgument;
+				continue;
+			}
+			if(p != c->rank) HIPOK(hipStreamWaitEvent(stream, g->cready[p], 0));
+			HIPOK(hipMemcpyAsync(static_cast<char*>(recvbuff) + (size_t) p * bytes, g->cptr[p], bytes, hipMemcpyDeviceToDevice, stream));
+		}
+		HIPOK(hipEventRecord(c->ev_cdone, stream));
+		g->cdone[c->rank] = c->ev_cdone;
+		g->barrier();
+		for(int p = 0; p < g->n; ++p)
+			if(p != c->rank) HIPOK(hipStreamWaitEvent(stream, g->cdone[p], 0));// the send buffer may be rewritten only behind every peer's copy
+		g->barrier();// (everybody has taken the events before anybody posts the next collective)
+		return rc;
+	}
 	HIPOK(hipStreamSynchronize(stream));
 	g->cptr[c->rank] = sendbuff, g->cbytes[c->rank] = bytes;
 	g->barrier();

@@ -6,7 +6,7 @@ served by the in-process double tests/rccl_double/rccl_double.cpp (MPM_RCCL_LIBR
 per run because the library loads its collective library once).  The union of the ranks' particles must follow the single-engine
 CPU oracle.  Prints "OK ..." on success.
 
-    MPM_RCCL_LIBRARY=/path/to/librccl_double.so python tests/rccl_double/run_group.py WORLD KIND   (KIND: fixed | substeps | adaptive | fail)
+    MPM_RCCL_LIBRARY=/path/to/librccl_double.so python tests/rccl_double/run_group.py WORLD KIND   (KIND: fixed | substeps | adaptive | fixed-big | fail)
 
 KIND fail: rank 1 runs with a block capacity it outgrows after a few substeps (no growth): it must come back with MPM_ERR_CAPACITY, and so
 must EVERY other rank, in the same substep (its status word travels in row 0 of the key all-gather) - nobody may be left waiting in a
@@ -88,6 +88,13 @@ def main():
         return run_failing_rank(world)
     sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=0.5, speed=2.0, youngs=2e4)
     nsteps, dt = 60, 1e-4
+    big = kind.endswith("-big")
+    if big:
+        # 2 x 2.1 M particles in contact: launches of a fraction of a millisecond, megabytes of halo per substep - long enough for a forgotten
+        # stream dependency (the double is stream-ordered, like RCCL) to show; compared with the plain single-GPU engine, not the CPU oracle
+        kind = kind[:-4]
+        sc = scenes.two_spheres(bits=8, radius_cells=40.0, gap_cells=0.5, speed=2.0, youngs=2e4)
+        nsteps = 40
     ident, have_id = {}, threading.Event()
 
     def bootstrap(raw):            # what bench.py does with one gloo broadcast
@@ -134,7 +141,7 @@ def main():
         assert [r[3] for r in results] == [steps_o] * world, ([r[3] for r in results], steps_o)
         want = [w[0] for w in want]
     else:
-        ora = build_engine(sc, api=oracle_api())
+        ora = build_engine(sc) if big else build_engine(sc, api=oracle_api())
         ora.initial_setup()
         ora.run_fixed(nsteps, dt)
         want = [ora.retrieve_state(m)[0] for m in range(len(sc["models"]))]
@@ -146,8 +153,8 @@ def main():
         idx, _ = match(xo.astype(np.float64), xm.astype(np.float64))
         rel = np.abs(xm[idx].astype(np.float64) - xo).max(axis=1) / np.abs(xo).max(axis=1)
         worst = max(worst, float(rel.max()))
-    assert worst < 1e-5, worst
-    print(f"OK world {world} {kind}: {results[0][3]} substeps, worst relative position error {worst:.2e}, grid blocks sent {[r[1] for r in results]}, halo particle blocks {[r[2] for r in results]}")
+    assert worst < (1e-6 if big else 1e-5), worst   # (big: 2.3e-7 is the sum-order difference; a mutant without the comm stream's wait for the collect kernel reaches 1.6e-6)
+    print(f"OK world {world} {kind}{' (big, vs the single-GPU engine)' if big else ''}: {results[0][3]} substeps, worst relative position error {worst:.2e}, grid blocks sent {[r[1] for r in results]}, halo particle blocks {[r[2] for r in results]}")
 
 
 if __name__ == "__main__":

@@ -480,15 +480,21 @@ def rccl_double_library(tmp_path_factory):
     return str(out)
 
 
-@pytest.mark.parametrize("world,kind", [(2, "fixed"), (3, "substeps"), (4, "fixed"), (2, "adaptive"), (3, "fixed-nodefer")])
+@pytest.mark.parametrize("world,kind", [(2, "fixed"), (3, "substeps"), (4, "fixed"), (2, "adaptive"), (3, "fixed-nodefer"), (4, "fixed-big"), (8, "fixed-big"), (4, "fixed-big-sync"), (8, "fixed-big-sync")])
 def test_rccl_transport_with_several_ranks_through_the_rccl_double(world, kind, rccl_double_library):
     """The RCCL branch of the group driver with world > 1 (RCCL itself cannot host two ranks on one device, the box has one GPU):
     every rank a thread with its own context, mpm_group_create with a unique id, the grouped ncclSend / ncclRecv of the halo exchange,
     the ncclAllGather of the keys and the ncclAllReduce of the maximum velocity served by an in-process double loaded through
-    MPM_RCCL_LIBRARY (tests/rccl_double/).  Runs in a subprocess (the library binds its collective library once per process)."""
+    MPM_RCCL_LIBRARY (tests/rccl_double/).  The double is STREAM-ORDERED like the real library (copies enqueued behind the peer's event,
+    nothing synchronises the host), so a stream dependency the driver forgot is a race here too; "fixed-big" runs 4.2 M particles in contact,
+    launches long enough for such a race to show, against the plain single-GPU engine.  Runs in a subprocess (the library binds its
+    collective library once per process)."""
     import subprocess
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, MPM_RCCL_LIBRARY=rccl_double_library)
+    if kind.endswith("-sync"):    # the double's other mode: every call synchronises the host (a mutant of the driver without the comm stream's wait for the
+        env["RCCL_DOUBLE_SYNC"] = "1"   # collect kernel fails here at once, in the stream-ordered mode only sometimes: profiles/r04_double_mutants.txt)
+        kind = kind[:-5]
     if kind == "fixed-nodefer":   # the same loop with the host waiting at the end of every substep (what "fixed" defers behind the next halo-first launch)
         env["MPM_GROUP_DEFER"] = "0"
         kind = "fixed"
