@@ -48,7 +48,6 @@ struct Comm {
 	size_t map_bytes = 0;
 	int rank = 0, world = 0;
 	std::string path;
-	void* staging = nullptr;// pinned bounce buffer is not needed: hipMemcpy from / to the mapping directly
 	char* slot(int r) const { return data + (size_t) r * h->slot_bytes; }
 	size_t lane_bytes() const { return (h->slot_bytes / (size_t) (world + 1)) & ~(size_t) 255; }
 	char* coll(int r) const { return slot(r) + (size_t) world * lane_bytes(); }
