@@ -156,6 +156,9 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    # (the host driver of this pool supports dmabuf IPC only: without this RCCL's cross-process buffer sharing fails in hipIpcGetMemHandle;
+    #  the harness exports it - kept here for a launch from a bare shell)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
