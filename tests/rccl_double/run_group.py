@@ -6,7 +6,7 @@ served by the in-process double tests/rccl_double/rccl_double.cpp (MPM_RCCL_LIBR
 per run because the library loads its collective library once).  The union of the ranks' particles must follow the single-engine
 CPU oracle.  Prints "OK ..." on success.
 
-    MPM_RCCL_LIBRARY=/path/to/librccl_double.so python tests/rccl_double/run_group.py WORLD KIND   (KIND: fixed | substeps | adaptive | fixed-big | fail)
+    MPM_RCCL_LIBRARY=/path/to/librccl_double.so python tests/rccl_double/run_group.py WORLD KIND   (KIND: fixed | substeps | adaptive | fixed-big | plate | fail)
 
 KIND fail: rank 1 runs with a block capacity it outgrows after a few substeps (no growth): it must come back with MPM_ERR_CAPACITY, and so
 must EVERY other rank, in the same substep (its status word travels in row 0 of the key all-gather) - nobody may be left waiting in a
@@ -81,11 +81,73 @@ def run_failing_rank(world):
     print(f"OK world {world} fail: every rank returned MPM_ERR_CAPACITY ({[o[1] for o in outcome]})")
 
 
+def run_plate(world):
+    """A rank whose particle blocks are ALL halo blocks at first and all interior later: a plate of elastic material two cells above a body
+    that belongs to the other rank (no contact, but the same grid blocks), thrown upwards.  The windowed loop launches a substep's G2P2G passes before the host has seen the
+    counts of the tagging they run on; the interior pass must not be skipped because the host's count of interior blocks (one tagging
+    old) is still zero - those blocks would be done by neither pass and their particles would silently disappear (round 4: they did)."""
+    from claymore_amd import _ffi
+    assert world == 2
+    bits = 7
+    prm = {"volume": (1.0 / (1 << bits)) ** 3 / 8.0, "youngs_modulus": 5e3, "poisson_ratio": 0.4, "rho": 1e3}
+    base = {"name": "plate_on_body", "bits": bits, "dt": 1e-4, "config": {"max_ppc": 128}}
+    body = dict(base, models=[{"material": _ffi.FIXED_COROTATED, "xyz": scenes.lattice_box(bits, (44, 40, 44), (84, 58, 84)), "v0": (0.0, 0.0, 0.0), "params": dict(prm)}])
+    plate = dict(base, models=[{"material": _ffi.FIXED_COROTATED, "xyz": scenes.lattice_box(bits, (52, 60, 52), (76, 62, 76)), "v0": (0.0, 5.0, 0.0), "params": dict(prm)}])
+    locals_ = [body, plate]
+    ident, have_id = {}, threading.Event()
+
+    def bootstrap(raw):
+        if raw is not None:
+            ident["raw"] = raw
+            have_id.set()
+        else:
+            assert have_id.wait(120)
+        return ident["raw"]
+
+    log, errors, sims, start = [[] for _ in range(world)], [], [None] * world, [None] * world
+    bar = threading.Barrier(world)
+
+    def work(rank):
+        try:
+            sim = sims[rank] = MgspGroupRank(locals_[rank], rank, world, device=0, bootstrap=bootstrap, prepartitioned=True)
+            sim.initial_setup()
+            c0 = sim.eng.counts()
+            start[rank] = (c0.particle_blocks, sim.n_halo_blocks)
+            for _ in range(40):
+                sim.run_fixed(10, 1e-4)
+                c, d = sim.eng.counts(), sim.eng.diagnostics()
+                log[rank].append((sum(c.particles[i] for i in range(c.model_count)), c.particle_blocks, sim.n_halo_blocks, d.lost_particles, d.discarded_p2g))
+                bar.wait(120)
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+            bar.abort()
+
+    threads = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck in a collective"
+    assert not errors, errors
+    n_local = [s.n_local for s in sims]
+    for s in sims:
+        s.close()
+    last = log[1][-1]
+    assert start[1][1] == start[1][0] and start[1][0] > 0, f"the plate's blocks are not all halo blocks at the start: (particle blocks, halo particle blocks) = {start[1]}"
+    assert last[2] == 0, f"the plate never left the body: {last}"
+    for r in range(world):
+        bad = [(10 * (k + 1), e) for k, e in enumerate(log[r]) if e[0] != n_local[r] or e[3] or e[4]]
+        assert not bad, f"rank {r} ({n_local[r]} particles) lost particles: (substep, (bucketed, particle blocks, halo particle blocks, lost, discarded)) {bad[:4]}"
+    print(f"OK world {world} plate: every particle bucketed through {10 * len(log[0])} substeps; the plate's halo particle blocks went {start[1][1]} (of {start[1][0]} particle blocks) -> {[e[2] for e in log[1]][:6]} ...")
+
+
 def main():
     world, kind = int(sys.argv[1]), sys.argv[2]
     assert os.environ.get("MPM_RCCL_LIBRARY"), "MPM_RCCL_LIBRARY is not set"
     if kind == "fail":
         return run_failing_rank(world)
+    if kind == "plate":
+        return run_plate(world)
     sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=0.5, speed=2.0, youngs=2e4)
     nsteps, dt = 60, 1e-4
     big = kind.endswith("-big")

@@ -480,14 +480,16 @@ def rccl_double_library(tmp_path_factory):
     return str(out)
 
 
-@pytest.mark.parametrize("world,kind", [(2, "fixed"), (3, "substeps"), (4, "fixed"), (2, "adaptive"), (3, "fixed-nodefer"), (4, "fixed-big"), (8, "fixed-big"), (4, "fixed-big-sync"), (8, "fixed-big-sync")])
+@pytest.mark.parametrize("world,kind", [(2, "fixed"), (3, "substeps"), (4, "fixed"), (2, "adaptive"), (3, "fixed-nodefer"), (4, "fixed-big"), (8, "fixed-big"), (4, "fixed-big-sync"), (8, "fixed-big-sync"), (2, "plate")])
 def test_rccl_transport_with_several_ranks_through_the_rccl_double(world, kind, rccl_double_library):
     """The RCCL branch of the group driver with world > 1 (RCCL itself cannot host two ranks on one device, the box has one GPU):
     every rank a thread with its own context, mpm_group_create with a unique id, the grouped ncclSend / ncclRecv of the halo exchange,
     the ncclAllGather of the keys and the ncclAllReduce of the maximum velocity served by an in-process double loaded through
     MPM_RCCL_LIBRARY (tests/rccl_double/).  The double is STREAM-ORDERED like the real library (copies enqueued behind the peer's event,
     nothing synchronises the host), so a stream dependency the driver forgot is a race here too; "fixed-big" runs 4.2 M particles in contact,
-    launches long enough for such a race to show, against the plain single-GPU engine.  Runs in a subprocess (the library binds its
+    launches long enough for such a race to show, against the plain single-GPU engine; "plate" is the regression scene of the windowed loop's
+    stale interior-block count (a rank whose blocks are all halo blocks at first, all interior 20 substeps later: it used to lose half its
+    particles without a flag).  Runs in a subprocess (the library binds its
     collective library once per process)."""
     import subprocess
     here = os.path.dirname(os.path.abspath(__file__))
