@@ -1,6 +1,6 @@
 """Per-rank particle accounting of the strong-scaling layout deep in the flow: WORLD ranks as threads on one GPU (RCCL branch of the group driver
 through the in-process double, MPM_RCCL_LIBRARY), the full C3 column, STEPS substeps of mpm_group_run_fixed in chunks; after every chunk each
-rank's bucketed particle count against its share, and its diagnostics.  usage: mgsp_flow_check.py WORLD [STEPS=3030] [CHUNK=500] [FRACTION=1.0]"""
+rank's bucketed particle count against its share, and its diagnostics.  usage: mgsp_flow_check.py WORLD [STEPS=3030] [CHUNK=500] [SCENE=c3|c4|c5|c3small]"""
 import os
 import sys
 import threading
@@ -12,9 +12,9 @@ from claymore_amd.mgsp import MgspGroupRank
 world = int(sys.argv[1])
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3030
 chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 500
-frac = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
+which = sys.argv[4] if len(sys.argv) > 4 else "c3"
 assert os.environ.get("MPM_RCCL_LIBRARY"), "MPM_RCCL_LIBRARY is not set"
-sc = scenes.sand_column(9) if frac >= 1.0 else scenes.scaled_sand_column(9, frac)
+sc = {"c3": lambda: scenes.sand_column(9), "c4": scenes.two_spheres_c4, "c5": lambda: scenes.fluid_dam(10), "c3small": lambda: scenes.scaled_sand_column(9, 1.0 / 16.0)}[which]()
 dt = sc["dt"]
 ident, have_id = {}, threading.Event()
 
@@ -57,7 +57,7 @@ for t in th:
     t.start()
 for t in th:
     t.join(timeout=1500)
-print(f"# world {world}, {steps} substeps, MPM_GROUP_DEFER={os.environ.get('MPM_GROUP_DEFER', '(unset)')}")
+print(f"# scene {which}, world {world}, {steps} substeps, MPM_GROUP_DEFER={os.environ.get('MPM_GROUP_DEFER', '(unset)')}")
 for k in range(max(len(x) for x in lines)):
     for r in range(world):
         if k < len(lines[r]) and ("+0)" not in lines[r][k] or k == len(lines[r]) - 1):
