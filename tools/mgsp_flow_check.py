@@ -30,6 +30,7 @@ def bootstrap(raw):
 
 bar = threading.Barrier(world)
 lines, errors = [[] for _ in range(world)], []
+sums = [None] * world   # per rank: (n, sum of positions, sum of squared heights) at the end
 
 
 def work(rank):
@@ -46,6 +47,14 @@ def work(rank):
             lines[rank].append(f"step {done}: rank {rank} bucketed {have} of {sim.n_local} ({have - sim.n_local:+d}) lost {d.lost_particles} discarded {d.discarded_p2g} dropped {d.dropped_particles} "
                                f"overflow {d.overflow_flags} blocks {c.particle_blocks}/{c.neighbor_blocks}/{c.exterior_blocks} halo blocks {sim.n_halo_blocks}")
             bar.wait(600)
+        import numpy as np
+        acc = [0, np.zeros(3), 0.0]
+        for xyz, *_ in sim.local_state():
+            x = xyz.astype(np.float64)
+            acc[0] += x.shape[0]
+            acc[1] += x.sum(axis=0)
+            acc[2] += float((x[:, 1] ** 2).sum())
+        sums[rank] = acc
         sim.close()
     except Exception as e:  # noqa: BLE001
         errors.append((rank, repr(e)))
@@ -63,3 +72,24 @@ for k in range(max(len(x) for x in lines)):
         if k < len(lines[r]) and ("+0)" not in lines[r][k] or k == len(lines[r]) - 1):
             print(lines[r][k])
 print("errors:", errors)
+
+if not errors and all(x is not None for x in sums):
+    # the same substeps on ONE engine: centre of mass and the second moment of the heights of all particles must agree (sums over 4e7 particles:
+    # the order of the float additions on the grid differs between the runs, a wrong or stale halo block would not average out)
+    import numpy as np
+    from claymore_amd.engine import build_engine
+    n = sum(x[0] for x in sums)
+    com = sum(x[1] for x in sums) / n
+    h2 = sum(x[2] for x in sums) / n
+    eng = build_engine(sc)
+    eng.initial_setup()
+    eng.run_fixed(steps, dt)
+    n1, s1, q1 = 0, np.zeros(3), 0.0
+    for m in range(len(sc["models"])):
+        x = eng.retrieve_positions(m).astype(np.float64)
+        n1 += x.shape[0]
+        s1 += x.sum(axis=0)
+        q1 += float((x[:, 1] ** 2).sum())
+    eng.close()
+    com1, h21 = s1 / n1, q1 / n1
+    print(f"centre of mass, {world} ranks: {com}  one engine: {com1}  difference {np.abs(com - com1).max():.3e}; mean squared height {h2:.9f} vs {h21:.9f} (relative {abs(h2 - h21) / h21:.2e}); particles {n} vs {n1}")
