@@ -6,7 +6,7 @@ served by the in-process double tests/rccl_double/rccl_double.cpp (MPM_RCCL_LIBR
 per run because the library loads its collective library once).  The union of the ranks' particles must follow the single-engine
 CPU oracle.  Prints "OK ..." on success.
 
-    MPM_RCCL_LIBRARY=/path/to/librccl_double.so python tests/rccl_double/run_group.py WORLD KIND   (KIND: fixed | substeps | adaptive | fixed-big | plate | fail)
+    MPM_RCCL_LIBRARY=/path/to/librccl_double.so python tests/rccl_double/run_group.py WORLD KIND   (KIND: fixed | substeps | adaptive | fixed-big | plate | plate-fall | fail)
 
 KIND fail: rank 1 runs with a block capacity it outgrows after a few substeps (no growth): it must come back with MPM_ERR_CAPACITY, and so
 must EVERY other rank, in the same substep (its status word travels in row 0 of the key all-gather) - nobody may be left waiting in a
@@ -81,7 +81,7 @@ def run_failing_rank(world):
     print(f"OK world {world} fail: every rank returned MPM_ERR_CAPACITY ({[o[1] for o in outcome]})")
 
 
-def run_plate(world):
+def run_plate(world, fall=False):
     """A rank whose particle blocks are ALL halo blocks at first and all interior later: a plate of elastic material two cells above a body
     that belongs to the other rank (no contact, but the same grid blocks), thrown upwards.  The windowed loop launches a substep's G2P2G passes before the host has seen the
     counts of the tagging they run on; the interior pass must not be skipped because the host's count of interior blocks (one tagging
@@ -93,6 +93,9 @@ def run_plate(world):
     base = {"name": "plate_on_body", "bits": bits, "dt": 1e-4, "config": {"max_ppc": 128}}
     body = dict(base, models=[{"material": _ffi.FIXED_COROTATED, "xyz": scenes.lattice_box(bits, (44, 40, 44), (84, 58, 84)), "v0": (0.0, 0.0, 0.0), "params": dict(prm)}])
     plate = dict(base, models=[{"material": _ffi.FIXED_COROTATED, "xyz": scenes.lattice_box(bits, (52, 60, 52), (76, 62, 76)), "v0": (0.0, 5.0, 0.0), "params": dict(prm)}])
+    if fall:   # the other way round: the plate starts 14 cells above the body - no block in common - and is thrown at it (no halo -> all halo -> contact)
+        plate["models"][0]["xyz"] = scenes.lattice_box(bits, (52, 72, 52), (76, 74, 76))
+        plate["models"][0]["v0"] = (0.0, -5.0, 0.0)
     locals_ = [body, plate]
     ident, have_id = {}, threading.Event()
 
@@ -104,7 +107,7 @@ def run_plate(world):
             assert have_id.wait(120)
         return ident["raw"]
 
-    log, errors, sims, start = [[] for _ in range(world)], [], [None] * world, [None] * world
+    log, errors, sims, start, final = [[] for _ in range(world)], [], [None] * world, [None] * world, [None] * world
     bar = threading.Barrier(world)
 
     def work(rank):
@@ -118,6 +121,7 @@ def run_plate(world):
                 c, d = sim.eng.counts(), sim.eng.diagnostics()
                 log[rank].append((sum(c.particles[i] for i in range(c.model_count)), c.particle_blocks, sim.n_halo_blocks, d.lost_particles, d.discarded_p2g))
                 bar.wait(120)
+            final[rank] = sim.local_state()[0][0]
         except Exception as e:  # noqa: BLE001
             errors.append((rank, repr(e)))
             bar.abort()
@@ -133,12 +137,30 @@ def run_plate(world):
     for s in sims:
         s.close()
     last = log[1][-1]
-    assert start[1][1] == start[1][0] and start[1][0] > 0, f"the plate's blocks are not all halo blocks at the start: (particle blocks, halo particle blocks) = {start[1]}"
-    assert last[2] == 0, f"the plate never left the body: {last}"
+    if fall:
+        assert start[1][1] == 0 and start[1][0] > 0, f"the plate shares blocks with the body at the start: (particle blocks, halo particle blocks) = {start[1]}"
+        assert max(e[2] for e in log[1]) == max(e[1] for e in log[1] if e[2]), f"the plate never became all halo blocks: {[e[1:3] for e in log[1]]}"
+    else:
+        assert start[1][1] == start[1][0] and start[1][0] > 0, f"the plate's blocks are not all halo blocks at the start: (particle blocks, halo particle blocks) = {start[1]}"
+        assert last[2] == 0, f"the plate never left the body: {last}"
     for r in range(world):
         bad = [(10 * (k + 1), e) for k, e in enumerate(log[r]) if e[0] != n_local[r] or e[3] or e[4]]
         assert not bad, f"rank {r} ({n_local[r]} particles) lost particles: (substep, (bucketed, particle blocks, halo particle blocks, lost, discarded)) {bad[:4]}"
-    print(f"OK world {world} plate: every particle bucketed through {10 * len(log[0])} substeps; the plate's halo particle blocks went {start[1][1]} (of {start[1][0]} particle blocks) -> {[e[2] for e in log[1]][:6]} ...")
+    # the physics: both bodies as two models of ONE engine, the same substeps
+    both = dict(base, models=[body["models"][0], plate["models"][0]])
+    one = build_engine(both)
+    one.initial_setup()
+    one.run_fixed(10 * len(log[0]), 1e-4)
+    worst = 0.0
+    for m in range(2):
+        xo = one.retrieve_state(m)[0]
+        xm = final[m]
+        assert xm.shape == xo.shape, (xm.shape, xo.shape)
+        idx, _ = match(xo.astype(np.float64), xm.astype(np.float64))
+        worst = max(worst, float((np.abs(xm[idx].astype(np.float64) - xo).max(axis=1) / np.abs(xo).max(axis=1)).max()))
+    one.close()
+    assert worst < 1e-5, worst
+    print(f"OK world {world} plate{'-fall' if fall else ''}: worst relative position error against one engine {worst:.2e}; every particle bucketed through {10 * len(log[0])} substeps; the plate's halo particle blocks went {start[1][1]} (of {start[1][0]} particle blocks) -> {[e[2] for e in log[1]][:6]} ...")
 
 
 def main():
@@ -146,8 +168,8 @@ def main():
     assert os.environ.get("MPM_RCCL_LIBRARY"), "MPM_RCCL_LIBRARY is not set"
     if kind == "fail":
         return run_failing_rank(world)
-    if kind == "plate":
-        return run_plate(world)
+    if kind in ("plate", "plate-fall"):
+        return run_plate(world, fall=kind == "plate-fall")
     sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=0.5, speed=2.0, youngs=2e4)
     nsteps, dt = 60, 1e-4
     big = kind.endswith("-big")
