@@ -110,6 +110,7 @@ HIP_ONLY = {
     "group_destroy": (None, [_vp]),
     "group_last_error": (C.c_char_p, [_vp]),
     "group_initial_setup": (_i, [_vp]),
+    "group_resume": (_i, [_vp]),
     "group_substep": (_i, [_vp, _f, _f, _fp]),
     "group_run_fixed": (_i, [_vp, _i, _f]),
     "group_compute_dt": (_f, [_vp, _f, _f, _f, _f]),

@@ -345,6 +345,15 @@ class MgspGroupRank:
     def initial_setup(self):
         self._check(self.api.group_initial_setup(self.grp))
 
+    def save_checkpoint(self):
+        """This rank's full state at a substep boundary (mpm_checkpoint_save of its context)."""
+        return self.eng.save_checkpoint()
+
+    def load_checkpoint(self, buf):
+        """Restart: load this rank's checkpoint, then rebuild the tagging with the other ranks (mpm_group_resume: collective)."""
+        self.eng.load_checkpoint(buf)
+        self._check(self.api.group_resume(self.grp))
+
     def substep(self, dt, next_dt):
         mv = C.c_float(0)
         self._check(self.api.group_substep(self.grp, dt, next_dt, C.byref(mv)))

@@ -296,6 +296,10 @@ void mpm_group_destroy(mpm_group* g);
 const char* mpm_group_last_error(const mpm_group* g);
 /* initial_setup of every rank + first tagging + one exchange that sums the rasterised grids (mgsp_benchmark.cuh:561-659). */
 int mpm_group_initial_setup(mpm_group* g);
+/* Restart (row f4 for the multi-GPU loop; the reference has none): after EVERY rank has loaded its own checkpoint with
+ * mpm_checkpoint_load (taken after a call of this driver returned), rebuild what a checkpoint does not carry - padded key length,
+ * overlap marks, halo / interior lists, per-peer send lists.  Collective: every rank calls it. */
+int mpm_group_resume(mpm_group* g);
 /* One substep, one host synchronisation; *max_vel_sqr = this rank's max |v|^2 (not reduced over ranks). */
 int mpm_group_substep(mpm_group* g, float dt, float next_dt, float* max_vel_sqr);
 int mpm_group_run_fixed(mpm_group* g, int nsteps, float dt);

@@ -6,7 +6,7 @@ served by the in-process double tests/rccl_double/rccl_double.cpp (MPM_RCCL_LIBR
 per run because the library loads its collective library once).  The union of the ranks' particles must follow the single-engine
 CPU oracle.  Prints "OK ..." on success.
 
-    MPM_RCCL_LIBRARY=/path/to/librccl_double.so python tests/rccl_double/run_group.py WORLD KIND   (KIND: fixed | substeps | adaptive | fixed-big | plate | plate-fall | fail)
+    MPM_RCCL_LIBRARY=/path/to/librccl_double.so python tests/rccl_double/run_group.py WORLD KIND   (KIND: fixed | substeps | adaptive | fixed-big | plate | plate-fall | resume | fail)
 
 KIND fail: rank 1 runs with a block capacity it outgrows after a few substeps (no growth): it must come back with MPM_ERR_CAPACITY, and so
 must EVERY other rank, in the same substep (its status word travels in row 0 of the key all-gather) - nobody may be left waiting in a
@@ -163,11 +163,90 @@ def run_plate(world, fall=False):
     print(f"OK world {world} plate{'-fall' if fall else ''}: worst relative position error against one engine {worst:.2e}; every particle bucketed through {10 * len(log[0])} substeps; the plate's halo particle blocks went {start[1][1]} (of {start[1][0]} particle blocks) -> {[e[2] for e in log[1]][:6]} ...")
 
 
+def run_resume(world):
+    """Restart of a group: 30 substeps, every rank saves its checkpoint, 30 more (A).  Then NEW contexts and a NEW communicator: initial
+    set-up, every rank loads its checkpoint, mpm_group_resume rebuilds the tagging, 30 substeps (B).  B must be A (to the float atomics'
+    last bits) and the CPU oracle's uninterrupted 60 substeps."""
+    sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=0.5, speed=2.0, youngs=2e4)
+    dt = 1e-4
+
+    def group_run(body):
+        ident, have_id = {}, threading.Event()
+
+        def bootstrap(raw):
+            if raw is not None:
+                ident["raw"] = raw
+                have_id.set()
+            else:
+                assert have_id.wait(120)
+            return ident["raw"]
+
+        out, errors = [None] * world, []
+
+        def work(rank):
+            sim = None
+            try:
+                sim = MgspGroupRank(sc, rank, world, device=0, bootstrap=bootstrap)
+                sim.initial_setup()
+                out[rank] = body(rank, sim)
+            except Exception as e:  # noqa: BLE001
+                errors.append((rank, repr(e)))
+            finally:
+                if sim is not None:
+                    sim.close()
+
+        threads = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not any(t.is_alive() for t in threads), "a rank is stuck in a collective"
+        assert not errors, errors
+        return out
+
+    def first(rank, sim):
+        sim.run_fixed(30, dt)
+        ck = sim.save_checkpoint().copy()
+        sim.run_fixed(30, dt)
+        return ck, sim.local_state(), sim.n_halo_blocks
+
+    def second(rank, sim):
+        sim.load_checkpoint(saved[rank][0])
+        sim.run_fixed(30, dt)
+        return sim.local_state(), sim.n_halo_blocks
+
+    saved = group_run(first)
+    again = group_run(second)
+    assert max(x[2] for x in saved) > 0, "no halo: the exchange was not exercised"
+    worst = 0.0
+    for r in range(world):
+        for m in range(len(sc["models"])):
+            a, b = saved[r][1][m][0].astype(np.float64), again[r][0][m][0].astype(np.float64)
+            assert a.shape == b.shape, (a.shape, b.shape)
+            if a.shape[0]:   # (the order of the particles in the bins need not be the same: the runs' atomics order the lists differently)
+                idx, _ = match(a, b)
+                worst = max(worst, float((np.abs(b[idx] - a).max(axis=1) / np.abs(a).max(axis=1)).max()))
+    ora = build_engine(sc, api=oracle_api())
+    ora.initial_setup()
+    ora.run_fixed(60, dt)
+    worst_o = 0.0
+    for m in range(len(sc["models"])):
+        xo = ora.retrieve_state(m)[0]
+        xm = np.concatenate([again[r][0][m][0] for r in range(world)])
+        idx, _ = match(xo.astype(np.float64), xm.astype(np.float64))
+        worst_o = max(worst_o, float((np.abs(xm[idx].astype(np.float64) - xo).max(axis=1) / np.abs(xo).max(axis=1)).max()))
+    ora.close()
+    assert worst < 2e-6 and worst_o < 1e-5, (worst, worst_o)
+    print(f"OK world {world} resume: restarted run against the uninterrupted one {worst:.2e}, against the oracle's 60 substeps {worst_o:.2e}; halo particle blocks {[x[2] for x in saved]} / {[x[1] for x in again]}")
+
+
 def main():
     world, kind = int(sys.argv[1]), sys.argv[2]
     assert os.environ.get("MPM_RCCL_LIBRARY"), "MPM_RCCL_LIBRARY is not set"
     if kind == "fail":
         return run_failing_rank(world)
+    if kind == "resume":
+        return run_resume(world)
     if kind in ("plate", "plate-fall"):
         return run_plate(world, fall=kind == "plate-fall")
     sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=0.5, speed=2.0, youngs=2e4)
