@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# build an engine library variant into gpurun_libs/<name>.so for a same-box A/B (tools/gpu_ab_libs.sh): tools/build_variant.sh name [-D...]
+# build an engine library variant into gpurun_libs/<name>.so for a same-box A/B (tools/gpu_ab.sh -> tools/ab_libs.py): tools/build_variant.sh name [-D...]
 cd "$(dirname "$0")/.."
 n=$1; shift
 mkdir -p gpurun_libs
