@@ -86,3 +86,21 @@ def test_experiment_switch_without_the_guard_does_not_compile():
         r = subprocess.run(base + ["-D" + sw], capture_output=True, text=True)
         assert r.returncode != 0 and "MPM_EXPERIMENT" in r.stderr, (sw, r.stderr[-300:])
         assert subprocess.run(base + ["-D" + sw, "-DMPM_EXPERIMENT"], capture_output=True).returncode == 0
+
+
+def test_bench_without_a_gpu_fails_loudly_with_one_json_error_line():
+    """The product path has no CPU fallback: on a box without a GPU bench.py exits non-zero and its stdout is ONE JSON record with an
+    `error` field (what a driver that parses the line sees instead of a traceback), never a number computed some other way."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this box has a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["value"] is None and "needs a GPU" in rec["error"] and rec["n_gpus"] == 1
