@@ -556,3 +556,28 @@ def test_the_drivers_multi_process_bench_launch_on_one_gpu(world, rccl_double_mp
     assert f"x{world}" in rec["config"]["parallelism"] and "oversubscribed" in rec["config"]
     assert rec["roofline"]["particles_per_launch"] * world == pytest.approx(rec["config"]["particles"], rel=0.02)   # equal-count slabs
     assert "collective library" in r.stderr and "rccl_double_mp" in r.stderr                                        # the library says what it loaded
+
+
+def test_bench_two_ranks_on_real_rccl_when_the_box_has_two_gpus():
+    """The same launch on the real library: skipped on the one-GPU boxes this suite usually runs on; on a box with two or more GPUs it is
+    the first place RCCL carries the halo exchange between two devices (strong scaling of a 1/32-scale column, bench.py's self-check)."""
+    import json
+    import socket
+    import subprocess
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--fraction", str(1.0 / 32.0), "--watchdog", "500"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MPM_RCCL_LIBRARY", None)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-6000:])
+    rec = json.loads(lines[0])
+    assert rec.get("error") is None and rec["n_gpus"] == 2 and rec["value"] > 0, rec
+    assert rec["config"]["self_check"]["lost_particles"] == 0 and rec["config"]["self_check"]["particles_bucketed"] == rec["config"]["particles"]
