@@ -171,7 +171,9 @@ def main():
     def error_line(reason):
         rec = {"metric": "particles*steps/sec", "value": None, "unit": "particles*steps/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
                "error": reason, "stage": stage["at"], "rank": rank, "ranks_seen": stage["ranks_seen"]}
-        os.write(json_fd, (json.dumps(rec) + "\n").encode())
+        # stdout carries ONE record: rank 0's.  The other ranks' records go to stderr (with N ranks failing together - which is what an
+        # engine error does: every rank returns it in the same substep - stdout would otherwise hold N lines)
+        os.write(json_fd if rank == 0 else 2, (json.dumps(rec) + "\n").encode())
 
     def watchdog():
         if not finished.wait(args.watchdog):
