@@ -14,11 +14,16 @@ value = particles of all ranks * K / time.
 
 Extra objects on the JSON line:
   roofline     - G2P2G (the dominant kernel): algorithmic bytes per launch (144 B/particle
-                 for sand) / average kernel duration from HIP events on the engine's compute stream, vs 8 TB/s;
-                 roofline.flow: the same for a second short window inside the flow (the default window of C3 is free fall, the
-                 kernel's cheapest regime); traffic / executed instructions from the PMC profile of the MATCHING window
-  cpu_baseline - the CPU oracle ("port" of the reference pipeline, serial) timed on this host on a bounded,
-                 geometrically similar sample of the same workload (rank 0, N = 1 only)
+                 for sand) / average kernel duration from HIP events on the engine's compute stream, vs 8 TB/s.  For the default
+                 run (N = 1, C3) the HEADLINE roofline.frac is that of a second window INSIDE THE FLOW (20 substeps after
+                 --flow-start: the column is collapsing - block churn, plastic return mapping, three Jacobi sweeps); the timed K
+                 substeps themselves (the column in free fall, the kernel's cheapest regime) are roofline.rest.  `traffic` and
+                 `valu_executed` come from the PMC profile of the MATCHING window (profiles/rNN_pmc.json) and are attached only
+                 when that file's stamp is the sha256 of the library this run loaded; physical_frac = those counter bytes /
+                 this run's kernel time / 8 TB/s (what the memory system really moved, beside the algorithmic figure)
+  cpu_baseline - the CPU oracle ("port" of the reference pipeline) timed on this host on the same input, outside the timed
+                 region (rank 0, N = 1 only): OpenMP over G2P2G's particle blocks, the grid update and the rebuild's
+                 order-independent loops; `cores` = the threads it ran on
 """
 import argparse
 import ctypes as C
@@ -66,10 +71,27 @@ def make_scene(args):
     return sc, name
 
 
+def _free_gb():
+    try:
+        import psutil
+        return psutil.virtual_memory().available / 2 ** 30
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        with open("/proc/meminfo") as f:
+            for ln in f:
+                if ln.startswith("MemAvailable:"):
+                    return int(ln.split()[1]) / 2 ** 20
+    except Exception:  # noqa: BLE001
+        pass
+    return 0.0
+
+
 def cpu_baseline(args, scene=None):
     """The CPU oracle (a port of the reference pipeline, oracle/mpm_oracle.c) timed on this host, outside the timed region of the GPU run:
       * on the SAME input as the GPU run - for the default scene the full C3 column (40.1 M particles; set-up ~40 s serial, 11 GB, then
-        one warm + two timed substeps, OpenMP over particle blocks in G2P2G on all host cores), and
+        one warm + five timed substeps; OpenMP over particle blocks in G2P2G, over grid blocks in the grid update and over the
+        order-independent loops of the rebuild - fills, per-block copies; the inserts that define the block numbering stay serial), and
       * single-threaded on the full C1 scene (BASELINE config 1: the reference's own CPU-runnable case).
     A host with less than 24 GB of free memory falls back to a 1/64-scale column (same aspect ratio, same grid) and says so."""
     import __graft_entry__ as g
@@ -79,47 +101,60 @@ def cpu_baseline(args, scene=None):
     from oracle_ffi import oracle_api
     api = oracle_api()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 64))
+    threads = max(1, min(cores, 64))
 
-    def timed(sc, threads, steps, warm=1):
+    def timed(sc, nthreads, steps, warm=1):
         eng = build_engine(sc, api=api)
         t0 = time.perf_counter()
         eng.initial_setup()
         setup = time.perf_counter() - t0
-        api.raw.mpmo_set_threads(eng.ctx, threads)
+        api.raw.mpmo_set_threads(eng.ctx, nthreads)
         eng.run_fixed(warm, sc["dt"])
         t0 = time.perf_counter()
         eng.run_fixed(steps, sc["dt"])
         dt = time.perf_counter() - t0
+        tm = eng.timers()                     # (the oracle's own clocks, last substep)
         eng.close()
-        return scenes.total_particles(sc) * steps / dt, dt, setup
+        return scenes.total_particles(sc) * steps / dt, dt, setup, {"grid_update_ms": tm.grid_update_ms, "g2p2g_ms": tm.g2p2g_ms, "partition_ms": tm.partition_ms}
 
-    try:
-        import psutil
-        free_gb = psutil.virtual_memory().available / 2 ** 30
-    except Exception:  # noqa: BLE001
-        free_gb = 0.0
+    free_gb = _free_gb()
+    same = False
     if args.scene == "sand40m":
         full = args.fraction >= 1.0 and free_gb >= 24.0 and scene is not None
+        same = full
         sc = scene if full else scenes.scaled_sand_column(9, 1.0 / 64.0)
-        steps = 2 if full else 19
-        what = (f"the full C3 scene ({scenes.total_particles(sc)} particles, 512^3)" if full else
-                f"sand column scaled to {scenes.total_particles(sc)} particles (1/64 of C3, same aspect ratio, 512^3 grid; the host has {free_gb:.0f} GB free, the full scene needs 24)")
+        steps = 5 if full else 19
+        what = (f"the full C3 scene ({scenes.total_particles(sc)} particles, 512^3): the same input as the GPU run" if full else
+                f"sand column scaled to {scenes.total_particles(sc)} particles (1/64 of C3, same aspect ratio, 512^3 grid: NOT the GPU run's input; the host has {free_gb:.0f} GB free, the full scene needs 24)")
     elif args.scene == "sphere5m":
-        sc, steps = (scene if scene is not None else scenes.sphere_drop()), 4
-        what = f"the full C2 scene ({scenes.total_particles(sc)} particles, 256^3)"
+        sc, steps = (scene if scene is not None else scenes.sphere_drop()), 5
+        same = scene is not None
+        what = f"the full C2 scene ({scenes.total_particles(sc)} particles, 256^3)" + (": the same input as the GPU run" if same else "")
     else:
         sc, steps = scenes.two_spheres(), 20
         what = "the full C1 scene"
-    rate, dt, setup = timed(sc, cores, steps)
-    out = {"value": rate, "unit": "particles*steps/s", "cores": cores, "kind": "port",
-           "sample": f"{what}: the same input as the GPU run, {steps} substeps after one warm-up substep, C oracle (oracle/mpm_oracle.c) with OpenMP over particle "
-                     f"blocks in G2P2G ({cores} threads; the rest of the pipeline is serial), {dt:.1f} s (+ {setup:.0f} s of serial set-up, not counted)"}
+    rate, dt, setup, last = timed(sc, threads, steps)
+    out = {"value": rate, "unit": "particles*steps/s", "cores": threads, "threads": threads, "host_cores": cores, "kind": "port", "same_input": same,
+           "timed_substeps": steps, "last_substep_ms": last,
+           "sample": f"{what}, {steps} substeps after one warm-up substep, C oracle (oracle/mpm_oracle.c) on {threads} OpenMP threads (G2P2G over particle "
+                     f"blocks, grid update over grid blocks, the rebuild's fills and per-block copies; its numbering inserts are serial), {dt:.1f} s "
+                     f"(+ {setup:.0f} s of serial set-up, not counted)"}
     c1 = scenes.two_spheres()
-    r1, t1, _ = timed(c1, 1, 100, warm=2)
+    r1, t1, _, _ = timed(c1, 1, 100, warm=2)
     out["c1_single_thread"] = {"value": r1, "unit": "particles*steps/s", "cores": 1,
                                "sample": f"the full C1 scene (BASELINE config 1: two elastic spheres, {scenes.total_particles(c1)} particles, 128^3), 100 substeps, one thread, {t1:.1f} s"}
     return out
+
+
+def loaded_library_sha16():
+    """First 16 hex digits of the sha256 of the engine library this process loads (what tools/stamp.sh writes into every profile)."""
+    import hashlib
+    from claymore_amd import _ffi
+    h = hashlib.sha256()
+    with open(_ffi.HIP_LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -148,6 +183,9 @@ def main():
     ap.add_argument("--watchdog", type=float, default=900.0,
                     help="seconds after which a run that has not finished prints a JSON error line and exits (a rank stuck in a collective "
                          "would otherwise sit there until the caller's own timeout); 0 = off")
+    ap.add_argument("--baseline-timeout", type=float, default=420.0,
+                    help="seconds the CPU baseline may take after the GPU measurement is complete; beyond it the record is emitted with "
+                         "cpu_baseline.error instead of a value (the finished GPU numbers are never lost to a slow host)")
     args = ap.parse_args()
 
     # stdout carries exactly one line, the JSON record: libraries that print banners there (gloo's "connected to N peer ranks",
@@ -360,24 +398,40 @@ def main():
         if check is not None:
             out["config"]["self_check"] = check
         # measured HBM traffic and executed instructions of the same kernel on the same workload and WINDOW (PMC passes are separate
-        # runs, see profiles/): "rest" = the default window, "flow" = a window that starts after >= 2000 substeps
+        # runs, see profiles/): "rest" = the default window, "flow" = a window that starts after >= 2000 substeps.  The counters describe
+        # ONE build of the kernel: they are attached only when the file's stamp carries the sha256 of the library this run loaded.
         import glob
+        import re
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))      # the newest round's counter passes
         tf = cands[-1] if cands else ""
         pmc_name = os.path.join("profiles", os.path.basename(tf)) if tf else "profiles/(none)"
         pmc = json.load(open(tf)) if tf else {}
         c3 = world == 1 and args.scene == "sand40m" and args.fraction >= 1.0
+        lib_sha = loaded_library_sha16()
+        m_ = re.search(r"sha256 ([0-9a-f]{16})", pmc.get("stamp", ""))
+        pmc_sha = m_.group(1) if m_ else None
+        out["library_sha256_16"] = lib_sha
 
         def attach(dst, window, kernel_ms):
             w = pmc.get(window)
             if not (c3 and w):
                 return
+            dst["algorithmic_bytes"] = n_rank * bpp
+            if pmc_sha != lib_sha:
+                dst["traffic"] = None
+                dst["traffic_source"] = (f"REFUSED: {pmc_name} was taken with library sha256 {pmc_sha} ({pmc.get('stamp', 'unstamped')}), this run loaded {lib_sha}: "
+                                         "counters of another build are not attached (re-take the PMC passes: tools/gpu_profile_r05.sh)")
+                return
             dst["traffic"] = w["traffic_bytes"]
-            dst["traffic_source"] = f"{pmc_name}[{window}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of g2p2g_kernel<2>, corrected as MI355X_MICROARCH.md prescribes; {pmc.get('stamp', 'unstamped')})"
+            dst["traffic_source"] = f"{pmc_name}[{window}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of g2p2g_kernel<2>, corrected as MI355X_MICROARCH.md prescribes; {pmc.get('stamp', 'unstamped')}: the library this run loaded)"
+            if kernel_ms > 0:
+                # what the memory system moved per launch (counters of the profiled launch) over THIS run's kernel time: the physical HBM rate
+                dst["physical_frac"] = w["traffic_bytes"] / (kernel_ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
             if window == "flow" and "traffic_bytes_low" in w:
                 # the fetch calibration is that of a streaming kernel; the flow window reads scattered 32-B records, whose requests the counter tallies in full
                 dst["traffic_range"] = [w["traffic_bytes_low"], w["traffic_bytes"]]
-            dst["algorithmic_bytes"] = n_rank * bpp
+                if kernel_ms > 0:
+                    dst["physical_frac_range"] = [w["traffic_bytes_low"] / (kernel_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), dst["physical_frac"]]
             if "valu_insts" in w:
                 # one wave-instruction serves 64 particles: instructions per particle (= per 64-particle iteration of a wave)
                 per_particle = w["valu_insts"] * 64.0 / n_rank
@@ -387,17 +441,55 @@ def main():
                 dst["valu_executed"] = {"wave_instructions_per_launch": w["valu_insts"], "executed_per_particle": per_particle, "issue_busy": busy,
                                         "note": "SQ_INSTS_VALU of the profiled launch; issue_busy prices an instruction at 2.75 cycles of a 1.97 GHz SIMD (measured mix and clock)"}
 
-        attach(out["roofline"], "flow" if args.start_step >= 2000 else "rest", g2p2g_ms)
+        timed_window = "flow" if args.start_step >= 2000 else "rest"
+        out["roofline"]["window"] = f"the timed K substeps ({'inside the flow' if timed_window == 'flow' else 'substeps ' + str(args.start_step + args.warmup) + '-' + str(args.start_step + args.warmup + args.steps)})"
+        attach(out["roofline"], timed_window, g2p2g_ms)
         if flow:
+            # The headline is the FLOW window (the timed K substeps of the default run are the column in free fall - every block
+            # settled, no Jacobi sweep, no plastic branch: the kernel's cheapest regime); the timed window moves to roofline.rest.
+            rest = dict(out["roofline"])
             fa = (n_rank * bpp) / (flow["kernel_ms"] * 1e-3) / 1e9
-            out["roofline"]["flow"] = {"start_step": flow["start_step"], "steps": flow["steps"], "kernel_ms": flow["kernel_ms"], "achieved": fa,
-                                       "frac": fa / HBM_PEAK_GBS, "ms_per_step": flow["ms_per_step"], "blocks": flow["blocks"], "traffic": None}
-            attach(out["roofline"]["flow"], "flow", flow["kernel_ms"])
+            head = {"bound": "hbm", "achieved": fa, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fa / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "g2p2g_kernel", "bytes_per_particle": bpp, "particles_per_launch": n_rank, "kernel_ms": flow["kernel_ms"],
+                    "window": f"flow: substeps {flow['start_step']}-{flow['start_step'] + flow['steps']} of the same run (the column is collapsing); the timed K substeps are roofline.rest",
+                    "start_step": flow["start_step"], "steps": flow["steps"], "ms_per_step": flow["ms_per_step"], "blocks": flow["blocks"]}
+            tflf = (n_rank * fpp) / (flow["kernel_ms"] * 1e-3) / 1e12
+            head["valu"] = {"flops_per_particle": fpp, "achieved_tflops": tflf, "peak": FP32_VECTOR_PEAK_TFLOPS, "frac": tflf / FP32_VECTOR_PEAK_TFLOPS,
+                            "note": "algorithmic FLOPs of the reference formulation (SURVEY.md 8d), not executed instructions"}
+            attach(head, "flow", flow["kernel_ms"])
+            head["rest"] = rest
+            out["roofline"] = head
+
+        def emit():
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+
         if world == 1 and not args.no_cpu_baseline and not args.mgsp:
+            # The GPU measurement is complete: from here on nothing may lose it.  The baseline runs in a worker with its own time limit; the
+            # watchdog is disarmed (it guards the GPU part: a rank stuck in a collective).
             stage["at"] = "cpu baseline (oracle on the host cores)"
-            out["cpu_baseline"] = cpu_baseline(args, sc)
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+            finished.set()
+            box = {}
+
+            def work():
+                try:
+                    box["value"] = cpu_baseline(args, sc)
+                except BaseException as e:  # noqa: BLE001
+                    box["error"] = f"{type(e).__name__}: {e}"
+
+            th = threading.Thread(target=work, daemon=True)
+            th.start()
+            th.join(args.baseline_timeout if args.baseline_timeout > 0 else None)
+            if "value" in box:
+                out["cpu_baseline"] = box["value"]
+            else:
+                out["cpu_baseline"] = {"value": None, "unit": "particles*steps/s", "kind": "port",
+                                       "error": box.get("error", f"not finished after {args.baseline_timeout:.0f} s (--baseline-timeout); the GPU record above is complete")}
+            emit()
+            if th.is_alive():
+                os._exit(0)       # (the worker cannot be cancelled: leave with the record written)
+        else:
+            emit()
     finished.set()
     if use_mgsp:
         dist.destroy_process_group()

@@ -7,7 +7,7 @@ product binds libclaymore_hip.so with prefix "mpm_", the tests additionally bind
 import ctypes as C
 import os
 
-MPM_OK, MPM_ERR_INVALID, MPM_ERR_DEVICE, MPM_ERR_CAPACITY, MPM_ERR_NONFINITE, MPM_ERR_NOT_READY = range(6)
+MPM_OK, MPM_ERR_INVALID, MPM_ERR_DEVICE, MPM_ERR_CAPACITY, MPM_ERR_NONFINITE, MPM_ERR_NOT_READY, MPM_ERR_INTERNAL = range(7)
 J_FLUID, FIXED_COROTATED, SAND, NACC = range(4)
 MATERIAL_NAMES = {"jfluid": J_FLUID, "fixed_corotated": FIXED_COROTATED, "sand": SAND, "nacc": NACC}
 
@@ -69,6 +69,7 @@ SIGNATURES = {
     "run_fixed": (_i, [_vp, _i, _f]),
     "retrieve_positions": (_i, [_vp, _i, _vp, _P(_sz)]),
     "retrieve_state": (_i, [_vp, _i, _vp, _vp, _vp, _P(_sz)]),
+    "state_kind": (_i, []),
     "get_counts": (_i, [_vp, _P(Counts)]),
     "get_timers": (_i, [_vp, _P(Timers)]),
     "grid_totals": (_i, [_vp, _P(C.c_double)]),

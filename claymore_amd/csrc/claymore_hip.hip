@@ -89,6 +89,7 @@ struct mpm_ctx {
 	unsigned long long* d_counter = nullptr;
 	bool ready = false;
 	int capacity_events = 0;// number of capacity growths so far (check_capacity)
+	long long books_bias = 0;// check_books: particles a loaded checkpoint's state lacked beyond this context's own lost / dropped counters
 	bool has_collision = false;// level-set collision object of the MGSP grid update
 	CollisionObject collision {};
 	float4* d_sdf = nullptr;
@@ -821,6 +822,32 @@ static void roll_partition(mpm_ctx* ctx) {
 	ctx->rollid ^= 1;
 }
 
+// The library checks its own books at every host synchronisation (the reference prints the particle total per frame and leaves the
+// reading to the user, gmpm_simulator.cuh:617): every particle that was added is either bucketed in a block of the partition just
+// built, or was counted as lost (left the domain / a block nobody registered, particle_buffer.cuh:105-113) or as dropped (overflow
+// policy).  The lost / dropped counters are per context, so the per-model statement is made when both are zero - the normal case -
+// and the totals are compared otherwise.  A failure is a bug of the engine (round 4's windowed group loop skipped a launch and lost
+// the particles of a few blocks with nothing counted as lost), never of the caller: MPM_ERR_INTERNAL.
+static int check_books(mpm_ctx* ctx) {
+	// (books_bias: what a loaded checkpoint's state was missing beyond this context's own counters - zero otherwise)
+	const long long gone = (long long) ctx->h_status[ST_LOST] + (long long) ctx->h_status[ST_DROPPED] + ctx->books_bias;
+	long long added = 0, held = 0;
+	for(size_t mi = 0; mi < ctx->models.size(); ++mi) {
+		const Model& m = ctx->models[mi];
+		added += (long long) m.n;
+		held += (long long) m.bucketed;
+		if(gone == 0 && (long long) m.bucketed != (long long) m.n)
+			return fail(ctx, MPM_ERR_INTERNAL,
+						"particle books of model " + std::to_string(mi) + " do not balance: " + std::to_string(m.bucketed) + " bucketed of " + std::to_string(m.n) +
+							" added, none counted as lost or dropped");
+	}
+	if(held + gone != added)
+		return fail(ctx, MPM_ERR_INTERNAL,
+					"particle books do not balance: " + std::to_string(held) + " bucketed + " + std::to_string(ctx->h_status[ST_LOST]) + " lost + " + std::to_string(ctx->h_status[ST_DROPPED]) +
+						" dropped != " + std::to_string(added) + " added");
+	return MPM_OK;
+}
+
 // Host synchronisation after one or more enqueued substeps (every one already rolled on the host): read the status block,
 // report what went wrong in the meantime (flags are sticky), take over the counts, grow capacities.
 static int apply_status(mpm_ctx* ctx, mpm_counts* counts);
@@ -846,6 +873,8 @@ static int apply_status(mpm_ctx* ctx, mpm_counts* counts) {
 		if((size_t) m.bincount > m.bin_cap) return fail(ctx, MPM_ERR_CAPACITY, "bin capacity exceeded");
 	}
 	if(ctx->h_status[ST_NONFINITE]) return fail(ctx, MPM_ERR_NONFINITE, "Maximum velocity is infinity");// gmpm_simulator.cuh:355-358
+	rc = check_books(ctx);
+	if(rc) return rc;
 	rc = grow_capacity(ctx);
 	if(rc) return rc;
 	if(counts) return mpm_get_counts(ctx, counts);
@@ -938,7 +967,8 @@ int mpm_run_fixed(mpm_ctx* ctx, int nsteps, float dt) {
 		// Capacities grow only at a synchronisation (by 3/2 per look, at 3/4 fill): a context whose blocks fill more than 7/10 of the capacity
 		// (set-up sizes it to 2/3) looks after EVERY substep - what the reference's check_capacity does (gmpm_simulator.cuh:283-300) -,
 		// so that a burst of new blocks cannot outrun the growth inside a window
-		const bool tight = ctx->cfg.grow && (long long) ctx->ebc * 10 > (long long) ctx->g.cap * 7;
+		const bool tight = ctx->cfg.grow && (long long) ctx->ebc * 10 > (long long) ctx->g.cap * 7 &&
+						   (size_t) ctx->g.cap < (size_t) ctx->g.G * ctx->g.G * ctx->g.G;// (a capacity that has reached the table size cannot grow: nothing to look for)
 		if(in_window == K || it + 1 == nsteps || tight) {
 			HIP_TRY(hipGetLastError());
 			rc = sync_counts(ctx, nullptr);// (one read-back: status, halo counters, max |v|^2 slots)
@@ -970,8 +1000,12 @@ int mpm_run_fixed(mpm_ctx* ctx, int nsteps, float dt) {
 	return MPM_OK;
 }
 
+int mpm_state_kind(void) {
+	return MPM_STATE_B;
+}
+
 const char* mpm_build_info(void) {
-	return "claymore_hip abi5 state=b"
+	return "claymore_hip abi6 state=b"
 #ifdef MPM_EXPERIMENT
 		   " experiment=MPM_EXPERIMENT"
 #ifdef MPM_HACK_EDGEWIN

@@ -38,7 +38,9 @@ typedef enum mpm_status {
 	MPM_ERR_DEVICE	   = 2, /* HIP runtime error (reference: check_cuda_errors -> exit) */
 	MPM_ERR_CAPACITY   = 3, /* block / bin / cell capacity exceeded (reference: std::abort) */
 	MPM_ERR_NONFINITE  = 4, /* inf/NaN grid velocity (reference: stops main loop, gmpm_simulator.cuh:355-358) */
-	MPM_ERR_NOT_READY  = 5
+	MPM_ERR_NOT_READY  = 5,
+	MPM_ERR_INTERNAL   = 6 /* the library's own books do not balance: particles bucketed + lost + dropped != particles added (the reference
+							  only prints the total per frame, gmpm_simulator.cuh:617); the message names the model */
 } mpm_status;
 
 /* Projects/GMPM/settings.h:20-26 */
@@ -158,6 +160,12 @@ int mpm_retrieve_positions(mpm_ctx* ctx, int model, float* xyz, size_t* n);
  * (claymore_amd/csrc/mpm_device_math.hpp); a negative state9[9*i] marks a reflected F (det F < 0, |.| is b00) -, or J in
  * state9[9*i] for J_FLUID; logjp may be NULL.  The reference itself retrieves positions only (mgmpm_kernels.cuh:1087-1122). */
 int mpm_retrieve_state(mpm_ctx* ctx, int model, float* xyz, float* state9, float* logjp, size_t* n);
+/* What state9 of mpm_retrieve_state holds for the solid models.  Until ABI 4 this library returned the deformation gradient F there
+ * (what the CPU oracle's mpmo_retrieve_state still returns); since ABI 5 it returns b = F F^T, from which F cannot be recovered (the
+ * rotation part of F never reaches an output of this path).  A caller written against the older meaning asks here instead of guessing;
+ * mpm_build_info() carries the same fact as "state=b" and the ABI number. */
+enum { MPM_STATE_F = 0, MPM_STATE_B = 1 };
+int mpm_state_kind(void);
 
 int mpm_get_counts(mpm_ctx* ctx, mpm_counts* counts);
 

@@ -114,7 +114,8 @@ int mpmo_set_exact_svd(int on) {
 	return MPM_OK;
 }
 
-/* oracle-only: OpenMP threads for G2P2G (bench.py cpu_baseline); 1 restores the deterministic serial order */
+/* oracle-only: OpenMP threads for G2P2G, the grid update and the order-independent loops of the rebuild (bench.py cpu_baseline); 1 restores
+ * the deterministic serial order */
 int mpmo_set_threads(mpmo_ctx* c, int n) {
 	if(!c || n < 1) return MPM_ERR_INVALID;
 	c->threads = n;
@@ -263,8 +264,21 @@ static inline int part_insert(mpmo_ctx* c, orc_partition* p, int x, int y, int z
 	p->keys[3 * idx + 2] = z;
 	return idx;
 }
+/* bench.py's multi-core cpu_baseline (mpmo_set_threads(n > 1)): besides G2P2G the loops below run on the OpenMP threads too - those whose
+ * iterations are independent and whose result does not depend on the order they run in (fills, per-block copies, a max).  The serial
+ * inserts that define the block numbering (register_*_blocks, update_partition) stay serial.  With one thread nothing changes. */
+#define ORC_PAR _Pragma("omp parallel for schedule(static) num_threads(c->threads > 1 ? c->threads : 1) if(c->threads > 1)")
+static void par_fill(const mpmo_ctx* c, void* dst, int byte, size_t bytes) {
+	const size_t chunk = (size_t) 1 << 22;
+	const long long nchunks = (long long) ((bytes + chunk - 1) / chunk);
+	ORC_PAR
+	for(long long i = 0; i < nchunks; ++i) {
+		const size_t off = (size_t) i * chunk;
+		memset((char*) dst + off, byte, bytes - off < chunk ? bytes - off : chunk);
+	}
+}
 static void part_reset_table(mpmo_ctx* c, orc_partition* p) {
-	memset(p->index_table, 0xff, sizeof(int) * (size_t) c->G * c->G * c->G);
+	par_fill(c, p->index_table, 0xff, sizeof(int) * (size_t) c->G * c->G * c->G);
 }
 
 static inline float* grid_block(float* grid, int blockno) {
@@ -275,13 +289,14 @@ static inline float* bin_ptr(const orc_model* m, const orc_pbuf* b, int binno) {
 }
 
 /* mgmpm_kernels.cuh:106-115 clear_grid */
-static void clear_grid(float* grid, int nblocks) {
-	memset(grid, 0, sizeof(float) * 256 * (size_t) nblocks);
+static void clear_grid(const mpmo_ctx* c, float* grid, int nblocks) {
+	par_fill(c, grid, 0, sizeof(float) * 256 * (size_t) nblocks);
 }
 
 /* mgmpm_kernels.cuh:70-84 cell_bucket_to_block: round k takes the k-th particle of every cell, cells ascending */
 static void cell_bucket_to_block(mpmo_ctx* c, orc_pbuf* b, int nblocks) {
 	const int mp = c->cfg.max_ppc;
+	ORC_PAR
 	for(int blk = 0; blk < nblocks; ++blk) {
 		const int* counts = b->cell_counts + (size_t) blk * ORC_BLOCKVOL;
 		int* out		  = b->blockbuckets + (size_t) blk * c->ppb;
@@ -470,7 +485,7 @@ int mpmo_initial_setup(mpmo_ctx* c) {
 		memcpy(m->buf[n].bucket_sizes, m->buf[r].bucket_sizes, sizeof(int) * (size_t) c->pbc);
 	}
 	/* rasterize, mgmpm_kernels.cuh:153-219, and init_adv_bucket :96-104 */
-	clear_grid(c->grid[0], c->nbc);
+	clear_grid(c, c->grid[0], c->nbc);
 	for(int mi = 0; mi < c->nmodels; ++mi) {
 		orc_model* m = &c->models[mi];
 		for(size_t i = 0; i < m->n; ++i) {
@@ -682,6 +697,7 @@ int mpmo_grid_update(mpmo_ctx* c, float dt, float* max_vel_sqr) {
 	const orc_partition* P	= &c->part[c->rollid];
 	const int bc			= c->cfg.boundary_blocks;
 	float maxv				= 0.f;
+#pragma omp parallel for schedule(static) reduction(max : maxv) num_threads(c->threads > 1 ? c->threads : 1) if(c->threads > 1)
 	for(int b = 0; b < c->nbc; ++b) {
 		const int* key = P->keys + 3 * b;
 		const int wx   = key[0] < bc || key[0] >= c->G - bc;
@@ -886,10 +902,10 @@ int mpmo_g2p2g(mpmo_ctx* c, float dt, float next_dt) {
 	if(!c || !c->ready) return MPM_ERR_NOT_READY;
 	double t0	= now_ms();
 	const int n = c->rollid ^ 1;
-	clear_grid(c->grid[1], c->nbc); /* gmpm_simulator.cuh:383 */
+	clear_grid(c, c->grid[1], c->nbc); /* gmpm_simulator.cuh:383 */
 	for(int mi = 0; mi < c->nmodels; ++mi) {
 		orc_model* m = &c->models[mi];
-		memset(m->buf[n].cell_counts, 0, sizeof(int) * (size_t) c->ebc * ORC_BLOCKVOL); /* :389 */
+		par_fill(c, m->buf[n].cell_counts, 0, sizeof(int) * (size_t) c->ebc * ORC_BLOCKVOL); /* :389 */
 		if((size_t) m->bincount > m->buf[n].bin_cap) return fail(c, MPM_ERR_CAPACITY, "bin capacity");
 		g2p2g_model(c, m, dt, next_dt, NULL, 0);
 	}
@@ -957,7 +973,7 @@ int mpmo_halo_tag_end(mpmo_ctx* c, int* halo_particle_blocks, int* send_counts) 
 int mpmo_g2p2g_halo(mpmo_ctx* c, float dt, float next_dt) {
 	if(!c || !c->ready || !c->halo_tagged) return MPM_ERR_NOT_READY;
 	const int n = c->rollid ^ 1;
-	clear_grid(c->grid[1], c->nbc);
+	clear_grid(c, c->grid[1], c->nbc);
 	for(int mi = 0; mi < c->nmodels; ++mi) {
 		orc_model* m = &c->models[mi];
 		memset(m->buf[n].cell_counts, 0, sizeof(int) * (size_t) c->ebc * ORC_BLOCKVOL);
@@ -1010,6 +1026,7 @@ int mpmo_rebuild_partition(mpmo_ctx* c, mpm_counts* counts) {
 	}
 	/* mark_active_grid_blocks (mgmpm_kernels.cuh:939-952) */
 	memset(c->marks, 0, sizeof(int) * (size_t) nbc);
+	ORC_PAR
 	for(int b = 0; b < nbc; ++b) {
 		const float* g = grid_block(c->grid[1], b);
 		for(int cell = 0; cell < 64; ++cell)
@@ -1054,6 +1071,7 @@ int mpmo_rebuild_partition(mpmo_ctx* c, mpm_counts* counts) {
 		orc_model* m	   = &c->models[mi];
 		const orc_pbuf* bn = &m->buf[n];
 		orc_pbuf* br	   = &m->buf[r];
+		ORC_PAR
 		for(int b = 0; b < new_pbc; ++b) {
 			const int s			= c->sources[b];
 			const int cnt		= bn->bucket_sizes[s];
@@ -1069,7 +1087,8 @@ int mpmo_rebuild_partition(mpmo_ctx* c, mpm_counts* counts) {
 	const int new_nbc = Pn->count;
 	if((size_t) new_nbc > c->cap) return fail(c, MPM_ERR_CAPACITY, "Too much neighbour blocks");
 	/* clear grid[0], copy_selected_grid_blocks (:536-541, kernel mgmpm_kernels.cuh:1002-1020) */
-	clear_grid(c->grid[0], ebc > new_nbc ? ebc : new_nbc);
+	clear_grid(c, c->grid[0], ebc > new_nbc ? ebc : new_nbc);
+	ORC_PAR
 	for(int b = 0; b < nbc; ++b) {
 		if(!c->marks[b]) continue;
 		const int bno = part_query(c, Pn, Pr->keys[3 * b], Pr->keys[3 * b + 1], Pr->keys[3 * b + 2]);
@@ -1145,6 +1164,11 @@ int mpmo_run_fixed(mpmo_ctx* c, int nsteps, float dt) {
 		if(rc) return rc;
 	}
 	return MPM_OK;
+}
+
+/* the oracle carries the reference's F (particle_buffer.cuh:141-264); the HIP library answers MPM_STATE_B */
+int mpmo_state_kind(void) {
+	return 0;
 }
 
 /* retrieve_particle_buffer, mgmpm_kernels.cuh:1087-1122 (+ state for the parity tests) */

@@ -75,6 +75,15 @@ def test_shipped_library_has_no_experiment_switch():
     assert not [f for f in ge.HIP_FLAGS if "MPM_" in f]
 
 
+def test_state_kind_says_what_retrieve_state_returns():
+    """mpm_retrieve_state kept its symbol when the solid models' state became b = F F^T (ABI 5): the library says so through
+    mpm_state_kind() and the ABI number in mpm_build_info(); the CPU oracle still carries the reference's F."""
+    from oracle_ffi import oracle_api
+    hip = _ffi.load_hip()
+    assert hip.state_kind() == 1 and " abi6 " in hip.build_info().decode() and "state=b" in hip.build_info().decode()
+    assert oracle_api().state_kind() == 0
+
+
 def test_experiment_switch_without_the_guard_does_not_compile():
     """A stray -DMPM_HACK_* (or any other experiment switch) without -DMPM_EXPERIMENT is a compile error (preprocessor only: fast)."""
     import subprocess
