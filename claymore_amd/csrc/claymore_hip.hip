@@ -1014,6 +1014,9 @@ const char* mpm_build_info(void) {
 #ifdef MPM_HACK_NOSHELL
 		   ",MPM_HACK_NOSHELL"
 #endif
+#ifdef MPM_HACK_STALE_INTERIOR
+		   ",MPM_HACK_STALE_INTERIOR"
+#endif
 #ifdef MPM_HACK_NOSERIAL
 		   ",MPM_HACK_NOSERIAL"
 #endif

@@ -631,6 +631,41 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 			pk[d]		   = min(max(((narena[d] - 1) & 3) + step, 0), 5);
 		}
 		if constexpr(kPreSites == 3) chain.template at<0>();
+#if !(defined(MPM_EXPERIMENT) && defined(MPM_NO_FASTSTAY))// round 5: a wave whose particles all stay in this block skips the look-up of the destination block and the ballot arithmetic (-1.1 % at rest, -1.9 % on C2: profiles/r04_ab_faststay.txt); MPM_NO_FASTSTAY: the general path only (A/B)
+		int ntag, dno, stay_leader, stay_rank;
+		bool stay;
+		int raw_stay = 0, raw_move = 0;
+		int b_opaque = b;
+		__asm__("" : "+v"(b_opaque));
+		if(__all((dirv[0] | dirv[1] | dirv[2]) == 0)) {
+			ntag		= kStay;
+			dno			= active ? b : -1;
+			stay		= active;
+			stay_leader = 0;
+			stay_rank	= lane;// (the active lanes are the first lanes of the slice)
+			const int n_act = __popcll(__ballot(active));
+			if(lane == 0) raw_stay = atomicAdd(&mv.out_count[b_opaque], n_act);
+		} else {
+			const bool dir_ok = ((unsigned) (dirv[0] + 1) < 3u) & ((unsigned) (dirv[1] + 1) < 3u) & ((unsigned) (dirv[2] + 1) < 3u);
+			ntag			  = dir_ok ? (dirv[0] + 1) * 9 + (dirv[1] + 1) * 3 + dirv[2] + 1 : kStay;
+			const int dno_raw = __shfl(info, 27 + ntag);
+			dno				  = (active && dir_ok) ? dno_raw : -1;
+			stay			  = dno >= 0 && ntag == kStay;
+			const unsigned long long stay_m = __ballot(stay);
+			stay_leader						= stay_m ? __ffsll((long long) stay_m) - 1 : 0;
+			stay_rank						= (int) __builtin_amdgcn_mbcnt_hi((unsigned) (stay_m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) stay_m, 0u));
+			if(stay_m != 0ull && lane == stay_leader) raw_stay = atomicAdd(&mv.out_count[b_opaque], __popcll(stay_m));
+			if(dno >= 0 && !stay) raw_move = atomicAdd(&mv.out_count[dno], 1);
+			if(active) {
+				if(dno < 0) atomicAdd(&status[ST_LOST], 1);
+				if(!in_arena) atomicAdd(&status[ST_ARENA], 1);
+			}
+		}
+		if constexpr(kPreSites == 3) chain.template at<1>();
+		const int pkey = pk[1] * 36 + pk[0] * 6 + pk[2];
+		const int rec  = (ntag << tag_shift) | (pkey << key_shift) | pidib;
+		settled		   = settled && __all(!active || (stay && pkey == okey));
+#else
 		const bool dir_ok = ((unsigned) (dirv[0] + 1) < 3u) & ((unsigned) (dirv[1] + 1) < 3u) & ((unsigned) (dirv[2] + 1) < 3u);
 		const int ntag	  = dir_ok ? (dirv[0] + 1) * 9 + (dirv[1] + 1) * 3 + dirv[2] + 1 : kStay;
 		const int dno_raw = __shfl(info, 27 + ntag);
@@ -654,6 +689,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 			if(dno < 0) atomicAdd(&status[ST_LOST], 1);// reference: particle silently lost (particle_buffer.cuh:105-113)
 			if(!in_arena) atomicAdd(&status[ST_ARENA], 1);// (:877-885) contribution discarded
 		}
+#endif
 		if constexpr(kPreSites == 3) chain.template at<2>();
 		MPM_MARK("L_material");
 		// ---- material update, store to the destination bin (slot == pidib: consecutive records) (:470-663)

@@ -317,11 +317,12 @@ class MgspGroupRank:
     the block keys, tagging - runs inside the library with one host synchronisation per substep.  Python only carries
     the 128-byte RCCL unique id from rank 0 to the others (`bootstrap`: callable(bytes or None) -> bytes)."""
 
-    def __init__(self, scene, rank, world, device=0, bootstrap=None, local_group=None, prepartitioned=False):
+    def __init__(self, scene, rank, world, device=0, bootstrap=None, local_group=None, prepartitioned=False, api=None):
         """`scene` is the whole scene (cut here with partition_scene) or, with prepartitioned=True, this rank's share of a
-        static particle partition the caller made (any partition is valid: the halo is whatever blocks the shares touch)."""
+        static particle partition the caller made (any partition is valid: the halo is whatever blocks the shares touch).
+        `api`: another build of the HIP library bound with _ffi.bind(..., hip=True) (A/B tools, mutation tests); default: the shipped one."""
         self.rank, self.world = rank, world
-        self.api = _ffi.load_hip()
+        self.api = api if api is not None else _ffi.load_hip()
         local = scene if prepartitioned else partition_scene(scene, rank, world)
         self.n_local = scenes.total_particles(local)
         self.eng = build_engine(local, device=device, api=self.api)

@@ -6,7 +6,7 @@ served by the in-process double tests/rccl_double/rccl_double.cpp (MPM_RCCL_LIBR
 per run because the library loads its collective library once).  The union of the ranks' particles must follow the single-engine
 CPU oracle.  Prints "OK ..." on success.
 
-    MPM_RCCL_LIBRARY=/path/to/librccl_double.so python tests/rccl_double/run_group.py WORLD KIND   (KIND: fixed | substeps | adaptive | fixed-big | plate | plate-fall | resume | fail)
+    MPM_RCCL_LIBRARY=/path/to/librccl_double.so python tests/rccl_double/run_group.py WORLD KIND   (KIND: fixed | substeps | adaptive | fixed-big | fixed-tightpad | plate | plate-fall | plate-stale | resume | fail)
 
 KIND fail: rank 1 runs with a block capacity it outgrows after a few substeps (no growth): it must come back with MPM_ERR_CAPACITY, and so
 must EVERY other rank, in the same substep (its status word travels in row 0 of the key all-gather) - nobody may be left waiting in a
@@ -81,7 +81,17 @@ def run_failing_rank(world):
     print(f"OK world {world} fail: every rank returned MPM_ERR_CAPACITY ({[o[1] for o in outcome]})")
 
 
-def run_plate(world, fall=False):
+def variant_api():
+    """RUN_GROUP_LIBRARY: another build of the engine library (a mutant with an experiment switch) instead of the shipped one."""
+    path = os.environ.get("RUN_GROUP_LIBRARY")
+    if not path:
+        return None
+    import ctypes as C
+    from claymore_amd import _ffi
+    return _ffi.bind(C.CDLL(os.path.abspath(path), mode=os.RTLD_LOCAL | os.RTLD_NOW), "mpm_", hip=True)
+
+
+def run_plate(world, fall=False, stale=False):
     """A rank whose particle blocks are ALL halo blocks at first and all interior later: a plate of elastic material two cells above a body
     that belongs to the other rank (no contact, but the same grid blocks), thrown upwards.  The windowed loop launches a substep's G2P2G passes before the host has seen the
     counts of the tagging they run on; the interior pass must not be skipped because the host's count of interior blocks (one tagging
@@ -109,10 +119,13 @@ def run_plate(world, fall=False):
 
     log, errors, sims, start, final = [[] for _ in range(world)], [], [None] * world, [None] * world, [None] * world
     bar = threading.Barrier(world)
+    api = variant_api()
+    if stale:
+        assert api is not None and "MPM_HACK_STALE_INTERIOR" in api.build_info().decode(), "plate-stale needs RUN_GROUP_LIBRARY = a build with -DMPM_EXPERIMENT -DMPM_HACK_STALE_INTERIOR"
 
     def work(rank):
         try:
-            sim = sims[rank] = MgspGroupRank(locals_[rank], rank, world, device=0, bootstrap=bootstrap, prepartitioned=True)
+            sim = sims[rank] = MgspGroupRank(locals_[rank], rank, world, device=0, bootstrap=bootstrap, prepartitioned=True, api=api)
             sim.initial_setup()
             c0 = sim.eng.counts()
             start[rank] = (c0.particle_blocks, sim.n_halo_blocks)
@@ -132,6 +145,21 @@ def run_plate(world, fall=False):
     for t in threads:
         t.join(timeout=300)
     assert not any(t.is_alive() for t in threads), "a rank is stuck in a collective"
+    if stale:
+        # Round 4's bug put back (the interior pass skipped on a block count one tagging old): the plate's particles vanish with nothing counted
+        # as lost.  The library's own books must catch that - MPM_ERR_INTERNAL on the rank that lost them, and on its peer in the same
+        # substep (the status word of the key all-gather) - where round 4 needed bench.py's end-of-run self-check to notice.
+        from claymore_amd import _ffi
+        for s_ in sims:
+            if s_ is not None:
+                s_.close()
+        assert len(errors) == world, f"the books did not trip on every rank: {errors} / {[e[-1:] for e in log]}"
+        text = {r: e for r, e in errors}
+        assert all(f"mpm status {_ffi.MPM_ERR_INTERNAL}:" in e for e in text.values()), errors
+        assert "do not balance" in text[1] and "rank 1 reported" in text[0], errors
+        steps_done = 10 * len(log[1])
+        print(f"OK world {world} plate-stale: the stale-count mutant tripped the library's books after {steps_done}+ substeps: {text[1][:200]} | peer: {text[0][:160]}")
+        return
     assert not errors, errors
     n_local = [s.n_local for s in sims]
     for s in sims:
@@ -247,8 +275,8 @@ def main():
         return run_failing_rank(world)
     if kind == "resume":
         return run_resume(world)
-    if kind in ("plate", "plate-fall"):
-        return run_plate(world, fall=kind == "plate-fall")
+    if kind in ("plate", "plate-fall", "plate-stale"):
+        return run_plate(world, fall=kind == "plate-fall", stale=kind == "plate-stale")
     sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=0.5, speed=2.0, youngs=2e4)
     nsteps, dt = 60, 1e-4
     big = kind.endswith("-big")
