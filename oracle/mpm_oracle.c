@@ -691,6 +691,38 @@ static void col_detect_and_resolve(const mpmo_ctx* c, const int* block_id, const
 	for(int d = 0; d < 3; ++d) vel[d] += v_obj[d];
 }
 
+/* the cell arithmetic of update_grid_velocity_query_max (mgmpm_kernels.cuh:353-388; with a collision object the MGSP project's overload,
+ * Projects/MGSP/mgmpm_kernels.cuh:362-373): one function for the pipeline and for the statement-level pin tests/golden/g19_* */
+static inline float orc_grid_cell(const mpmo_ctx* col, const int* key, int cell, float* g, int wx, int wy, int wz, float gravity, float dt) {
+	const float mass = g[cell];
+	float vel_sqr	 = 0.f;
+	if(mass > 0.0f) {
+		const float mass_inv = 1.f / mass;
+		float v0 = g[64 + cell], v1 = g[128 + cell], v2 = g[192 + cell];
+		v0 = wx ? 0.0f : v0 * mass_inv;
+		v1 = wy ? 0.0f : v1 * mass_inv;
+		v1 += gravity * dt;
+		v2 = wz ? 0.0f : v2 * mass_inv;
+		if(col) { /* boundary overload, Projects/MGSP/mgmpm_kernels.cuh:362-373 */
+			float vel[3]		 = {v0, v1, v2};
+			const int cellid[3] = {(cell & 0x30) >> 4, (cell & 0xc) >> 2, cell & 0x3};
+			col_detect_and_resolve(col, key, cellid, col->col.time, vel);
+			v0 = vel[0];
+			v1 = vel[1];
+			v2 = vel[2];
+			vel_sqr = v0 * v0 + v1 * v1 + v2 * v2; /* vel.dot(vel), then added again below: the reference's 2 |v|^2 */
+		}
+		g[64 + cell]  = v0;
+		g[128 + cell] = v1;
+		g[192 + cell] = v2;
+		vel_sqr += v0 * v0;
+		vel_sqr += v1 * v1;
+		vel_sqr += v2 * v2;
+	}
+	if(isnan(vel_sqr)) vel_sqr = INFINITY;
+	return vel_sqr;
+}
+
 int mpmo_grid_update(mpmo_ctx* c, float dt, float* max_vel_sqr) {
 	if(!c || !c->ready) return MPM_ERR_NOT_READY;
 	double t0				= now_ms();
@@ -705,32 +737,7 @@ int mpmo_grid_update(mpmo_ctx* c, float dt, float* max_vel_sqr) {
 		const int wz   = key[2] < bc || key[2] >= c->G - bc;
 		float* g	   = grid_block(c->grid[0], b);
 		for(int cell = 0; cell < 64; ++cell) {
-			const float mass = g[cell];
-			float vel_sqr	 = 0.f;
-			if(mass > 0.0f) {
-				const float mass_inv = 1.f / mass;
-				float v0 = g[64 + cell], v1 = g[128 + cell], v2 = g[192 + cell];
-				v0 = wx ? 0.0f : v0 * mass_inv;
-				v1 = wy ? 0.0f : v1 * mass_inv;
-				v1 += c->cfg.gravity * dt;
-				v2 = wz ? 0.0f : v2 * mass_inv;
-				if(c->has_collision) { /* boundary overload, Projects/MGSP/mgmpm_kernels.cuh:362-373 */
-					float vel[3]		 = {v0, v1, v2};
-					const int cellid[3] = {(cell & 0x30) >> 4, (cell & 0xc) >> 2, cell & 0x3};
-					col_detect_and_resolve(c, key, cellid, c->col.time, vel);
-					v0 = vel[0];
-					v1 = vel[1];
-					v2 = vel[2];
-					vel_sqr = v0 * v0 + v1 * v1 + v2 * v2; /* vel.dot(vel), then added again below: the reference's 2 |v|^2 */
-				}
-				g[64 + cell]  = v0;
-				g[128 + cell] = v1;
-				g[192 + cell] = v2;
-				vel_sqr += v0 * v0;
-				vel_sqr += v1 * v1;
-				vel_sqr += v2 * v2;
-			}
-			if(isnan(vel_sqr)) vel_sqr = INFINITY;
+			const float vel_sqr = orc_grid_cell(c->has_collision ? c : NULL, key, cell, g, wx, wy, wz, c->cfg.gravity, dt);
 			if(vel_sqr > maxv) maxv = vel_sqr;
 		}
 	}
@@ -741,6 +748,124 @@ int mpmo_grid_update(mpmo_ctx* c, float dt, float* max_vel_sqr) {
 
 float mpmo_compute_dt(const mpmo_ctx* c, float max_vel, float cur_time, float next_time, float dt_default) {
 	return orc_compute_dt(max_vel, cur_time, next_time, dt_default, c->dx, c->cfg.cfl);
+}
+
+/* ---- the per-particle body of g2p2g, Projects/GMPM/mgmpm_kernels.cuh:774-905 (with the per-material bodies :470-663) ----
+ * One function for the pipeline (g2p2g_model) and for the statement-level pin: tests/golden/g16_* were produced by the reference's own
+ * statements of these lines, cut out of its kernel as text (tests/golden/gen/gen_golden_kernel.sh), one particle at a time. */
+typedef struct {
+	int base[3], arena[3]; /* base_index, its image in the 8^3 arena (:774-797) */
+	float vel[3], A[9], pos[3];
+	float J, F[9], log_jp; /* what the material body stores */
+	float stress[9];	   /* contrib as compute_stress / the J-fluid block leaves it */
+	float contrib[9];	   /* after :850 */
+	int adv_cell[3], dirtag; /* the arguments of add_advection (:863) */
+	int narena[3], discarded;
+	float local_pos[3];
+} orc_particle_out;
+static inline void orc_particle_body(int material, float dx, float dx_inv, float d_inv, float mass, float volume, float mu, float lambda, float bm, const mpm_material_params* prm, const float (*g2p)[8][8][8], float (*p2g)[8][8][8],
+									 const float* pos_in, float J, const float* Fold, float log_jp, float dt, float new_dt, orc_particle_out* o) {
+	float pos[3] = {pos_in[0], pos_in[1], pos_in[2]};
+	memset(o, 0, sizeof(*o));
+	o->discarded = 1;
+	/* stencil base, weights (:774-797) */
+	int base_index[3], arena[3];
+	float local_pos[3], dws[3][3];
+	for(int d = 0; d < 3; ++d) {
+		base_index[d] = orc_node_index(pos[d], dx_inv) - 1;
+		local_pos[d]  = pos[d] - base_index[d] * dx;
+		orc_bspline_weight(local_pos[d], dx_inv, dws[d]);
+		arena[d] = ((base_index[d] - 1) & 3) + 1;
+	}
+	/* G2P gather (:803-835) */
+	float vel[3] = {0.f, 0.f, 0.f};
+	float A[9]	 = {0};
+	for(int i = 0; i < 3; i++)
+		for(int j = 0; j < 3; j++)
+			for(int k = 0; k < 3; k++) {
+				const float xixp[3] = {(float) i * dx - local_pos[0], (float) j * dx - local_pos[1], (float) k * dx - local_pos[2]};
+				const float W		= dws[0][i] * dws[1][j] * dws[2][k];
+				const float vi[3]	= {g2p[0][arena[0] + i][arena[1] + j][arena[2] + k], g2p[1][arena[0] + i][arena[1] + j][arena[2] + k], g2p[2][arena[0] + i][arena[1] + j][arena[2] + k]};
+				vel[0] += W * vi[0];
+				vel[1] += W * vi[1];
+				vel[2] += W * vi[2];
+				A[0] += W * vi[0] * xixp[0];
+				A[1] += W * vi[1] * xixp[0];
+				A[2] += W * vi[2] * xixp[0];
+				A[3] += W * vi[0] * xixp[1];
+				A[4] += W * vi[1] * xixp[1];
+				A[5] += W * vi[2] * xixp[1];
+				A[6] += W * vi[0] * xixp[2];
+				A[7] += W * vi[1] * xixp[2];
+				A[8] += W * vi[2] * xixp[2];
+			}
+	/* advect (:838) */
+	for(int d = 0; d < 3; ++d) pos[d] += vel[d] * dt;
+	for(int d = 0; d < 3; ++d) {
+		o->base[d]	= base_index[d];
+		o->arena[d] = arena[d];
+		o->vel[d]	= vel[d];
+		o->pos[d]	= pos[d];
+	}
+	for(int d = 0; d < 9; ++d) o->A[d] = A[d];
+	/* material update (calculate_contribution_and_store_particle_data, :470-663) */
+	float contrib[9];
+	o->J	  = J;
+	o->log_jp = log_jp;
+	if(material == MPM_J_FLUID) {
+		o->J = orc_jfluid(J, A, dt, d_inv, volume, prm->bulk, prm->gamma, prm->viscosity, contrib);
+	} else {
+		float dws9[9], F[9];
+		for(int d = 0; d < 9; ++d) dws9[d] = A[d] * dt * d_inv + ((d & 0x3) != 0 ? 0.f : 1.f);
+		orc_matmul3(dws9, Fold, F);
+		if(material == MPM_FIXED_COROTATED) {
+			orc_stress_fixed_corotated(volume, mu, lambda, F, contrib);
+		} else if(material == MPM_SAND) {
+			orc_stress_sand(volume, mu, lambda, prm->cohesion, prm->beta, prm->yield_surface, prm->volume_correction, F, &log_jp, contrib);
+		} else {
+			orc_stress_nacc(volume, mu, lambda, bm, prm->xi, prm->beta, prm->msqr, prm->hardening_on, F, &log_jp, contrib);
+		}
+		for(int d = 0; d < 9; ++d) o->F[d] = F[d];
+		o->log_jp = log_jp;
+	}
+	for(int d = 0; d < 9; ++d) o->stress[d] = contrib[d];
+	/* :850 */
+	for(int d = 0; d < 9; ++d) contrib[d] = (A[d] * mass - contrib[d] * new_dt) * d_inv;
+	/* new base, re-bucket (:852-866) */
+	int new_base[3], narena[3], dirv[3];
+	for(int d = 0; d < 3; ++d) {
+		new_base[d]	 = orc_node_index(pos[d], dx_inv) - 1;
+		local_pos[d] = pos[d] - new_base[d] * dx;
+		dirv[d]		 = (base_index[d] - 1) / 4 - (new_base[d] - 1) / 4;
+	}
+	for(int d = 0; d < 3; ++d) o->adv_cell[d] = new_base[d] - 1;
+	o->dirtag = orc_dir_offset(dirv[0], dirv[1], dirv[2]);
+	for(int d = 0; d < 3; ++d) {
+		orc_bspline_weight(local_pos[d], dx_inv, dws[d]);
+		narena[d] = (((base_index[d] - 1) & 3) + 1) + (new_base[d] - base_index[d]);
+	}
+	for(int d = 0; d < 9; ++d) o->contrib[d] = contrib[d];
+	for(int d = 0; d < 3; ++d) {
+		o->narena[d]	= narena[d];
+		o->local_pos[d] = local_pos[d];
+	}
+	o->discarded = 0;
+	if(narena[0] < 0 || narena[1] < 0 || narena[2] < 0 || narena[0] + 2 >= 8 || narena[1] + 2 >= 8 || narena[2] + 2 >= 8) {
+		o->discarded = 1;
+		return; /* :877-885: particle's grid contribution is discarded */
+	}
+	/* P2G scatter (:887-905) */
+	for(int i = 0; i < 3; i++)
+		for(int j = 0; j < 3; j++)
+			for(int k = 0; k < 3; k++) {
+				const float xp[3] = {(float) i * dx - local_pos[0], (float) j * dx - local_pos[1], (float) k * dx - local_pos[2]};
+				const float W	  = dws[0][i] * dws[1][j] * dws[2][k];
+				const float wm	  = mass * W;
+				p2g[0][narena[0] + i][narena[1] + j][narena[2] + k] += wm;
+				p2g[1][narena[0] + i][narena[1] + j][narena[2] + k] += wm * vel[0] + (contrib[0] * xp[0] + contrib[3] * xp[1] + contrib[6] * xp[2]) * W;
+				p2g[2][narena[0] + i][narena[1] + j][narena[2] + k] += wm * vel[1] + (contrib[1] * xp[0] + contrib[4] * xp[1] + contrib[7] * xp[2]) * W;
+				p2g[3][narena[0] + i][narena[1] + j][narena[2] + k] += wm * vel[2] + (contrib[2] * xp[0] + contrib[5] * xp[1] + contrib[8] * xp[2]) * W;
+			}
 }
 
 /* ---- g2p2g, Projects/GMPM/mgmpm_kernels.cuh:665-937 ---- */
@@ -789,99 +914,29 @@ static void g2p2g_model(mpmo_ctx* c, orc_model* m, float dt, float new_dt, const
 			const int ss		   = source_pidib % ORC_BIN;
 			float pos[3]		   = {sbin[ss], sbin[ORC_BIN + ss], sbin[2 * ORC_BIN + ss]};
 			float J				   = (m->material == MPM_J_FLUID) ? sbin[3 * ORC_BIN + ss] : 0.f;
-			/* stencil base, weights (:774-797) */
-			int base_index[3], arena[3];
-			float local_pos[3], dws[3][3];
-			for(int d = 0; d < 3; ++d) {
-				base_index[d] = orc_node_index(pos[d], dx_inv) - 1;
-				local_pos[d]  = pos[d] - base_index[d] * dx;
-				orc_bspline_weight(local_pos[d], dx_inv, dws[d]);
-				arena[d] = ((base_index[d] - 1) & 3) + 1;
+			/* the particle's body (:774-905): orc_particle_body below, shared with the statement-level pin of tests/golden/g16_* */
+			float Fold[9] = {0};
+			float log_jp  = 0.f;
+			if(m->material != MPM_J_FLUID) {
+				for(int d = 0; d < 9; ++d) Fold[d] = sbin[(3 + d) * ORC_BIN + ss];
+				if(m->material != MPM_FIXED_COROTATED) log_jp = sbin[12 * ORC_BIN + ss];
 			}
-			/* G2P gather (:803-835) */
-			float vel[3] = {0.f, 0.f, 0.f};
-			float A[9]	 = {0};
-			for(int i = 0; i < 3; i++)
-				for(int j = 0; j < 3; j++)
-					for(int k = 0; k < 3; k++) {
-						const float xixp[3] = {(float) i * dx - local_pos[0], (float) j * dx - local_pos[1], (float) k * dx - local_pos[2]};
-						const float W		= dws[0][i] * dws[1][j] * dws[2][k];
-						const float vi[3]	= {g2p[0][arena[0] + i][arena[1] + j][arena[2] + k], g2p[1][arena[0] + i][arena[1] + j][arena[2] + k], g2p[2][arena[0] + i][arena[1] + j][arena[2] + k]};
-						vel[0] += W * vi[0];
-						vel[1] += W * vi[1];
-						vel[2] += W * vi[2];
-						A[0] += W * vi[0] * xixp[0];
-						A[1] += W * vi[1] * xixp[0];
-						A[2] += W * vi[2] * xixp[0];
-						A[3] += W * vi[0] * xixp[1];
-						A[4] += W * vi[1] * xixp[1];
-						A[5] += W * vi[2] * xixp[1];
-						A[6] += W * vi[0] * xixp[2];
-						A[7] += W * vi[1] * xixp[2];
-						A[8] += W * vi[2] * xixp[2];
-					}
-			/* advect (:838) */
-			for(int d = 0; d < 3; ++d) pos[d] += vel[d] * dt;
-			/* material update + store (calculate_contribution_and_store_particle_data, :470-663) */
-			float contrib[9];
+			orc_particle_out o;
+			orc_particle_body(m->material, dx, dx_inv, d_inv, m->mass, m->volume, m->mu, m->lambda, m->bm, &m->p, (const float(*)[8][8][8]) g2p, p2g, pos, J, Fold, log_jp, dt, new_dt, &o);
+			/* store (calculate_contribution_and_store_particle_data, :506-515, :533-548, :591-606) */
 			float* dbin	 = bin_ptr(m, dst, dst->bin_offsets[b] + pidib / ORC_BIN);
 			const int ds = pidib % ORC_BIN;
+			dbin[ds]			   = o.pos[0];
+			dbin[ORC_BIN + ds]	   = o.pos[1];
+			dbin[2 * ORC_BIN + ds] = o.pos[2];
 			if(m->material == MPM_J_FLUID) {
-				J					 = orc_jfluid(J, A, dt, d_inv, m->volume, m->p.bulk, m->p.gamma, m->p.viscosity, contrib);
-				dbin[ds]			 = pos[0];
-				dbin[ORC_BIN + ds]	 = pos[1];
-				dbin[2 * ORC_BIN + ds] = pos[2];
-				dbin[3 * ORC_BIN + ds] = J;
+				dbin[3 * ORC_BIN + ds] = o.J;
 			} else {
-				float dws9[9], Fold[9], F[9];
-				for(int d = 0; d < 9; ++d) dws9[d] = A[d] * dt * d_inv + ((d & 0x3) != 0 ? 0.f : 1.f);
-				for(int d = 0; d < 9; ++d) Fold[d] = sbin[(3 + d) * ORC_BIN + ss];
-				orc_matmul3(dws9, Fold, F);
-				float log_jp = 0.f;
-				if(m->material == MPM_FIXED_COROTATED) {
-					orc_stress_fixed_corotated(m->volume, m->mu, m->lambda, F, contrib);
-				} else if(m->material == MPM_SAND) {
-					log_jp = sbin[12 * ORC_BIN + ss];
-					orc_stress_sand(m->volume, m->mu, m->lambda, m->p.cohesion, m->p.beta, m->p.yield_surface, m->p.volume_correction, F, &log_jp, contrib);
-				} else {
-					log_jp = sbin[12 * ORC_BIN + ss];
-					orc_stress_nacc(m->volume, m->mu, m->lambda, m->bm, m->p.xi, m->p.beta, m->p.msqr, m->p.hardening_on, F, &log_jp, contrib);
-				}
-				dbin[ds]			   = pos[0];
-				dbin[ORC_BIN + ds]	   = pos[1];
-				dbin[2 * ORC_BIN + ds] = pos[2];
-				for(int d = 0; d < 9; ++d) dbin[(3 + d) * ORC_BIN + ds] = F[d];
-				if(m->nch == 13) dbin[12 * ORC_BIN + ds] = log_jp;
+				for(int d = 0; d < 9; ++d) dbin[(3 + d) * ORC_BIN + ds] = o.F[d];
+				if(m->nch == 13) dbin[12 * ORC_BIN + ds] = o.log_jp;
 			}
-			/* :850 */
-			for(int d = 0; d < 9; ++d) contrib[d] = (A[d] * m->mass - contrib[d] * new_dt) * d_inv;
-			/* new base, re-bucket (:852-866) */
-			int new_base[3], narena[3], dirv[3];
-			for(int d = 0; d < 3; ++d) {
-				new_base[d]	 = orc_node_index(pos[d], dx_inv) - 1;
-				local_pos[d] = pos[d] - new_base[d] * dx;
-				dirv[d]		 = (base_index[d] - 1) / 4 - (new_base[d] - 1) / 4;
-			}
-			add_advection(c, dst, cur, new_base[0] - 1, new_base[1] - 1, new_base[2] - 1, orc_dir_offset(dirv[0], dirv[1], dirv[2]), pidib);
-			for(int d = 0; d < 3; ++d) {
-				orc_bspline_weight(local_pos[d], dx_inv, dws[d]);
-				narena[d] = (((base_index[d] - 1) & 3) + 1) + (new_base[d] - base_index[d]);
-			}
-			if(narena[0] < 0 || narena[1] < 0 || narena[2] < 0 || narena[0] + 2 >= 8 || narena[1] + 2 >= 8 || narena[2] + 2 >= 8) {
-				continue; /* :877-885: particle's grid contribution is discarded */
-			}
-			/* P2G scatter (:887-905) */
-			for(int i = 0; i < 3; i++)
-				for(int j = 0; j < 3; j++)
-					for(int k = 0; k < 3; k++) {
-						const float xp[3] = {(float) i * dx - local_pos[0], (float) j * dx - local_pos[1], (float) k * dx - local_pos[2]};
-						const float W	  = dws[0][i] * dws[1][j] * dws[2][k];
-						const float wm	  = m->mass * W;
-						p2g[0][narena[0] + i][narena[1] + j][narena[2] + k] += wm;
-						p2g[1][narena[0] + i][narena[1] + j][narena[2] + k] += wm * vel[0] + (contrib[0] * xp[0] + contrib[3] * xp[1] + contrib[6] * xp[2]) * W;
-						p2g[2][narena[0] + i][narena[1] + j][narena[2] + k] += wm * vel[1] + (contrib[1] * xp[0] + contrib[4] * xp[1] + contrib[7] * xp[2]) * W;
-						p2g[3][narena[0] + i][narena[1] + j][narena[2] + k] += wm * vel[2] + (contrib[2] * xp[0] + contrib[5] * xp[1] + contrib[8] * xp[2]) * W;
-					}
+			/* re-bucket (:863) */
+			add_advection(c, dst, cur, o.adv_cell[0], o.adv_cell[1], o.adv_cell[2], o.dirtag, pidib);
 		}
 		/* arena -> next grid (:907-936) */
 		for(int lb = 0; lb < 8; ++lb) {
@@ -1384,6 +1439,47 @@ int mpmo_test_stress(int material, const mpm_material_params* p, const float* Fi
 		memcpy(out19 + 19 * i, F, sizeof(F));
 		memcpy(out19 + 19 * i + 9, PF, sizeof(PF));
 		out19[19 * i + 18] = lj;
+	}
+	return MPM_OK;
+}
+/* G19: rows (mass, mvx, mvy, mvz, is_in_bound bits x=4 y=2 z=1) -> (vx, vy, vz as the cell holds them afterwards, vel_sqr) */
+void mpmo_fn_grid_cells(const float* in5, size_t n, float gravity, float dt, float* out4) {
+	for(size_t i = 0; i < n; ++i) {
+		float g[256] = {0};
+		const int key[3] = {0, 0, 0};
+		for(int ch = 0; ch < 4; ++ch) g[64 * ch] = in5[5 * i + ch];
+		const int bound = (int) in5[5 * i + 4];
+		out4[4 * i + 3] = orc_grid_cell(NULL, key, 0, g, bound & 4, bound & 2, bound & 1, gravity, dt);
+		for(int d = 0; d < 3; ++d) out4[4 * i + d] = g[64 * (1 + d)];
+	}
+}
+/* G16-G18: one particle per row through the body of g2p2g on a given velocity arena (g2pbuffer[3][8][8][8]) and an empty scatter arena.
+ * rows_in: pos[3], F[9] (column-major), log_jp (13 floats); out_f (154 floats): vel[3] A[9] pos[3] | F[9] log_jp stress[9] | contrib[9]
+ * local_pos[3] | the 27 x {m, mvx, mvy, mvz} the particle left in the arena, stencil offsets row-major; out_i (14 ints): base[3] arena[3]
+ * add_advection cell[3] dirtag narena[3] discarded (narena = -99 when discarded) */
+int mpmo_fn_particle_step(int material, const mpm_material_params* p, int domain_bits, const float* arena, const float* rows_in, size_t n, float dt, float new_dt, float* out_f, int* out_i) {
+	if(!p || !arena || !rows_in || !out_f || !out_i || material < 1 || material > 3) return MPM_ERR_INVALID;
+	const float dx_inv = (float) (1 << domain_bits), dx = 1.f / dx_inv, d_inv = 4.f * dx_inv * dx_inv; /* settings.h:60-66 */
+	const float e = p->youngs_modulus, nu = p->poisson_ratio;
+	const float mass = p->volume * p->rho, lambda = e * nu / ((1 + nu) * (1 - 2 * nu)), mu = e / (2 * (1 + nu));
+	const float bm = 2.f / 3.f * (e / (2 * (1 + nu))) + (e * nu / ((1 + nu) * (1 - 2 * nu)));
+	for(size_t i = 0; i < n; ++i) {
+		float p2g[4][8][8][8];
+		memset(p2g, 0, sizeof(p2g));
+		const float* in = rows_in + 13 * i;
+		orc_particle_out o;
+		orc_particle_body(material, dx, dx_inv, d_inv, mass, p->volume, mu, lambda, bm, p, (const float(*)[8][8][8]) arena, p2g, in, 0.f, in + 3, in[12], dt, new_dt, &o);
+		float* f = out_f + 154 * i;
+		int* q	 = out_i + 14 * i;
+		memcpy(f, o.vel, 12), memcpy(f + 3, o.A, 36), memcpy(f + 12, o.pos, 12);
+		memcpy(f + 15, o.F, 36), f[24] = o.log_jp, memcpy(f + 25, o.stress, 36);
+		memcpy(f + 34, o.contrib, 36), memcpy(f + 43, o.local_pos, 12);
+		for(int s = 0; s < 27; ++s)
+			for(int ch = 0; ch < 4; ++ch) f[46 + 4 * s + ch] = o.discarded ? 0.f : p2g[ch][o.narena[0] + s / 9][o.narena[1] + (s / 3) % 3][o.narena[2] + s % 3];
+		memcpy(q, o.base, 12), memcpy(q + 3, o.arena, 12), memcpy(q + 6, o.adv_cell, 12);
+		q[9] = o.dirtag;
+		for(int d = 0; d < 3; ++d) q[10 + d] = o.discarded ? -99 : o.narena[d];
+		q[13] = o.discarded;
 	}
 	return MPM_OK;
 }

@@ -481,7 +481,7 @@ def rccl_double_library(tmp_path_factory):
 
 
 @pytest.mark.parametrize("world,kind", [(2, "fixed"), (3, "substeps"), (4, "fixed"), (2, "adaptive"), (3, "fixed-nodefer"), (4, "fixed-big"), (8, "fixed-big"), (4, "fixed-big-sync"), (8, "fixed-big-sync"), (2, "plate"), (2, "plate-fall"), (3, "resume"),
-                                        (2, "fixed-tightpad"), (3, "fixed-tightpad"), (3, "fixed-tightpad-nodefer"), (4, "fixed-big-tightpad")])
+                                        (2, "plate-tightpad"), (2, "plate-fall-tightpad"), (2, "plate-tightpad-nodefer"), (4, "fixed-big-tightpad")])
 def test_rccl_transport_with_several_ranks_through_the_rccl_double(world, kind, rccl_double_library):
     """The RCCL branch of the group driver with world > 1 (RCCL itself cannot host two ranks on one device, the box has one GPU):
     every rank a thread with its own context, mpm_group_create with a unique id, the grouped ncclSend / ncclRecv of the halo exchange,
@@ -498,6 +498,9 @@ def test_rccl_transport_with_several_ranks_through_the_rccl_double(world, kind, 
     if kind.endswith("-sync"):    # the double's other mode: every call synchronises the host (a mutant of the driver without the comm stream's wait for the
         env["RCCL_DOUBLE_SYNC"] = "1"   # collect kernel fails here at once, in the stream-ordered mode only sometimes: profiles/r04_double_mutants.txt)
         kind = kind[:-5]
+    if kind.endswith("-nodefer") and kind != "fixed-nodefer":
+        env["MPM_GROUP_DEFER"] = "0"
+        kind = kind[:-8]
     tight = "-tightpad" in kind
     if tight:
         # The key lists of the tagging all-gather travel WITHOUT slack (MPM_GROUP_PAD_TIGHT=1): every substep in which a rank's block count grows

@@ -330,3 +330,89 @@ def test_g14_detect_and_resolve_collision(collision_oracle):
             assert np.array_equal(vel != vin, w != vin)
             assert np.abs(vel - w).max() <= 4e-6 * max(1.0, np.abs(w).max()), (cf[:4], np.abs(vel - w).max())
     assert changed > 12 * m // 4
+
+
+# ---- G16-G19: the BODY of the reference's g2p2g kernel and of its grid update at statement level ----------------------------
+# tests/golden/gen/gen_golden_kernel.sh cuts the statements of Projects/GMPM/mgmpm_kernels.cuh:772-838 (stencil base, weights, gather,
+# advection), :518-663 (the FC / sand / NACC bodies: F <- (I + dt grad v) F, compute_stress, what they store), :845-905 (the contrib
+# line, the re-bucketing arguments, the arena test, the 27 x 4 scatter) and :353-388 (the grid update's cell arithmetic) out of the
+# reference AS TEXT and runs them between locals, one particle per row, on five velocity arenas.  The oracle's pipeline goes through
+# the SAME function (orc_particle_body / orc_grid_cell in oracle/mpm_oracle.c) that mpmo_fn_particle_step / mpmo_fn_grid_cells expose.
+def kernel_rows():
+    par = f32("g16_params.f32")
+    names = "bits vol mass mu lam cohesion beta_sand yield_surface volume_correction bm xi msqr hardening_on dt new_dt beta_nacc E nu rho".split()
+    P = dict(zip(names, [float(v) for v in par]))
+    arenas = f32("g16_arenas.f32").reshape(-1, 3 * 512)
+    rin = f32("g16_particle_in.f32").reshape(-1, 15)
+    return P, arenas, rin, f32("g16_particle_out.f32").reshape(-1, 154), i32("g16_particle_out.i32").reshape(-1, 14)
+
+
+def kernel_params(P, material):
+    api = oracle_api()
+    p = _ffi.MaterialParams()
+    assert api.default_material(material, int(P["bits"]), C.byref(p)) == 0
+    p.rho, p.volume, p.youngs_modulus, p.poisson_ratio = P["rho"], P["vol"], P["E"], P["nu"]
+    p.cohesion, p.yield_surface, p.volume_correction = P["cohesion"], P["yield_surface"], int(P["volume_correction"])
+    p.beta = P["beta_sand"] if material == _ffi.SAND else P["beta_nacc"]
+    p.xi, p.msqr, p.hardening_on = P["xi"], P["msqr"], int(P["hardening_on"])
+    return p
+
+
+def same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+@pytest.mark.parametrize("material", [_ffi.FIXED_COROTATED, _ffi.SAND, _ffi.NACC])
+def test_g16_g17_g18_kernel_body_against_the_references_own_statements(material):
+    api = oracle_api()
+    fn = api.raw.mpmo_fn_particle_step
+    fn.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    fn.restype = C.c_int
+    P, arenas, rin, want_f, want_i = kernel_rows()
+    p = kernel_params(P, material)
+    # the derived constants are the reference's (particle_buffer.cuh:155-162, :187-188, :255)
+    assert np.float32(P["vol"]) * np.float32(P["rho"]) == np.float32(P["mass"])
+    seen = dict(rows=0, crossed=0, discarded=0)
+    for a in range(arenas.shape[0]):
+        sel = (rin[:, 0] == material) & (rin[:, 1] == a)
+        rows = np.ascontiguousarray(rin[sel][:, 2:])
+        n = rows.shape[0]
+        assert n == 48
+        got_f, got_i = np.zeros((n, 154), np.float32), np.zeros((n, 14), np.int32)
+        assert fn(material, C.byref(p), int(P["bits"]), ptr(arenas[a]), ptr(rows), n, P["dt"], P["new_dt"], ptr(got_f), ptr(got_i)) == 0
+        wf, wi = want_f[sel], want_i[sel]
+        # every integer the body produces: stencil base, its image in the arena, the cell and direction tag handed to add_advection (:863),
+        # the new base in the arena, whether the contribution is discarded (:877-885)
+        assert np.array_equal(got_i, wi), (a, np.argwhere(got_i != wi)[:5])
+        # G16 gather / advect (:772-838): vel, A, the advected position - IEEE +, -, * only
+        assert same_bits(got_f[:, :15], wf[:, :15]), a
+        fin = np.isfinite(wf).all(axis=1)        # (the violent arenas drive a few sand / NACC rows to inf / nan - in the reference's statements too)
+        assert np.array_equal(np.isfinite(got_f).all(axis=1), fin), a
+        exact = material == _ffi.FIXED_COROTATED
+        if exact:    # (the FC body stores no log Jp: column 24 is whatever the row carried)
+            cols = np.r_[15:24, 25:154]
+            assert same_bits(got_f[:, cols], wf[:, cols]), a
+        else:        # sand / NACC go through logf / expf / sinhf: same libm here -> same bits in this image; the bound is G5 / G6's
+            scale = np.maximum(1e-30, np.abs(wf[fin]).max(axis=0, keepdims=True))
+            assert (np.abs(got_f[fin] - wf[fin]) / scale).max() <= 2e-6, a
+        seen["rows"] += n
+        seen["crossed"] += int((wi[:, 9] != 13).sum())
+        seen["discarded"] += int(wi[:, 13].sum())
+    # the set exercises what it claims to: particles that change block, particles thrown out of the arena
+    assert seen["rows"] == 240 and seen["crossed"] >= 20 and seen["discarded"] >= 8, seen
+
+
+def test_g19_grid_update_cell_arithmetic_bit_exact():
+    api = oracle_api()
+    fn = api.raw.mpmo_fn_grid_cells
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p]
+    fn.restype = None
+    P = kernel_rows()[0]
+    cells = f32("g19_gridcell_in.f32").reshape(-1, 5)
+    want = f32("g19_gridcell_out.f32").reshape(-1, 4)
+    got = np.zeros_like(want)
+    fn(ptr(np.ascontiguousarray(cells)), cells.shape[0], -9.8, P["dt"], ptr(got))
+    live = cells[:, 0] > 0                      # (a cell without mass is left alone: its velocity entries are whatever they were)
+    assert same_bits(got[live][:, :3], want[live][:, :3])
+    assert same_bits(got[:, 3], want[:, 3])     # |v|^2, +inf where the arithmetic produced a NaN (:380-383)
+    assert np.isinf(want[:, 3]).sum() >= 6 and (cells[:, 0] <= 0).sum() >= 100 and (cells[:, 4] > 0).sum() > 400

@@ -841,3 +841,109 @@ def test_failed_run_then_checkpoint_load_recovers():
     rel = np.abs(got[idx].astype(np.float64) - want).max(axis=1) / np.abs(want).max(axis=1)
     assert rel.max() < 2e-6, rel.max()
     eng.close()
+
+
+@pytest.mark.parametrize("material", [_ffi.FIXED_COROTATED, _ffi.SAND, _ffi.NACC])
+def test_one_particle_scenes_through_the_real_kernel_against_the_references_statements(material):
+    """G16-G18 on the GPU, through the PUBLIC C ABI and the real g2p2g_kernel (no test kernel): the golden rows whose particle is in the state
+    initial_setup leaves one in (F = I, the model's log Jp_0) are replayed as one-particle scenes - mpm_add_model at the row's position,
+    mpm_initial_setup, the row's velocity arena written into the eight grid blocks of the particle's node cube (mpm_halo_reduce adds blocks by
+    key into the current grid, whose momentum channels are exactly zero for a particle at rest), mpm_g2p2g(dt, new_dt), mpm_rebuild_partition -
+    and what comes out (mpm_retrieve_state: position, b, log Jp; mpm_dump_grid: every node) is compared with what the REFERENCE'S OWN
+    STATEMENTS of mgmpm_kernels.cuh:772-905 + :518-663 produced for that particle (tests/golden/gen/gen_golden_kernel.sh): position <= 1e-6
+    relative, state 2e-5, the 27 x {m, mv} node values 1e-5 of the stencil's largest, nothing anywhere else, a discarded particle
+    (:877-885) counted and absent from the grid, the particle bucketed in the block add_advection was given (:863)."""
+    import torch
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    par = np.fromfile(os.path.join(G, "g16_params.f32"), np.float32)
+    names = "bits vol mass mu lam cohesion beta_sand yield_surface volume_correction bm xi msqr hardening_on dt new_dt beta_nacc E nu rho".split()
+    P = dict(zip(names, [float(v) for v in par]))
+    bits = int(P["bits"])
+    dx = 1.0 / (1 << bits)
+    arenas = np.fromfile(os.path.join(G, "g16_arenas.f32"), np.float32).reshape(-1, 3, 8, 8, 8)
+    rin = np.fromfile(os.path.join(G, "g16_particle_in.f32"), np.float32).reshape(-1, 15)
+    wf = np.fromfile(os.path.join(G, "g16_particle_out.f32"), np.float32).reshape(-1, 154)
+    wi = np.fromfile(os.path.join(G, "g16_particle_out.i32"), np.int32).reshape(-1, 14)
+    eye = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1], np.float32)
+    lj0 = np.float32(-0.01 if material == _ffi.NACC else 0.0)
+    plain = (rin[:, 0] == material) & np.all(rin[:, 5:14] == eye, axis=1) & (rin[:, 14] == lj0)
+    rows = np.flatnonzero(plain)
+    assert rows.size >= 60, rows.size
+    prm = dict(rho=P["rho"], volume=P["vol"], youngs_modulus=P["E"], poisson_ratio=P["nu"])
+    if material == _ffi.SAND:
+        prm.update(cohesion=P["cohesion"], beta=P["beta_sand"], yield_surface=P["yield_surface"], volume_correction=int(P["volume_correction"]))
+    if material == _ffi.NACC:
+        prm.update(beta=P["beta_nacc"], xi=P["xi"], msqr=P["msqr"], hardening_on=int(P["hardening_on"]))
+    bad, seen = [], dict(crossed=0, discarded=0, arenas=set())
+    for r in rows:
+        a = int(rin[r, 1])
+        pos = rin[r, 2:5].astype(np.float32)
+        base, arena_c, adv_cell, dirtag, narena, disc = wi[r, 0:3], wi[r, 3:6], wi[r, 6:9], int(wi[r, 9]), wi[r, 10:13], int(wi[r, 13])
+        blk = (base - 1) >> 2
+        assert np.array_equal(((base - 1) & 3) + 1, arena_c)
+        sc = {"name": "one", "bits": bits, "dt": P["dt"], "config": {"max_ppc": 8}, "models": [{"material": material, "xyz": pos.reshape(1, 3), "v0": (0.0, 0.0, 0.0), "params": dict(prm)}]}
+        eng = build_engine(sc)
+        eng.initial_setup()
+        # the velocity arena -> the eight grid blocks of the node cube (channel 0, the mass, stays what the rasteriser left: G2P2G does not read it)
+        keys = np.zeros((8, 3), np.int32)
+        blocks = np.zeros((8, 4, 64), np.float32)
+        for lb in range(8):
+            ox, oy, oz = (lb >> 2) & 1, (lb >> 1) & 1, lb & 1
+            keys[lb] = blk + (ox, oy, oz)
+            blocks[lb, 1:4] = arenas[a][:, 4 * ox:4 * ox + 4, 4 * oy:4 * oy + 4, 4 * oz:4 * oz + 4].reshape(3, 64)
+        dk, db = torch.from_numpy(keys).cuda(), torch.from_numpy(blocks).cuda()
+        eng._check(eng.api.halo_reduce(eng.ctx, 0, C.c_void_p(dk.data_ptr()), C.c_void_p(db.data_ptr()), 8))
+        eng.g2p2g(P["dt"], P["new_dt"])
+        cnt = eng.rebuild_partition()
+        x, st, lj = eng.retrieve_state(0)
+        gk, gb = eng.dump_grid()
+        dg = eng.diagnostics()
+        eng.close()
+        tag = f"row {r} (arena {a}, dirtag {dirtag}, discarded {disc})"
+        want = wf[r]
+        # position (G16)
+        e = np.abs(x[0].astype(np.float64) - want[12:15]).max() / np.abs(want[12:15]).max()
+        if not e <= 1e-6:
+            bad.append((tag, "pos", e))
+        # state: b = F F^T of what the body stored, log Jp (G18)
+        F = want[15:24].astype(np.float64).reshape(3, 3).T
+        b = to_b(st, True)[0].reshape(3, 3)
+        if np.isfinite(F).all():
+            e = np.abs(b - F @ F.T).max() / max(1.0, np.abs(F @ F.T).max())
+            if not e <= 2e-5:
+                bad.append((tag, "b", e))
+            if material != _ffi.FIXED_COROTATED and not abs(float(lj[0]) - float(want[24])) <= 2e-6 + 1e-5 * abs(float(want[24])):
+                bad.append((tag, "logjp", float(lj[0]), float(want[24])))
+        # the block the particle is bucketed in (add_advection's cell, :863)
+        if cnt.particle_blocks != 1 or int(cnt.particles[0]) != 1:
+            bad.append((tag, "counts", cnt.particle_blocks, int(cnt.particles[0])))
+        # the grid (G17): the 27 nodes of the new stencil, nothing else
+        nodes = {}
+        for k, blkv in zip(gk, gb):
+            nz = np.flatnonzero(np.abs(blkv).sum(axis=0))
+            for cell in nz:
+                nodes[(4 * int(k[0]) + (cell >> 4), 4 * int(k[1]) + ((cell >> 2) & 3), 4 * int(k[2]) + (cell & 3))] = blkv[:, cell].astype(np.float64)
+        if disc:
+            if nodes or dg.discarded_p2g != 1:
+                bad.append((tag, "a discarded particle reached the grid / was not counted", len(nodes), int(dg.discarded_p2g)))
+        else:
+            stencil = want[46:154].astype(np.float64).reshape(27, 4)
+            if np.isfinite(stencil).all():
+                scale_m, scale_p = np.abs(stencil[:, 0]).max(), max(np.abs(stencil[:, 1:]).max(), 1e-30)
+                origin = 4 * blk + narena
+                for s in range(27):
+                    node = tuple(int(v) for v in origin + (s // 9, (s // 3) % 3, s % 3))
+                    got = nodes.pop(node, np.zeros(4))
+                    e = max(abs(got[0] - stencil[s, 0]) / scale_m, np.abs(got[1:] - stencil[s, 1:]).max() / scale_p)
+                    if not e <= 1e-5:
+                        bad.append((tag, "node", s, e))
+                        break
+                if nodes:
+                    bad.append((tag, "mass outside the stencil", list(nodes)[:3]))
+            if dg.discarded_p2g != 0 or dg.lost_particles != 0:
+                bad.append((tag, "counted as discarded / lost", int(dg.discarded_p2g), int(dg.lost_particles)))
+        seen["crossed"] += dirtag != 13
+        seen["discarded"] += disc
+        seen["arenas"].add(a)
+    assert not bad, (len(bad), bad[:12])
+    assert len(seen["arenas"]) == arenas.shape[0] and seen["crossed"] >= 4 and seen["discarded"] >= 2, seen
