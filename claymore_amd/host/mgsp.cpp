@@ -4,10 +4,13 @@
 // `model_dev[d]_frame[f].bgeo` (mgsp_benchmark.cuh:582-585).
 //
 // The reference's structure: one process, N devices, one worker thread per device (mgsp_benchmark.cuh:309-356).  Each
-// worker drives the library's MGSP loop (mpm_group_*, claymore_amd/csrc/mpm_group.inc): halo blocks travel with grouped
-// RCCL send / recv over xGMI where the reference uses cudaMemcpyPeerAsync (halo_buffer.cuh:54-59).
+// worker drives the library's MGSP loop (mpm_group_*, claymore_amd/csrc/mpm_group.inc).  Two transports for the halo blocks:
+//   peer (default here: one process owns all devices, as in the reference) - hipMemcpyPeerAsync between the devices with peer access
+//        enabled, the reference's own mechanism (cudaMemcpyPeerAsync, halo_buffer.cuh:54-59; Cuda.cu:120-127), RCCL not needed;
+//   rccl - grouped ncclSend / ncclRecv over xGMI, the transport of the one-process-per-GPU launch (bench.py).
+// --transport peer|rccl or MPM_GROUP_TRANSPORT selects.
 //
-//   mgsp [--devices N] [--scenario 2|3] [--bits B] [--frames F] [--fps R] [--same-device] [--out DIR]
+//   mgsp [--devices N] [--scenario 2|3] [--bits B] [--frames F] [--fps R] [--same-device] [--transport peer|rccl] [--out DIR]
 //        [--boundary PREFIX [--boundary-type sticky|slip|separate] [--friction MU]]
 // --boundary reads PREFIX_sdf.bin, PREFIX_grad_{0,1,2}.bin (N^3 floats each) like MgspBenchmark::init_boundary
 // (mgsp_benchmark.cuh:257-266, boundary_condition.cuh:292-321) and installs the collision object on every device.
@@ -54,6 +57,7 @@ int main(int argc, char** argv) {
 	int ndev = 2, scenario = 2, bits = 8, frames = 2, fps = 48;
 	bool same = false;
 	std::string out = ".", boundary, boundary_type = "sticky";
+	std::string transport = std::getenv("MPM_GROUP_TRANSPORT") ? std::getenv("MPM_GROUP_TRANSPORT") : "peer";
 	float friction = 0.3f;
 	for(int i = 1; i < argc; ++i) {
 		auto is = [&](const char* s) { return !std::strcmp(argv[i], s) && i + 1 < argc; };
@@ -63,10 +67,15 @@ int main(int argc, char** argv) {
 		else if(is("--frames")) frames = std::atoi(argv[++i]);
 		else if(is("--fps")) fps = std::atoi(argv[++i]);
 		else if(is("--out")) out = argv[++i];
+		else if(is("--transport")) transport = argv[++i];
 		else if(is("--boundary")) boundary = argv[++i];
 		else if(is("--boundary-type")) boundary_type = argv[++i];
 		else if(is("--friction")) friction = (float) std::atof(argv[++i]);
 		else if(!std::strcmp(argv[i], "--same-device")) same = true;
+	}
+	if(transport != "peer" && transport != "rccl") {
+		std::fprintf(stderr, "--transport must be peer or rccl\n");
+		return 1;
 	}
 	int ngpu = 0;
 	HIPCHK(hipGetDeviceCount(&ngpu));
@@ -138,11 +147,13 @@ int main(int argc, char** argv) {
 	}
 	// One worker thread per device, as the reference (mgsp_benchmark.cuh:309-356), each driving the library's MGSP loop
 	// (mpm_group_main_loop: halo-first G2P2G, grouped RCCL send / recv beside the interior G2P2G, all-gather of block keys,
-	// adaptive dt from the maximum velocity over all devices).  --same-device puts all contexts on GPU 0 over the in-process
-	// transport (functional runs on a single-GPU box).
+	// adaptive dt from the maximum velocity over all devices).  --same-device puts all contexts on GPU 0 (functional runs on a
+	// single-GPU box); RCCL cannot host two ranks on one device, so that always means the in-process transport.
 	std::vector<mpm_group*> groups(ndev, nullptr);
 	unsigned char ident[128] = {};
-	if(same) {
+	const bool local = same || transport == "peer";
+	std::printf("halo transport: %s\n", local ? (same ? "in-process (one device)" : "peer-direct (hipMemcpyPeerAsync)") : "rccl");
+	if(local) {
 		std::vector<mpm_ctx*> ctxs;
 		for(auto& D: devs) ctxs.push_back(D.ctx);
 		if(mpm_group_create_local(ctxs.data(), ndev, groups.data()) != MPM_OK) {
@@ -177,7 +188,7 @@ int main(int argc, char** argv) {
 	for(int d = 0; d < ndev; ++d)
 		workers.emplace_back([&, d] {
 			Dev& D = devs[d];
-			if(!same && mpm_group_create(D.ctx, d, ndev, ident, &groups[d]) != MPM_OK) {
+			if(!local && mpm_group_create(D.ctx, d, ndev, ident, &groups[d]) != MPM_OK) {
 				std::fprintf(stderr, "device %d: %s\n", d, mpm_last_error(D.ctx));
 				failed = 1;
 				return;

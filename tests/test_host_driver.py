@@ -198,18 +198,30 @@ def test_mgsp_executable_same_device(tmp_path):
 
 
 @pytest.mark.gpu
-def test_mgsp_executable_equals_oracle(tmp_path):
+@pytest.mark.parametrize("transport", ["in-process", "peer"])
+def test_mgsp_executable_equals_oracle(tmp_path, transport):
     """The `mgsp` executable (scenario 2 of Projects/MGSP/mgsp.cu:34-81: one lattice cube per device, MGSP gravity -4.9 and CFL 0.3,
     adaptive dt) against the single-rank CPU oracle driven through MgspBenchmark::main_loop on the union of the cubes: the frames the
-    executable writes must hold the oracle's particles within 1e-5 relative."""
+    executable writes must hold the oracle's particles within 1e-5 relative.  "peer": the peer-direct transport's code path
+    (MPM_GROUP_TRANSPORT=peer: hipMemcpyPeerAsync on the comm stream behind the peer's event, no host synchronisation - the reference's
+    cudaMemcpyPeerAsync, halo_buffer.cuh:54-59) with both contexts on the one GPU a test box has; between two devices the same code
+    runs with peer access enabled."""
     import __graft_entry__ as g
     from test_mgsp_gpu import _oracle_mgsp_main_loop
     from parity_util import match
     from claymore_amd import _ffi
     g.build_host()
     bits, frames, fps = 7, 2, 200
-    out = subprocess.check_output([os.path.join(HOST, "mgsp"), "--devices", "2", "--same-device", "--bits", str(bits), "--frames", str(frames),
-                                   "--fps", str(fps), "--out", str(tmp_path)], text=True)
+    env = dict(os.environ, MPM_GROUP_VERBOSE="1")
+    if transport == "peer":
+        env["MPM_GROUP_TRANSPORT"] = "peer"
+    else:
+        env.pop("MPM_GROUP_TRANSPORT", None)
+    run = subprocess.run([os.path.join(HOST, "mgsp"), "--devices", "2", "--same-device", "--bits", str(bits), "--frames", str(frames),
+                          "--fps", str(fps), "--out", str(tmp_path)], text=True, capture_output=True, env=env, timeout=600)
+    assert run.returncode == 0, run.stderr[-2000:]
+    out = run.stdout
+    assert ("peer-direct (hipMemcpyPeerAsync)" in run.stderr) == (transport == "peer"), run.stderr[-1000:]   # the library says which copies it issues
     steps_exe = int(out.strip().splitlines()[-1].split()[-2])
     n = 1 << bits
     dx = 1.0 / n

@@ -413,9 +413,11 @@ def test_full_size_c5_fluid_dam_8_ranks():
     assert abs(com[0] - com0[0]) < 2e-8 and abs(com[2] - com0[2]) < 2e-8
 
 
-@pytest.mark.parametrize("material", [_ffi.SAND, _ffi.FIXED_COROTATED])
-def test_cpp_group_equals_single_engine(material):
-    """N ranks against ONE rank of the same engine: the static particle partition changes block numbering, sort order and the
+@pytest.mark.parametrize("material,transport", [(_ffi.SAND, "in-process"), (_ffi.FIXED_COROTATED, "in-process"), (_ffi.SAND, "peer")])
+def test_cpp_group_equals_single_engine(material, transport, monkeypatch):
+    """("peer": the peer-direct transport's code path - hipMemcpyPeerAsync behind the peer's event on the comm stream, no host
+    synchronisation in the exchange or the key all-gather - with all contexts on the one GPU; MPM_GROUP_TRANSPORT is read when the group is made.)
+    N ranks against ONE rank of the same engine: the static particle partition changes block numbering, sort order and the
     order of the float additions on shared grid blocks, and nothing else - every per-particle decision (Jacobi sweeps included: the
     convergence mask is per lane) depends on the particle alone.  150 substeps of two colliding bodies, 2 and 3 ranks: positions within
     1e-6 relative of the single-engine run (measured 2-3e-7, i.e. float-atomic noise; tools/nrank_vs_one.py)."""
@@ -423,6 +425,10 @@ def test_cpp_group_equals_single_engine(material):
     if material == _ffi.SAND:
         for m in sc["models"]:
             m["params"] = {}
+    if transport == "peer":
+        monkeypatch.setenv("MPM_GROUP_TRANSPORT", "peer")
+    else:
+        monkeypatch.delenv("MPM_GROUP_TRANSPORT", raising=False)
     nsteps = 150
     one = run_engine(sc, nsteps, 1e-4)
     for world in (2, 3):

@@ -947,3 +947,70 @@ def test_one_particle_scenes_through_the_real_kernel_against_the_references_stat
         seen["arenas"].add(a)
     assert not bad, (len(bad), bad[:12])
     assert len(seen["arenas"]) == arenas.shape[0] and seen["crossed"] >= 4 and seen["discarded"] >= 2, seen
+
+
+def test_full_size_c3_parity_40m():
+    """C3 at size against the ORACLE (VERDICT r4 #4a; until now the 40 M-particle runs were property checks): the BASELINE column (128 x 306 x 128
+    cells of Drucker-Prager sand, 40 108 032 particles, 512^3) set down with its lowest layers inside the floor's wall zone and thrown at it at
+    0.4 m/s - the grid update zeroes their vertical velocity from the first substep, the bottom of the column is compressed and yields -,
+    8 substeps on both engines (the oracle with OpenMP over particle blocks), particles matched by the lattice site they started from:
+    positions within 1e-5 relative, b and log Jp within the test_parity bounds, block counts equal."""
+    bits = 9
+    sc = scenes.sand_column(bits, min_corner=(192, 7, 192))
+    v0 = -0.4
+    sc["models"][0]["v0"] = (0.0, v0, 0.0)
+    n = scenes.total_particles(sc)
+    assert n == 40108032
+    nsteps, dt = 8, 1e-4
+    hip = run_engine(sc, nsteps, dt)
+    xh, bh, lh = hip["state"][0]
+    oh = _lattice_order(xh - np.array([0.0, v0 * nsteps * dt, 0.0]), bits)
+    xh, bh, lh = xh[oh], to_b(bh, True)[oh], lh[oh]
+    ch = hip["counts"]
+    hc = (ch.particle_blocks, ch.neighbor_blocks, ch.exterior_blocks)
+    del hip, oh
+    api = oracle_api_threads(64)
+    ora = run_engine(sc, nsteps, dt, api=api)
+    xo, fo, lo = ora["state"][0]
+    assert xh.shape == xo.shape == (n, 3)
+    oo = _lattice_order(xo - np.array([0.0, v0 * nsteps * dt, 0.0]), bits)
+    xo, lo = xo[oo], lo[oo]
+    rel = np.abs(xh.astype(np.float64) - xo.astype(np.float64)).max(axis=1) / np.abs(xo).max(axis=1)
+    assert rel.max() < POS_TOL, rel.max()
+    bo = to_b(fo[oo], False)
+    assert np.abs(bh - bo).max() < 1e-4, np.abs(bh - bo).max()
+    assert np.abs(lh - lo).max() < 1e-5, np.abs(lh - lo).max()
+    assert np.abs(bo - np.eye(3).reshape(1, 9)).max() > 1e-3 and np.abs(lo).max() > 1e-5     # the floor really deformed the sand, and some of it yielded
+    co = ora["counts"]
+    assert hc == (co.particle_blocks, co.neighbor_blocks, co.exterior_blocks)
+
+
+def test_reflected_deformation_gradient_in_a_pipeline_scene():
+    """The reflection bit of the b-state (sign of b00: det F < 0) reached through the PIPELINE, not only by the function-level tests
+    (VERDICT r4, weak #3): two fixed-corotated blocks driven into each other at +-3 m/s with a substep 30 x beyond the CFL limit
+    (dt = 5e-3 on a 64^3 grid: dt grad v ~ 1.3 in the contact layer), so det(I + dt grad v) < 0 for the particles of that layer in the
+    first substep - 512 of 8 192 in the oracle, whose SVD then carries the sign in the smallest singular value (svd.cuh:590-770).  The HIP
+    engine must flag exactly those particles, keep them flagged, and still follow the oracle's positions."""
+    bits = 6
+    prm = {"volume": (1.0 / (1 << bits)) ** 3 / 8.0, "youngs_modulus": 5e3, "poisson_ratio": 0.4, "rho": 1e3}
+    V, dt = 3.0, 5e-3
+    sc = {"name": "clash", "bits": bits, "dt": dt, "config": {"max_ppc": 128, "gravity": 0.0},
+          "models": [{"material": _ffi.FIXED_COROTATED, "xyz": scenes.lattice_box(bits, (24, 28, 28), (32, 36, 36)), "v0": (V, 0, 0), "params": dict(prm)},
+                     {"material": _ffi.FIXED_COROTATED, "xyz": scenes.lattice_box(bits, (32, 28, 28), (40, 36, 36)), "v0": (-V, 0, 0), "params": dict(prm)}]}
+    for nsteps in (1, 3):
+        res = run_pair(sc, nsteps=nsteps, dt=dt)
+        flagged = reflected = 0
+        for (xh, sh, _), (xo, so, _) in zip(res["hip"]["state"], res["oracle"]["state"]):
+            from parity_util import match
+            idx, _ = match(xo.astype(np.float64), xh.astype(np.float64))
+            F = so.reshape(-1, 3, 3).transpose(0, 2, 1).astype(np.float64)
+            neg_o = np.linalg.det(F) < 0
+            neg_h = sh[idx][:, 0] < 0                     # the sign bit of b00
+            assert np.array_equal(neg_o, neg_h), (nsteps, int(neg_o.sum()), int(neg_h.sum()))
+            reflected += int(neg_o.sum())
+            flagged += int(neg_h.sum())
+            rel = np.abs(xh[idx].astype(np.float64) - xo).max(axis=1) / np.abs(xo).max(axis=1)
+            assert rel.max() < POS_TOL, (nsteps, rel.max())
+            b_o, b_h = to_b(so, False), to_b(sh[idx], True)
+            assert np.abs(b_h - b_o).max() / max(1.0, np.abs(b_o).max()) < 1e-4, (nsteps, np.abs(b_h - b_o).max())
+        assert reflected == flagged and reflected >= 256, (nsteps, reflected)
