@@ -1,0 +1,15 @@
+#!/usr/bin/env bash
+# round 5: [tests selected by $1] + smoke + the driver's bench line + the profile set (tools/gpu_profile_r05.sh all)
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+cat build_stamp.txt
+if [ -n "$1" ]; then
+  timeout 1500 python -m pytest tests -m gpu -q -k "$1" > gpurun_out/r05_select_pytest.log 2>&1; echo "pytest rc $?" >> gpurun_out/r05_select_pytest.log
+  grep -E "^(FAILED|ERROR)|passed|failed|pytest rc" gpurun_out/r05_select_pytest.log | tail -12
+fi
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r05_smoke.log 2>&1; tail -1 gpurun_out/r05_smoke.log
+timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r05_bench_default_line.json 2> gpurun_out/r05_bench.err; echo "bench rc $?"
+tail -c 300 gpurun_out/r05_bench_default_line.json
+bash tools/gpu_profile_r05.sh all > gpurun_out/r05_profile.log 2>&1
+tail -3 gpurun_out/r05_profile.log

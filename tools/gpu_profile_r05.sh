@@ -1,9 +1,9 @@
 #!/usr/bin/env bash
-# Round-4 profile set (run through gpurun): kernel traces + HBM / SQ counters of the C3 launch in the default (rest) window and in the
-# flow (--start-step 3000), FC (C2) trace.  Summaries land in gpurun_out/prof_r04/*.txt; tools/make_pmc_json.py turns them into profiles/r04_pmc.json.
+# Round-5 profile set (run through gpurun): kernel traces + HBM / SQ counters of the C3 launch in the default (rest) window and in the
+# flow (--start-step 3000), FC (C2) trace.  Summaries land in gpurun_out/prof_r05/*.txt; tools/make_pmc_json.py turns them into profiles/r05_pmc.json.
 cd "$(dirname "$0")/.."
 R=$PWD
-O=$R/gpurun_out/prof_r04
+O=$R/gpurun_out/prof_r05
 rm -rf $O; mkdir -p $O
 STAMP=$(cat $R/build_stamp.txt 2>/dev/null || echo "no build stamp: run tools/stamp.sh before gpurun")
 cd /tmp && export TMPDIR=/tmp
@@ -43,8 +43,14 @@ LAST=""
 if [ "$1" = "all" ]; then
   trace c2_fc --scene sphere5m
   pmc c2_fc "$SQA" --scene sphere5m --steps 3 --warmup 2
+  pmc c2_fc "$SQB" --scene sphere5m --steps 3 --warmup 2
   trace c5_fluid --scene fluid12m
+  # the J-fluid instantiation with the full set the sand kernel has (LDS bank conflicts, the wait split)
   pmc c5_fluid "$SQA" --scene fluid12m --steps 3 --warmup 2
+  pmc c5_fluid "$SQB" --scene fluid12m --steps 3 --warmup 2
+  pmc c5_fluid "$SQC" --scene fluid12m --steps 3 --warmup 2
+  pmc c5_fluid "FETCH_SIZE" --scene fluid12m --steps 3 --warmup 2
+  pmc c5_fluid "WRITE_SIZE" --scene fluid12m --steps 3 --warmup 2
   # the two multi-GPU configurations whole on ONE GPU (they fit: 288 GB): the per-particle rate of FC / the J-fluid without C2's launch tail
   trace c4_fc_one_gpu --scene spheres40m --steps 40 --warmup 10
   trace c5_fluid_one_gpu --scene fluid100m --steps 40 --warmup 10
