@@ -101,7 +101,7 @@ def cpu_baseline(args, scene=None):
     from oracle_ffi import oracle_api
     api = oracle_api()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(cores, 128))     # (the oracle's block loop stops scaling well before that on the hosts seen so far; `host_cores` says what was there)
+    threads = max(1, min(cores, 64))
 
     def timed(sc, nthreads, steps, warm=1):
         eng = build_engine(sc, api=api)
