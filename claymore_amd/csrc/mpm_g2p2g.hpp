@@ -602,7 +602,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 		constexpr int kSites	   = kPreSites + kStressSites + 2;
 		// (Round 5 tried a second claim round - a lane that loses in its own arena takes the other one if no first-round winner sits there: the losers
 		//  stay at 1.29 % of the particles of the C3 flow and the launch is 1.5 % slower - they are keys with three or more particles in one slice, cells
-		//  compressed beyond 2 S particles, for which two arenas are not enough; profiles/r05_ab_claim2_dynq.txt.  Also tried there: persistent workgroups that
+		//  compressed beyond 2 S particles, for which two arenas are not enough; profiles/r05_ab_not_kept.txt.  Also tried there: persistent workgroups that
 		//  pull further blocks from a per-XCD device counter - any data-dependent block loop makes the compiler spill 50-90 dwords in every instantiation.)
 		const int pv_key = (pv_in ? code_key(pv_code) : 0) + (lane & 1) * 216;// even / odd lanes: separate arenas, separate claims
 		if(pv_in) s_owner[pv_key] = (unsigned char) lane;
