@@ -487,7 +487,7 @@ def rccl_double_library(tmp_path_factory):
 
 
 @pytest.mark.parametrize("world,kind", [(2, "fixed"), (3, "substeps"), (4, "fixed"), (2, "adaptive"), (3, "fixed-nodefer"), (4, "fixed-big"), (8, "fixed-big"), (4, "fixed-big-sync"), (8, "fixed-big-sync"), (2, "plate"), (2, "plate-fall"), (3, "resume"),
-                                        (4, "fixed-big-tightpad"), (4, "fixed-big-tightpad-nodefer"), (8, "fixed-big-tightpad")])
+                                        (4, "fixed-big-tightpad"), (4, "fixed-big-tightpad-nodefer")])
 def test_rccl_transport_with_several_ranks_through_the_rccl_double(world, kind, rccl_double_library):
     """The RCCL branch of the group driver with world > 1 (RCCL itself cannot host two ranks on one device, the box has one GPU):
     every rank a thread with its own context, mpm_group_create with a unique id, the grouped ncclSend / ncclRecv of the halo exchange,
