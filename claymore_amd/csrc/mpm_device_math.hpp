@@ -14,7 +14,7 @@
 // tools/build_variant.sh without it); mpm_build_info() reports the switches a library was built with and tests/test_abi.py checks
 // that the shipped one has none.  A stray -DMPM_HACK_* without the guard does not compile.
 #if !defined(MPM_EXPERIMENT)
-#if defined(MPM_UNROLL2) || defined(MPM_NO_FASTSTAY) || defined(MPM_HACK_STALE_INTERIOR) || defined(MPM_HACK_EDGEWIN) || defined(MPM_HACK_NOSHELL) || defined(MPM_HACK_NOSERIAL) || defined(MPM_HACK_NOWB) || defined(MPM_HACK_UNDEF) || defined(MPM_SCALAR_GS) || defined(MPM_GATHER_B96) || \
+#if defined(MPM_NO_FASTSTAY) || defined(MPM_HACK_STALE_INTERIOR) || defined(MPM_HACK_EDGEWIN) || defined(MPM_HACK_NOSHELL) || defined(MPM_HACK_NOSERIAL) || defined(MPM_HACK_NOWB) || defined(MPM_HACK_UNDEF) || defined(MPM_SCALAR_GS) || defined(MPM_GATHER_B96) || \
 	defined(MPM_NT_LOADS) || defined(MPM_LDS_PAD) || defined(MPM_G2P2G_NOLOOP) || defined(MPM_G2P2G_STATS) || defined(MPM_PRE_SITES) || defined(MPM_SERIAL_QUEUE) ||        \
 	defined(MPM_G2P2G_WAVES) || defined(MPM_G2P2G_WAVES_FLUID) || defined(MPM_QUEUE_ENTRIES)
 #error "experiment switch without -DMPM_EXPERIMENT: a product library is built with none of them"

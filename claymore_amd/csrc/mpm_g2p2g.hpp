@@ -536,16 +536,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 #ifdef MPM_G2P2G_STATS
 	int st_iter = 0, st_losers = 0, st_edge = 0, st_retry_iters = 0, st_partial = 0;
 #endif
-#if defined(MPM_EXPERIMENT) && defined(MPM_UNROLL2)// experiment: the particle loop unrolled by two with two prefetch register sets (no loop-carried copies of the prefetched record)
-	int idx0 = 0;
-	Prefetch pf_b;
-	auto iteration = [&](Prefetch& pfc, Prefetch& pfn) -> bool {
-#define MPM_LOOP_BREAK return true
-#else
 	for(int idx0 = 0;; idx0 += 64) {
-		Prefetch &pfc = pf, &pfn = pf;
-#define MPM_LOOP_BREAK break
-#endif
 		// one pass more than there are iterations: the last one only drains the pipeline (scatter of the last payload)
 		const bool drain = idx0 >= size;
 		bool win		 = false;
@@ -562,24 +553,24 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 #endif
 		const int pidib	  = idx0 + lane;// slot in the destination bins == position in the sorted order
 		// ---- advection record -> source bin (:747-768): data was requested one iteration ago
-		float pos[3] = {pfc.q[0].x, pfc.q[0].y, pfc.q[0].z};
+		float pos[3] = {pf.q[0].x, pf.q[0].y, pf.q[0].z};
 		float st[7];// J, or b {00, 11, 22, 10, 20, 21} (+ log Jp)
-		st[0] = pfc.q[0].w;
+		st[0] = pf.q[0].w;
 		if constexpr(MAT != 0) {
-			st[1] = pfc.q[1].x;
-			st[2] = pfc.q[1].y;
-			st[3] = pfc.q[1].z;
-			st[4] = pfc.q[1].w;
-			st[5] = pfc.row[0];
-			if constexpr(ROW == 2) st[6] = pfc.row[1];
+			st[1] = pf.q[1].x;
+			st[2] = pf.q[1].y;
+			st[3] = pf.q[1].z;
+			st[4] = pf.q[1].w;
+			st[5] = pf.row[0];
+			if constexpr(ROW == 2) st[6] = pf.row[1];
 		}
-		const int okey	  = pfc.key;// the sort key this particle was processed under
+		const int okey	  = pf.key;// the sort key this particle was processed under
 		const int slot_nn = idx0 + 128 < size ? idx0 + 128 : 0;
 		const int cnt_nn  = idx0 + 128 < size ? slice_records_at(size, idx0 + 128) : 1;
 		const int rec_nn  = list[slot_nn + min(lane, cnt_nn - 1)];
 		// the next iteration's particle record is requested a whole iteration ahead: record loads of 64 scattered 64-B sectors
 		// take long to return, and at three waves per SIMD the 16 registers are there
-		fetch(rec_next, pfn);
+		fetch(rec_next, pf);
 		rec_next = rec_nn;
 		cnt_cur			   = cnt_next;
 		cnt_next		   = cnt_nn;
@@ -800,7 +791,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 					p2g_serial(p2g, left, pv_code, pv, mass, lane, info, next_grid);
 			}
 		}
-		if(drain) MPM_LOOP_BREAK;
+		if(drain) break;
 		MPM_MARK("L_handoff");
 		// ---- hand the payload to the next iteration (:887-905).  It is formed here, after the last reader of the previous
 		//      payload (chain, p2g_serial), so that it can be computed straight into the loop-carried registers (no copies).
@@ -816,19 +807,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_G2P2G_WAVES_FLUID : M
 			for(int d = 0; d < 9; ++d) pv.contrib[d] = fmaf(A[d], am, pl.contrib[d]);// (pl.contrib = -stress new_dt D^-1 dx: StressScale)
 		}
 		pv_code = ncode;
-#if defined(MPM_EXPERIMENT) && defined(MPM_UNROLL2)
-		return false;
-	};
-	for(;;) {
-		if(iteration(pf, pf_b)) break;
-		idx0 += 64;
-		if(iteration(pf_b, pf)) break;
-		idx0 += 64;
 	}
-#else
-	}
-#endif
-#undef MPM_LOOP_BREAK
 #ifdef MPM_G2P2G_STATS
 	if(lane == 0) {
 		atomicAdd(&status[24], st_iter);
