@@ -63,6 +63,7 @@ struct mpm_ctx {
 	int device = 0;
 	hipStream_t s_compute = nullptr, s_comm = nullptr;
 	hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_g0 = nullptr, ev_g1 = nullptr, ev_comm = nullptr, ev_halo = nullptr;
+	hipEvent_t ev_tag0 = nullptr, ev_tag1 = nullptr;// group loop: key list exported (compute -> comm) / tagging complete (comm -> compute); created on first use
 	// MGSP windowed loop: the status read-back of substep t is waited for AFTER the halo-first G2P2G of substep t + 1 has been enqueued,
 	// so the timing events exist twice (index = parity of the substep)
 	hipEvent_t ev_status = nullptr, ev2_a[2] = {nullptr, nullptr}, ev2_b[2] = {nullptr, nullptr}, ev2_g0[2] = {nullptr, nullptr}, ev2_g1[2] = {nullptr, nullptr};
@@ -343,6 +344,8 @@ void mpm_destroy(mpm_ctx* ctx) {
 	if(ctx->ev_g1) hipEventDestroy(ctx->ev_g1);
 	if(ctx->ev_comm) hipEventDestroy(ctx->ev_comm);
 	if(ctx->ev_halo) hipEventDestroy(ctx->ev_halo);
+	if(ctx->ev_tag0) hipEventDestroy(ctx->ev_tag0);
+	if(ctx->ev_tag1) hipEventDestroy(ctx->ev_tag1);
 	if(ctx->ev_status) hipEventDestroy(ctx->ev_status);
 	for(int i = 0; i < 2; ++i)
 		for(hipEvent_t e: {ctx->ev2_a[i], ctx->ev2_b[i], ctx->ev2_g0[i], ctx->ev2_g1[i]})
@@ -727,7 +730,15 @@ static int launch_prepare(mpm_ctx* ctx, int cur, int prev, bool list_is_out, int
 // partition rebuild, gmpm_simulator.cuh:415-579 (launches only: no host round trip, no runtime fill / copy commands; launch sizes
 // from the host's estimates of the block counts, true counts from the status block)
 // fuse_dt > 0: the carry-over applies the grid update of the next substep (dt = fuse_dt) as well
-static int launch_rebuild(mpm_ctx* ctx, float fuse_dt = 0.f) {
+// without_prepare: everything but the last kernel (prepare_blocks_kernel: list sort, look-up rows, publication of the exterior block count), which
+// launch_rebuild_prepare issues - the group loop puts the tagging's key export in between, so that the key all-gather and the tagging kernels
+// run on the comm stream beside it
+static int launch_rebuild_prepare(mpm_ctx* ctx) {
+	const int r = ctx->rollid, n = r ^ 1;
+	const int ebc_est = std::min(ctx->g.cap, ctx->ebc + ctx->ebc / 16 + 1024);
+	return launch_prepare(ctx, n, r, true, n, &ctx->d_status[ST_CNT_P], ebc_est, true, true);
+}
+static int launch_rebuild(mpm_ctx* ctx, float fuse_dt = 0.f, bool without_prepare = false) {
 	if(fuse_dt == 0.f) fuse_dt = ctx->fuse_dt_once;
 	ctx->fuse_dt_once = 0.f;
 	hipStream_t s = ctx->s_compute;
@@ -762,6 +773,7 @@ static int launch_rebuild(mpm_ctx* ctx, float fuse_dt = 0.f) {
 	register_blocks_kernel<-1, 1><<<rg32, 256, 0, s>>>(g, &st[ST_CNT_P], &st[ST_CNT_N], &st[ST_CNT_E], &st[ST_NBC], Pn.table, Pn.keys, st);
 	// the next G2P2G runs in the new numbering n with the particle data laid out in r: sort its lists (the ones the last
 	// G2P2G appended to), look up its blocks' neighbours; this last kernel also publishes the exterior block count
+	if(without_prepare) return MPM_OK;
 	return launch_prepare(ctx, n, r, true, n, &st[ST_CNT_P], ebc_est, true, true);
 }
 
