@@ -157,6 +157,42 @@ def loaded_library_sha16():
     return h.hexdigest()[:16]
 
 
+def attach_counters(dst, pmc, pmc_name, window, lib_sha, kernel_ms, n_rank, bpp):
+    """Counter fields of one window (`rest` / `flow`) of the profiled kernel -> dst, ONLY if the profile was taken with the library this run
+    loaded (the stamp of profiles/rNN_pmc.json carries its sha256): `traffic` (+ `traffic_range` for the flow window), `physical_frac` =
+    those bytes over THIS run's kernel time over the HBM peak, `valu_executed`.  Another build's counters are refused, and said so."""
+    import re
+    w = pmc.get(window)
+    if not w:
+        return
+    m_ = re.search(r"sha256 ([0-9a-f]{16})", pmc.get("stamp", ""))
+    pmc_sha = m_.group(1) if m_ else None
+    dst["algorithmic_bytes"] = n_rank * bpp
+    if pmc_sha != lib_sha:
+        dst["traffic"] = None
+        dst["traffic_source"] = (f"REFUSED: {pmc_name} was taken with library sha256 {pmc_sha} ({pmc.get('stamp', 'unstamped')}), this run loaded {lib_sha}: "
+                                 "counters of another build are not attached (re-take the PMC passes: tools/gpu_profile_r05.sh)")
+        return
+    dst["traffic"] = w["traffic_bytes"]
+    dst["traffic_source"] = f"{pmc_name}[{window}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of g2p2g_kernel<2>, corrected as MI355X_MICROARCH.md prescribes; {pmc.get('stamp', 'unstamped')}: the library this run loaded)"
+    if kernel_ms > 0:
+        # what the memory system moved per launch (counters of the profiled launch) over THIS run's kernel time: the physical HBM rate
+        dst["physical_frac"] = w["traffic_bytes"] / (kernel_ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
+    if window == "flow" and "traffic_bytes_low" in w:
+        # the fetch calibration is that of a streaming kernel; the flow window reads scattered 32-B records, whose requests the counter tallies in full
+        dst["traffic_range"] = [w["traffic_bytes_low"], w["traffic_bytes"]]
+        if kernel_ms > 0:
+            dst["physical_frac_range"] = [w["traffic_bytes_low"] / (kernel_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), dst["physical_frac"]]
+    if w.get("valu_insts"):
+        # one wave-instruction serves 64 particles: instructions per particle (= per 64-particle iteration of a wave)
+        per_particle = w["valu_insts"] * 64.0 / n_rank
+        # issue-busy: wave-instructions x the measured cost of this kernel's mix (profiles/r03_energy_model.txt: VOP2 2.07, VOP3 2.16,
+        # packed 4.26 cycles; ~2.75 on average) / SIMD cycles available at the sclk the launch runs at (1.97 GHz: it is power-limited)
+        busy = w["valu_insts"] * 2.75 / (1024 * kernel_ms * 1e-3 * 1.97e9) if kernel_ms > 0 else 0.0
+        dst["valu_executed"] = {"wave_instructions_per_launch": w["valu_insts"], "executed_per_particle": per_particle, "issue_busy": busy,
+                                "note": "SQ_INSTS_VALU of the profiled launch; issue_busy prices an instruction at 2.75 cycles of a 1.97 GHz SIMD (measured mix and clock)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -401,45 +437,17 @@ def main():
         # runs, see profiles/): "rest" = the default window, "flow" = a window that starts after >= 2000 substeps.  The counters describe
         # ONE build of the kernel: they are attached only when the file's stamp carries the sha256 of the library this run loaded.
         import glob
-        import re
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))      # the newest round's counter passes
         tf = cands[-1] if cands else ""
         pmc_name = os.path.join("profiles", os.path.basename(tf)) if tf else "profiles/(none)"
         pmc = json.load(open(tf)) if tf else {}
         c3 = world == 1 and args.scene == "sand40m" and args.fraction >= 1.0
         lib_sha = loaded_library_sha16()
-        m_ = re.search(r"sha256 ([0-9a-f]{16})", pmc.get("stamp", ""))
-        pmc_sha = m_.group(1) if m_ else None
         out["library_sha256_16"] = lib_sha
 
         def attach(dst, window, kernel_ms):
-            w = pmc.get(window)
-            if not (c3 and w):
-                return
-            dst["algorithmic_bytes"] = n_rank * bpp
-            if pmc_sha != lib_sha:
-                dst["traffic"] = None
-                dst["traffic_source"] = (f"REFUSED: {pmc_name} was taken with library sha256 {pmc_sha} ({pmc.get('stamp', 'unstamped')}), this run loaded {lib_sha}: "
-                                         "counters of another build are not attached (re-take the PMC passes: tools/gpu_profile_r05.sh)")
-                return
-            dst["traffic"] = w["traffic_bytes"]
-            dst["traffic_source"] = f"{pmc_name}[{window}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of g2p2g_kernel<2>, corrected as MI355X_MICROARCH.md prescribes; {pmc.get('stamp', 'unstamped')}: the library this run loaded)"
-            if kernel_ms > 0:
-                # what the memory system moved per launch (counters of the profiled launch) over THIS run's kernel time: the physical HBM rate
-                dst["physical_frac"] = w["traffic_bytes"] / (kernel_ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
-            if window == "flow" and "traffic_bytes_low" in w:
-                # the fetch calibration is that of a streaming kernel; the flow window reads scattered 32-B records, whose requests the counter tallies in full
-                dst["traffic_range"] = [w["traffic_bytes_low"], w["traffic_bytes"]]
-                if kernel_ms > 0:
-                    dst["physical_frac_range"] = [w["traffic_bytes_low"] / (kernel_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), dst["physical_frac"]]
-            if "valu_insts" in w:
-                # one wave-instruction serves 64 particles: instructions per particle (= per 64-particle iteration of a wave)
-                per_particle = w["valu_insts"] * 64.0 / n_rank
-                # issue-busy: wave-instructions x the measured cost of this kernel's mix (profiles/r03_energy_model.txt: VOP2 2.07, VOP3 2.16,
-                # packed 4.26 cycles; ~2.75 on average) / SIMD cycles available at the sclk the launch runs at (1.97 GHz: it is power-limited)
-                busy = w["valu_insts"] * 2.75 / (1024 * kernel_ms * 1e-3 * 1.97e9) if kernel_ms > 0 else 0.0
-                dst["valu_executed"] = {"wave_instructions_per_launch": w["valu_insts"], "executed_per_particle": per_particle, "issue_busy": busy,
-                                        "note": "SQ_INSTS_VALU of the profiled launch; issue_busy prices an instruction at 2.75 cycles of a 1.97 GHz SIMD (measured mix and clock)"}
+            if c3:
+                attach_counters(dst, pmc, pmc_name, window, lib_sha, kernel_ms, n_rank, bpp)
 
         timed_window = "flow" if args.start_step >= 2000 else "rest"
         out["roofline"]["window"] = f"the timed K substeps ({'inside the flow' if timed_window == 'flow' else 'substeps ' + str(args.start_step + args.warmup) + '-' + str(args.start_step + args.warmup + args.steps)})"

@@ -113,3 +113,30 @@ def test_bench_without_a_gpu_fails_loudly_with_one_json_error_line():
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
     assert rec["value"] is None and "needs a GPU" in rec["error"] and rec["n_gpus"] == 1
+
+
+def test_bench_attaches_counters_only_of_the_library_it_loaded():
+    """bench.py's `traffic` / `physical_frac` / `valu_executed` come from profiles/rNN_pmc.json, a separate rocprofv3 run: they are attached only when
+    that file's stamp carries the sha256 of the library this run loaded (a kernel edit without a re-profile must not report
+    stale traffic), and the newest committed counter file is stamped at all."""
+    import glob
+    import json
+    import re
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))
+    assert files
+    pmc = json.load(open(files[-1]))
+    m = re.search(r"sha256 ([0-9a-f]{16})", pmc.get("stamp", ""))
+    assert m, "the newest counter file carries no library hash"
+    n, bpp = 40108032, 144
+    ok, stale = {}, {}
+    bench.attach_counters(ok, pmc, "profiles/x.json", "flow", m.group(1), 1.9, n, bpp)
+    assert ok["traffic"] == pmc["flow"]["traffic_bytes"] and ok["traffic_range"][0] <= ok["traffic"]
+    assert ok["physical_frac"] == pytest.approx(pmc["flow"]["traffic_bytes"] / 1.9e-3 / 8e12) and 0.2 < ok["physical_frac"] < 1.0
+    assert ok["valu_executed"]["executed_per_particle"] == pytest.approx(pmc["flow"]["valu_insts"] * 64 / n)
+    bench.attach_counters(stale, pmc, "profiles/x.json", "flow", "0123456789abcdef", 1.9, n, bpp)
+    assert stale["traffic"] is None and stale["traffic_source"].startswith("REFUSED") and "physical_frac" not in stale and "valu_executed" not in stale
+    assert stale["algorithmic_bytes"] == n * bpp
+    assert len(bench.loaded_library_sha16()) == 16
