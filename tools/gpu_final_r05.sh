@@ -9,7 +9,9 @@ if [ -n "$1" ]; then
   grep -E "^(FAILED|ERROR)|passed|failed|pytest rc" gpurun_out/r05_select_pytest.log | tail -12
 fi
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r05_smoke.log 2>&1; tail -1 gpurun_out/r05_smoke.log
-timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r05_bench_default_line.json 2> gpurun_out/r05_bench.err; echo "bench rc $?"
-tail -c 300 gpurun_out/r05_bench_default_line.json
+# the profile set first: bench.py attaches the counters of profiles/r05_pmc.json only if they were taken with the library it loads
 bash tools/gpu_profile_r05.sh all > gpurun_out/r05_profile.log 2>&1
 tail -3 gpurun_out/r05_profile.log
+python tools/make_pmc_json.py gpurun_out/prof_r05 profiles/r05_pmc.json > /dev/null && cp profiles/r05_pmc.json gpurun_out/r05_pmc.json
+timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r05_bench_default_line.json 2> gpurun_out/r05_bench.err; echo "bench rc $?"
+tail -c 300 gpurun_out/r05_bench_default_line.json
