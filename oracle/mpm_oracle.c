@@ -1454,11 +1454,11 @@ void mpmo_fn_grid_cells(const float* in5, size_t n, float gravity, float dt, flo
 	}
 }
 /* G16-G18: one particle per row through the body of g2p2g on a given velocity arena (g2pbuffer[3][8][8][8]) and an empty scatter arena.
- * rows_in: pos[3], F[9] (column-major), log_jp (13 floats); out_f (154 floats): vel[3] A[9] pos[3] | F[9] log_jp stress[9] | contrib[9]
+ * rows_in: pos[3], F[9] (column-major; J-fluid: J in F[0]), log_jp (13 floats); out_f (154 floats): vel[3] A[9] pos[3] | F[9] log_jp stress[9] | contrib[9]
  * local_pos[3] | the 27 x {m, mvx, mvy, mvz} the particle left in the arena, stencil offsets row-major; out_i (14 ints): base[3] arena[3]
  * add_advection cell[3] dirtag narena[3] discarded (narena = -99 when discarded) */
 int mpmo_fn_particle_step(int material, const mpm_material_params* p, int domain_bits, const float* arena, const float* rows_in, size_t n, float dt, float new_dt, float* out_f, int* out_i) {
-	if(!p || !arena || !rows_in || !out_f || !out_i || material < 1 || material > 3) return MPM_ERR_INVALID;
+	if(!p || !arena || !rows_in || !out_f || !out_i || material < 0 || material > 3) return MPM_ERR_INVALID;
 	const float dx_inv = (float) (1 << domain_bits), dx = 1.f / dx_inv, d_inv = 4.f * dx_inv * dx_inv; /* settings.h:60-66 */
 	const float e = p->youngs_modulus, nu = p->poisson_ratio;
 	const float mass = p->volume * p->rho, lambda = e * nu / ((1 + nu) * (1 - 2 * nu)), mu = e / (2 * (1 + nu));
@@ -1468,7 +1468,8 @@ int mpmo_fn_particle_step(int material, const mpm_material_params* p, int domain
 		memset(p2g, 0, sizeof(p2g));
 		const float* in = rows_in + 13 * i;
 		orc_particle_out o;
-		orc_particle_body(material, dx, dx_inv, d_inv, mass, p->volume, mu, lambda, bm, p, (const float(*)[8][8][8]) arena, p2g, in, 0.f, in + 3, in[12], dt, new_dt, &o);
+		orc_particle_body(material, dx, dx_inv, d_inv, mass, p->volume, mu, lambda, bm, p, (const float(*)[8][8][8]) arena, p2g, in, in[3], in + 3, in[12], dt, new_dt, &o); /* (J-fluid: the state J sits in the slot of F[0]) */
+		if(material == MPM_J_FLUID) o.F[0] = o.J;
 		float* f = out_f + 154 * i;
 		int* q	 = out_i + 14 * i;
 		memcpy(f, o.vel, 12), memcpy(f + 3, o.A, 36), memcpy(f + 12, o.pos, 12);

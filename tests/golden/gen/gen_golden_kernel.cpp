@@ -10,7 +10,7 @@
 //
 //   G16  gather + advect                       mgmpm_kernels.cuh:772-838   (gather.inc)
 //   G17  contrib line, re-bucketing, scatter    mgmpm_kernels.cuh:845-905   (scatter.inc)
-//   G18  FC / sand / NACC store + stress call   mgmpm_kernels.cuh:518-663   (body_fc.inc, body_sand.inc, body_nacc.inc)
+//   G18  J-fluid / FC / sand / NACC bodies        mgmpm_kernels.cuh:473-663   (body_jfluid.inc, body_fc.inc, body_sand.inc, body_nacc.inc)
 //   G19  grid-update cell arithmetic            mgmpm_kernels.cuh:353-388   (gridcell.inc)
 // One row of G16-G18 is ONE particle walked through the kernel's whole per-particle body (the three text blocks in the kernel's own
 // order, sharing locals exactly as they do there); the files record the inputs and every intermediate.
@@ -59,6 +59,7 @@ struct Buffer {// the members of ParticleBuffer<M> the statements read (particle
 	bool volume_correction;
 	float bm, xi, msqr;
 	bool hardening_on;
+	float bulk, gamma, viscosity;// J_FLUID (particle_buffer.cuh:148-153)
 	template<typename I>
 	BinRef ch(I, int binno) const {
 		return BinRef {bins[binno]};
@@ -74,6 +75,9 @@ struct Advection {// recorder for next_particle_buffer.add_advection(partition, 
 };
 
 // the three per-material bodies of calculate_contribution_and_store_particle_data (the signature is the reference's, :519 / :562 / :613)
+void body_jfluid(const Buffer particle_buffer, const Buffer next_particle_buffer, int advection_source_blockno, int source_pidib, int src_blockno, int particle_id_in_block, Duration dt, const std::array<float, 9>& A, std::array<float, 9>& contrib, CalculateContributionAndStoreParticleDataIntermediate& data) {
+#include "body_jfluid.inc"
+}
 void body_fc(const Buffer particle_buffer, const Buffer next_particle_buffer, int advection_source_blockno, int source_pidib, int src_blockno, int particle_id_in_block, Duration dt, const std::array<float, 9>& A, std::array<float, 9>& contrib, CalculateContributionAndStoreParticleDataIntermediate& data) {
 #include "body_fc.inc"
 }
@@ -116,7 +120,7 @@ void particle(int material, const float (&g2pbuffer)[3][8][8][8], const Buffer& 
 	bins_src[0][12][source_pidib] = r.logjp_in;
 	// (:770-772: the kernel fetches pos through fetch_particle_buffer_data, three channel reads)
 	vec3 pos {bins_src[0][0][source_pidib], bins_src[0][1][source_pidib], bins_src[0][2][source_pidib]};
-	float J = 0.f;
+	float J = material == 0 ? bins_src[0][3][source_pidib] : 0.f;// (fetch_particle_buffer_data<J_FLUID>: channel 3 is J; for the solid models it is F[0], not used as J)
 	r.discarded = 1;
 #include "gather.inc"
 	for(int d = 0; d < 3; ++d) {
@@ -131,6 +135,7 @@ void particle(int material, const float (&g2pbuffer)[3][8][8][8], const Buffer& 
 	store_particle_buffer_tmp.pos													= pos;
 	store_particle_buffer_tmp.J														= J;
 	vec9 contrib;
+	if(material == 0) body_jfluid(particle_buffer, next_bins, advection_source_blockno, source_pidib, src_blockno, particle_id_in_block, dt, A.data_arr(), contrib.data_arr(), store_particle_buffer_tmp);
 	if(material == 1) body_fc(particle_buffer, next_bins, advection_source_blockno, source_pidib, src_blockno, particle_id_in_block, dt, A.data_arr(), contrib.data_arr(), store_particle_buffer_tmp);
 	if(material == 2) body_sand(particle_buffer, next_bins, advection_source_blockno, source_pidib, src_blockno, particle_id_in_block, dt, A.data_arr(), contrib.data_arr(), store_particle_buffer_tmp);
 	if(material == 3) body_nacc(particle_buffer, next_bins, advection_source_blockno, source_pidib, src_blockno, particle_id_in_block, dt, A.data_arr(), contrib.data_arr(), store_particle_buffer_tmp);
@@ -242,9 +247,10 @@ int main(int argc, char** argv) {
 		pb.yield_surface = 0.816496580927726f * 2.f * 0.5f / (3.f - 0.5f);// particle_buffer.cuh:217
 	}
 	pb.bm = 2.f / 3.f * pb.mu + pb.lambda, pb.xi = 0.8f, pb.msqr = 3.423772074299613f, pb.hardening_on = true;
+	pb.bulk = 4e4f, pb.gamma = 7.15f, pb.viscosity = 0.01f;
 	const float dtv = 1e-4f, new_dtv = 7.5e-5f;// (dt != new_dt: the two uses must not be confused)
 	const float beta_nacc = 0.5f;// (particle_buffer.cuh:243; sand: 1, :213)
-	std::vector<float> par = {(float) config::DOMAIN_BITS, vol, pb.mass, pb.mu, pb.lambda, pb.cohesion, pb.beta, pb.yield_surface, pb.volume_correction ? 1.f : 0.f, pb.bm, pb.xi, pb.msqr, pb.hardening_on ? 1.f : 0.f, dtv, new_dtv, beta_nacc, E, nu, rho};
+	std::vector<float> par = {(float) config::DOMAIN_BITS, vol, pb.mass, pb.mu, pb.lambda, pb.cohesion, pb.beta, pb.yield_surface, pb.volume_correction ? 1.f : 0.f, pb.bm, pb.xi, pb.msqr, pb.hardening_on ? 1.f : 0.f, dtv, new_dtv, beta_nacc, E, nu, rho, pb.bulk, pb.gamma, pb.viscosity};
 	dump("g16_params.f32", par);
 	// ---- five velocity arenas (g2pbuffer[3][8][8][8]): rigid translation, shear + noise, fast divergent flow, violent noise, a 90 m/s stream
 	const int NA = 5;
@@ -266,12 +272,12 @@ int main(int argc, char** argv) {
 		memcpy(av.data(), arenas, sizeof(arenas));
 		dump("g16_arenas.f32", av);
 	}
-	// ---- particles: rows of 3 materials x NA arenas x 48
+	// ---- particles: rows of 4 materials (0 = J-fluid) x NA arenas x 48
 	const int PER = 48;
 	std::vector<float> in, out;
 	std::vector<int> iout;
 	int discarded = 0, crossed = 0;
-	for(int material = 1; material <= 3; ++material)
+	for(int material = 0; material <= 3; ++material)
 		for(int a = 0; a < NA; ++a)
 			for(int i = 0; i < PER; ++i) {
 				Row r {};
@@ -291,8 +297,13 @@ int main(int argc, char** argv) {
 				if(i % 16 == 15 && !plain) {// compressed: sand inside the cone / NACC hardening
 					for(int d = 0; d < 9; ++d) r.F_in[d] = ((d & 3) == 0 ? 0.85f : 0.f) + 0.03f * rnd_sym();
 				}
+				if(material == 0) {// the J-fluid's state is J (channel 3 = the slot of F[0]); a plain row carries J = 1
+					for(int d = 1; d < 9; ++d) r.F_in[d] = 0.f;
+					r.F_in[0] = plain ? 1.f : (i % 16 == 15 ? 0.11f : 0.6f + 0.8f * rnd01());
+				}
 				r.logjp_in = material == 3 ? -0.01f + 0.02f * rnd_sym() : 0.01f * rnd_sym();
 				if(plain) r.logjp_in = material == 3 ? -0.01f : 0.f;// LOG_JP_0 (particle_buffer.cuh:210, :242)
+				if(material == 0) r.logjp_in = 0.f;
 				Buffer pbm = pb;
 				if(material == 3) pbm.beta = beta_nacc;
 				particle(material, arenas[a], pbm, Duration(dtv), Duration(new_dtv), r);

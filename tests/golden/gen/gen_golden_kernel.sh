@@ -28,7 +28,9 @@ grep -q "contrib = (A \* particle_buffer.mass - contrib \* new_dt.count()) \* co
 grep -q "next_particle_buffer.add_advection(partition, new_global_base_index - 1, dirtag, particle_id_in_block);" "$S/scatter.inc"
 test "$(grep -c atomicAdd "$S/scatter.inc")" = 4
 ! grep -q "__syncthreads" "$S/scatter.inc"
-# G18: the bodies of calculate_contribution_and_store_particle_data<FC | SAND | NACC> (:518-663), without their signature and closing brace
+# G18: the bodies of calculate_contribution_and_store_particle_data<J_FLUID | FC | SAND | NACC> (:473-663), without their signature and closing brace
+sed -n "/^__forceinline__ __device__ void calculate_contribution_and_store_particle_data<MaterialE::J_FLUID>/,/^}/p" "$K" | sed '1d;$d' > "$S/body_jfluid.inc"
+grep -q "powf(data.J, -particle_buffer.gamma)" "$S/body_jfluid.inc"
 for m in FIXED_COROTATED:fc SAND:sand NACC:nacc; do
   sed -n "/^__forceinline__ __device__ void calculate_contribution_and_store_particle_data<MaterialE::${m%%:*}>/,/^}/p" "$K" | sed '1d;$d' > "$S/body_${m##*:}.inc"
   grep -q "compute_stress<float, MaterialE::${m%%:*}>" "$S/body_${m##*:}.inc"

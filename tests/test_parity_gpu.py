@@ -844,7 +844,7 @@ def test_failed_run_then_checkpoint_load_recovers():
     eng.close()
 
 
-@pytest.mark.parametrize("material", [_ffi.FIXED_COROTATED, _ffi.SAND, _ffi.NACC])
+@pytest.mark.parametrize("material", [_ffi.J_FLUID, _ffi.FIXED_COROTATED, _ffi.SAND, _ffi.NACC])
 def test_one_particle_scenes_through_the_real_kernel_against_the_references_statements(material):
     """G16-G18 on the GPU, through the PUBLIC C ABI and the real g2p2g_kernel (no test kernel): the golden rows whose particle is in the state
     initial_setup leaves one in (F = I, the model's log Jp_0) are replayed as one-particle scenes - mpm_add_model at the row's position,
@@ -857,7 +857,7 @@ def test_one_particle_scenes_through_the_real_kernel_against_the_references_stat
     import torch
     G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     par = np.fromfile(os.path.join(G, "g16_params.f32"), np.float32)
-    names = "bits vol mass mu lam cohesion beta_sand yield_surface volume_correction bm xi msqr hardening_on dt new_dt beta_nacc E nu rho".split()
+    names = "bits vol mass mu lam cohesion beta_sand yield_surface volume_correction bm xi msqr hardening_on dt new_dt beta_nacc E nu rho bulk gamma viscosity".split()
     P = dict(zip(names, [float(v) for v in par]))
     bits = int(P["bits"])
     dx = 1.0 / (1 << bits)
@@ -865,12 +865,14 @@ def test_one_particle_scenes_through_the_real_kernel_against_the_references_stat
     rin = np.fromfile(os.path.join(G, "g16_particle_in.f32"), np.float32).reshape(-1, 15)
     wf = np.fromfile(os.path.join(G, "g16_particle_out.f32"), np.float32).reshape(-1, 154)
     wi = np.fromfile(os.path.join(G, "g16_particle_out.i32"), np.int32).reshape(-1, 14)
-    eye = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1], np.float32)
+    eye = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1], np.float32) if material != _ffi.J_FLUID else np.array([1, 0, 0, 0, 0, 0, 0, 0, 0], np.float32)   # (J-fluid: J = 1 in the slot of F[0])
     lj0 = np.float32(-0.01 if material == _ffi.NACC else 0.0)
     plain = (rin[:, 0] == material) & np.all(rin[:, 5:14] == eye, axis=1) & (rin[:, 14] == lj0)
     rows = np.flatnonzero(plain)
     assert rows.size >= 60, rows.size
     prm = dict(rho=P["rho"], volume=P["vol"], youngs_modulus=P["E"], poisson_ratio=P["nu"])
+    if material == _ffi.J_FLUID:
+        prm = dict(rho=P["rho"], volume=P["vol"], bulk=P["bulk"], gamma=P["gamma"], viscosity=P["viscosity"])
     if material == _ffi.SAND:
         prm.update(cohesion=P["cohesion"], beta=P["beta_sand"], yield_surface=P["yield_surface"], volume_correction=int(P["volume_correction"]))
     if material == _ffi.NACC:
@@ -909,7 +911,10 @@ def test_one_particle_scenes_through_the_real_kernel_against_the_references_stat
         # state: b = F F^T of what the body stored, log Jp (G18)
         F = want[15:24].astype(np.float64).reshape(3, 3).T
         b = to_b(st, True)[0].reshape(3, 3)
-        if np.isfinite(F).all():
+        if material == _ffi.J_FLUID:
+            if np.isfinite(want[15]) and not abs(float(st[0, 0]) - float(want[15])) <= 2e-6 * max(1.0, abs(float(want[15]))):
+                bad.append((tag, "J", float(st[0, 0]), float(want[15])))
+        elif np.isfinite(F).all():
             e = np.abs(b - F @ F.T).max() / max(1.0, np.abs(F @ F.T).max())
             if not e <= 2e-5:
                 bad.append((tag, "b", e))
