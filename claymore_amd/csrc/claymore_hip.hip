@@ -615,6 +615,22 @@ static ModelView make_view(mpm_ctx* ctx, Model& m) {
 	return v;
 }
 
+// Which materials' G2P2G runs two particles per lane (bit m = material m; mpm_g2p2g_pair.hpp).  MPM_PAIR_BUILD: the instantiations compiled in;
+// MPM_PAIR_DEFAULT: the ones used unless the environment says otherwise (MPM_G2P2G_PAIRS=<mask>, read once: same-library A/B and tests).
+#ifndef MPM_PAIR_BUILD
+#define MPM_PAIR_BUILD 0xF
+#endif
+#ifndef MPM_PAIR_DEFAULT
+#define MPM_PAIR_DEFAULT 0x1
+#endif
+static int pair_mask() {
+	static const int mask = [] {
+		const char* e = std::getenv("MPM_G2P2G_PAIRS");
+		return (e && *e ? (int) std::strtol(e, nullptr, 0) : MPM_PAIR_DEFAULT) & MPM_PAIR_BUILD;
+	}();
+	return mask;
+}
+
 // a launch size for `n` (an estimate that may be a few substeps old) particle blocks: margin for growth, a multiple of 8 (XCDs)
 static inline int hint_blocks(const mpm_ctx* ctx, int n) {
 	const long long h = (long long) n + n / 16 + 64;
@@ -639,6 +655,22 @@ static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, co
 	sk.jdiv		= g.dx * dt * g.d_inv;
 	sk.jvisc	= g.dx * g.d_inv * m.mc.viscosity;
 	const int nwg = nblocks_ptr ? hint_blocks(ctx, nblocks) : nblocks;
+	// two particles per lane (mpm_g2p2g_pair.hpp) for the materials of pair_mask(); the others one particle per lane
+	const int pairs = pair_mask();
+#define MPM_LAUNCH_PAIR(M)                                                                                                                                                                      \
+	if constexpr((MPM_PAIR_BUILD >> M) & 1) {                                                                                                                                                   \
+		if((pairs >> M) & 1) {                                                                                                                                                                  \
+			g2p2g_pair_kernel<M><<<nwg, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, only_flag, nblocks_ptr, nblocks, dt, next_dt, sk, ctx->d_status); \
+			return;                                                                                                                                                                             \
+		}                                                                                                                                                                                       \
+	}
+	switch(m.material) {
+		case MPM_J_FLUID: MPM_LAUNCH_PAIR(0) break;
+		case MPM_FIXED_COROTATED: MPM_LAUNCH_PAIR(1) break;
+		case MPM_SAND: MPM_LAUNCH_PAIR(2) break;
+		default: MPM_LAUNCH_PAIR(3) break;
+	}
+#undef MPM_LAUNCH_PAIR
 	switch(m.material) {
 		case MPM_J_FLUID: g2p2g_kernel<0><<<nwg, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, only_flag, nblocks_ptr, nblocks, dt, next_dt, sk, ctx->d_status); break;
 		case MPM_FIXED_COROTATED: g2p2g_kernel<1><<<nwg, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, only_flag, nblocks_ptr, nblocks, dt, next_dt, sk, ctx->d_status); break;

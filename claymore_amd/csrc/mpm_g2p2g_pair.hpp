@@ -1,0 +1,652 @@
+// mpm_g2p2g_pair.hpp — G2P2G with TWO particles of one stencil base per lane (round 6; the structural step DESIGN.md 7 / VERDICT r5 #1 ask for).
+//
+// Same fused G2P + particle update + P2G as g2p2g_kernel (mpm_g2p2g.hpp; reference g2p2g, Projects/GMPM/mgmpm_kernels.cuh:665-937 with the
+// per-material bodies :422-663), same one-wave-per-block structure, same arenas, same list / bin formats.  What changes is the unit of an
+// iteration: a lane carries the records of TWO consecutive 64-slot slices of the block's sorted list - particle A = slot (2d, lane), particle
+// B = slot (2d + 1, lane).  The sort deals the records of one predicted stencil base to consecutive slices of one lane (wrap-around rule,
+// mpm_kernels.hpp), so A and B share their base wherever a cell holds an even run of particles - all of a resting lattice.  Then
+//   * the 27 gather nodes are read ONCE for both (27 ds_read_b128 per 128 particles instead of 54), when the whole wave's pairs share their base;
+//   * the two P2G contributions are summed in registers and take ONE read-modify-write per node: 27 pairs of ds_read_b128 / ds_write_b128 per 128
+//     particles instead of 54 - the scatter chain's 27 ordered LDS round trips serve twice the particles;
+//   * claims, exec brackets, slice arithmetic, list prefetch: once per 128 particles.
+// A pair whose members END the step with different bases (or whose B lost its A) splits: A takes the chain, B the serial path.
+// Cost: a second set of gather accumulators, payload and chain registers - the instantiation runs at two waves per SIMD.
+#pragma once
+#include "mpm_g2p2g.hpp"
+
+namespace mpm {
+
+#if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_WAVES))
+#define MPM_PAIR_WAVES 3
+#endif
+// MPM_PAIR_THREADED 1: the scatter chain of pair i - 1 is threaded through the update of pair i (payloads and chain state are loop-carried:
+// 231 VGPRs for the J-fluid, two waves per SIMD); 0: the pair scatters at the end of its own iteration, 27 steps back to back (no loop-carried
+// payload, no chain state beside the gather: fewer registers, more waves to cover the exposed round trips)
+#if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_THREADED))
+#define MPM_PAIR_THREADED 0
+#endif
+// bit m: material m reads the 27 gather nodes once for both particles when the wave's pairs share their bases (else: one gather per particle)
+#if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_SHARED_GATHER))
+#define MPM_PAIR_SHARED_GATHER 0x1// (the solid models' second set of gather accumulators does not fit 168 registers: spills inside the loop, +60 %)
+#endif
+
+// Tensor-product APIC gather (gather_apic, mpm_g2p2g.hpp) for two particles that share their stencil base: every node is loaded once.
+MPM_DEV void gather_apic_shared(const float4* __restrict__ gbase, const float (&w)[2][3][3], const float (&fd)[2][3], float (&vel)[2][3], float (&A)[2][9]) {
+	v2f_ wz[2][3], wy[2][3], wx[2][3];
+#pragma unroll
+	for(int h = 0; h < 2; ++h)
+#pragma unroll
+		for(int t = 0; t < 3; ++t) {
+			wx[h][t] = (v2f_) {w[h][0][t], w[h][0][t] * ((float) t - fd[h][0])};
+			wy[h][t] = (v2f_) {w[h][1][t], w[h][1][t] * ((float) t - fd[h][1])};
+			wz[h][t] = (v2f_) {w[h][2][t], w[h][2][t] * ((float) t - fd[h][2])};
+		}
+	v2f_ vel_xy[2], A0_xy[2], A3_xy[2], A6_xy[2], velz_A2[2];
+	float A5[2], A8[2];
+#pragma unroll
+	for(int h = 0; h < 2; ++h) {
+		vel_xy[h] = A0_xy[h] = A3_xy[h] = A6_xy[h] = velz_A2[h] = (v2f_) {0.f, 0.f};
+		A5[h] = A8[h] = 0.f;
+	}
+#pragma unroll
+	for(int i = 0; i < 3; ++i) {
+		v2f_ u0_xy[2], uy_xy[2], uz_xy[2], u0z_uyz[2];
+		float uzz[2];
+#pragma unroll
+		for(int h = 0; h < 2; ++h) {
+			u0_xy[h] = uy_xy[h] = uz_xy[h] = u0z_uyz[h] = (v2f_) {0.f, 0.f};
+			uzz[h]										= 0.f;
+		}
+#pragma unroll
+		for(int j = 0; j < 3; ++j) {
+			v2f_ t0_xy[2], t1_xy[2], t0z_t1z[2];
+#pragma unroll
+			for(int h = 0; h < 2; ++h) t0_xy[h] = t1_xy[h] = t0z_t1z[h] = (v2f_) {0.f, 0.f};
+#pragma unroll
+			for(int k = 0; k < 3; ++k) {
+				const float4 v = gbase[i * kG2PStrideX + j * kG2PStrideY + k * kG2PStrideZ];
+				const v2f_ vxy = {v.x, v.y}, vzz = {v.z, v.w};
+#pragma unroll
+				for(int h = 0; h < 2; ++h) {
+					t0_xy[h]   = vxy * wz[h][k].x + t0_xy[h];
+					t1_xy[h]   = vxy * wz[h][k].y + t1_xy[h];
+					t0z_t1z[h] = wz[h][k] * vzz + t0z_t1z[h];
+				}
+			}
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for(int h = 0; h < 2; ++h) {
+				u0_xy[h]   = t0_xy[h] * wy[h][j].x + u0_xy[h];
+				uy_xy[h]   = t0_xy[h] * wy[h][j].y + uy_xy[h];
+				uz_xy[h]   = t1_xy[h] * wy[h][j].x + uz_xy[h];
+				u0z_uyz[h] = wy[h][j] * t0z_t1z[h].x + u0z_uyz[h];
+				uzz[h] += wy[h][j].x * t0z_t1z[h].y;
+			}
+		}
+#pragma unroll
+		for(int h = 0; h < 2; ++h) {
+			vel_xy[h]  = u0_xy[h] * wx[h][i].x + vel_xy[h];
+			A0_xy[h]   = u0_xy[h] * wx[h][i].y + A0_xy[h];
+			A3_xy[h]   = uy_xy[h] * wx[h][i].x + A3_xy[h];
+			A6_xy[h]   = uz_xy[h] * wx[h][i].x + A6_xy[h];
+			velz_A2[h] = wx[h][i] * u0z_uyz[h].x + velz_A2[h];
+			A5[h] += wx[h][i].x * u0z_uyz[h].y;
+			A8[h] += wx[h][i].x * uzz[h];
+		}
+	}
+#pragma unroll
+	for(int h = 0; h < 2; ++h) {
+		vel[h][0] = vel_xy[h].x;
+		vel[h][1] = vel_xy[h].y;
+		vel[h][2] = velz_A2[h].x;
+		A[h][0]	  = A0_xy[h].x;
+		A[h][1]	  = A0_xy[h].y;
+		A[h][2]	  = velz_A2[h].y;
+		A[h][3]	  = A3_xy[h].x;
+		A[h][4]	  = A3_xy[h].y;
+		A[h][5]	  = A5[h];
+		A[h][6]	  = A6_xy[h].x;
+		A[h][7]	  = A6_xy[h].y;
+		A[h][8]	  = A8[h];
+#pragma unroll
+		for(int d = 0; d < 9; ++d) __asm__ volatile("" : "+v"(A[h][d]));
+#pragma unroll
+		for(int d = 0; d < 3; ++d) __asm__ volatile("" : "+v"(vel[h][d]));
+	}
+}
+
+// One particle's share of a chain step: B-spline weights of the new position and the incremental walk of the affine momentum term
+// (ScatterChain, mpm_g2p2g.hpp).  `on` = false zeroes the x weights: the particle contributes nothing (its pair split).
+struct ChainHalf {
+	float pw[3][3];
+	float cx0, cy0, cz0, cz0x2;
+	v2f_ cx12, cy12, cz12, cz12x2;
+	float slab0, pen0, wij;
+	v2f_ slab12, pen12;
+	MPM_DEV void init(const P2GPayload& p, bool on) {
+#pragma unroll
+		for(int d = 0; d < 3; ++d) bspline_weight_cells(p.fd[d], pw[d]);
+		if(!on) pw[0][0] = pw[0][1] = pw[0][2] = 0.f;
+		cx0	 = p.contrib[0], cy0 = p.contrib[3], cz0 = p.contrib[6];
+		cx12 = (v2f_) {p.contrib[1], p.contrib[2]}, cy12 = (v2f_) {p.contrib[4], p.contrib[5]}, cz12 = (v2f_) {p.contrib[7], p.contrib[8]};
+		slab0  = p.mv[0] - cx0 * p.fd[0] - cy0 * p.fd[1] - cz0 * p.fd[2];
+		slab12 = (v2f_) {p.mv[1], p.mv[2]} - cx12 * p.fd[0] - cy12 * p.fd[1] - cz12 * p.fd[2];
+		cz0x2  = cz0 + cz0;
+		cz12x2 = cz12 + cz12;
+	}
+	MPM_DEV void add(int o, float mass, v2f_& a01, v2f_& a23) {// o: compile-time after unrolling
+		const int i = o / 9, j = (o / 3) % 3, k = o % 3;
+		if(k == 0) {
+			if(j == 0) {
+				if(i != 0) {
+					slab0 += cx0;
+					slab12 += cx12;
+				}
+				pen0  = slab0;
+				pen12 = slab12;
+			} else {
+				pen0 += cy0;
+				pen12 += cy12;
+			}
+			wij = pw[0][i] * pw[1][j];
+		}
+		const float W  = wij * pw[2][k];
+		const v2f_ m0  = {mass, k == 0 ? pen0 : (k == 1 ? pen0 + cz0 : pen0 + cz0x2)};
+		const v2f_ t12 = k == 0 ? pen12 : (k == 1 ? pen12 + cz12 : pen12 + cz12x2);
+		a01			   = m0 * W + a01;
+		a23			   = t12 * W + a23;
+	}
+};
+
+// The scatter chain for a PAIR: per node the two contributions are summed in registers, one read-modify-write (cf. ScatterChain).
+template<int NSITES>
+struct ScatterChain2 {
+	float4* node0;
+	float mass;
+	int win;
+	ChainHalf h[2];
+	float4 acc;
+	MPM_DEV ScatterChain2(float4* n0, const P2GPayload& pa, const P2GPayload& pb, float m, bool w, bool with_b)
+		: node0(n0)
+		, mass(m)
+		, win(w) {
+		h[0].init(pa, true);
+		h[1].init(pb, with_b);
+		if(win) acc = node0[0];
+	}
+	MPM_DEV void step(int o) {
+		v2f_ a01 = {acc.x, acc.y};
+		v2f_ a23 = {acc.z, acc.w};
+		h[0].add(o, mass, a01, a23);
+		h[1].add(o, mass, a01, a23);
+		const int i = o / 9, j = (o / 3) % 3, k = o % 3;
+		node0[i * kP2GStrideX + j * kP2GStrideY + k] = make_float4(a01.x, a01.y, a23.x, a23.y);
+		__asm__ volatile("" ::: "memory");
+		if(o + 1 < 27) {
+			const int i1 = (o + 1) / 9, j1 = ((o + 1) / 3) % 3, k1 = (o + 1) % 3;
+			acc			 = node0[i1 * kP2GStrideX + j1 * kP2GStrideY + k1];
+		}
+	}
+	template<int SITE>
+	MPM_DEV void at() {
+		static_assert(SITE >= 0 && SITE < NSITES, "site out of range");
+		if(win) {
+#pragma unroll
+			for(int o = SITE * 27 / NSITES; o < (SITE + 1) * 27 / NSITES; ++o) step(o);
+		}
+	}
+};
+
+template<int MAT>
+__global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_keys, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, const int* __restrict__ only_flag, const int* __restrict__ nblocks_ptr, int nblocks, float dt, float new_dt, StepConst sk, int* __restrict__ status) {
+	constexpr int NCH = MatTraits<MAT>::nch;
+	constexpr int REC = MatTraits<MAT>::rec;
+	__shared__ float4 g2p[kG2PNodes];
+	__shared__ float4 p2g[kP2GArena2 + kP2GNodes];
+	__shared__ unsigned char s_owner[2 * 216];
+	constexpr bool kQueue = MAT != 0 && kSerialQueue > 0;
+	__shared__ float4 s_queue[kQueue ? 4 * kSerialQueue : 1];
+
+	const int lane0 = threadIdx.x;
+	const int total = nblocks_ptr ? min(*nblocks_ptr, cfg.cap) : nblocks;
+	const int xcd = (int) (blockIdx.x & 7u), nq = nblocks_ptr ? (int) (gridDim.x >> 3) : 0x40000000;
+	const int share = (total >> 3) + (xcd < (total & 7) ? 1 : 0);
+	const int first = xcd * (total >> 3) + min(xcd, total & 7);
+	for(int q = (int) (blockIdx.x >> 3); q < share; q += nq) {
+	int lane = lane0;
+	__asm__ volatile("" : "+v"(lane));
+	const int bid = first + q;
+	const int b	  = block_list ? block_list[bid] : bid;
+	const int size		 = mv.size[b];
+	const int row		 = mv.row_of[b];
+	const int binoff_dst = mv.binoff_dst[b];
+	const int flag		 = only_flag ? only_flag[b] : 1;
+	if(size == 0 || flag == 0) continue;
+	const int* list		= mv.list_in + (size_t) row * cfg.ppb;
+	const float mass	= mv.mc.mass;
+	const int key_shift = cfg.pid_bits;
+	const int tag_shift = cfg.pid_bits + kKeyBits;
+	const int info		= mv.blockinfo[(size_t) b * kInfoRow + lane];
+	// ---- the list records of a pair iteration: slices (idx, idx + 64) of the sorted list.  B is absent when the block's last chunk has an odd
+	//      number of slices: the lane then re-reads A's record (same inputs, same results, stored to the same slot; never active).
+	struct Recs {
+		int rec[2];
+		int cnt[2];
+		int has_b;
+	};
+	auto load_recs = [&](int idx, Recs& r) {
+		const bool in = idx < size;// (beyond the end: a harmless dummy, never processed)
+		const int ia  = in ? idx : 0;
+		r.cnt[0]	  = in ? slice_records_at(size, idx) : 1;
+		r.has_b		  = in && idx + 64 < size;
+		r.cnt[1]	  = r.has_b ? slice_records_at(size, idx + 64) : 0;
+		r.rec[0]	  = list[ia + min(lane, r.cnt[0] - 1)];
+		r.rec[1]	  = list[r.has_b ? ia + 64 + min(lane, r.cnt[1] - 1) : ia + min(lane, r.cnt[0] - 1)];
+	};
+	Recs r_cur, r_next;
+	load_recs(0, r_cur);
+	load_recs(128, r_next);
+	for(int i = lane; i < kP2GArena2 + kP2GNodes; i += 64) p2g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+	__syncthreads();
+	float4 gv[8];
+#pragma unroll
+	for(int lb = 0; lb < 8; ++lb) {
+		const int nb	= __shfl(info, 54 + lb);
+		const float* gb = grid + (size_t) (nb < 0 ? 0 : nb) * 256;
+		gv[lb].x		= gb[64 + lane];
+		gv[lb].y		= gb[128 + lane];
+		gv[lb].z		= gb[192 + lane];
+		if(nb < 0) gv[lb].x = gv[lb].y = gv[lb].z = 0.f;
+		gv[lb].w = gv[lb].z;
+	}
+	constexpr int ROW = NCH - REC;
+	struct Prefetch {
+		float4 q[REC / 4];
+		float row[ROW ? ROW : 1];
+		int key;
+	};
+	auto fetch = [&](int rec, Prefetch& f) {
+		const int tag	  = (rec >> tag_shift) & 31;
+		const int sp	  = rec & (cfg.ppb - 1);
+		const int sbin	  = __shfl(info, tag) + (sp >> 6);
+		const float* bin  = mv.bins_src + (size_t) sbin * (kBin * NCH);
+		const float4* src = reinterpret_cast<const float4*>(bin + (sp & 63) * REC);
+		f.key			  = (rec >> key_shift) & 255;
+#pragma unroll
+		for(int d = 0; d < REC / 4; ++d) f.q[d] = src[d];
+		if constexpr(ROW == 1) f.row[0] = bin[kBin * REC + (sp & 63)];
+		if constexpr(ROW == 2) {
+			const float2 t = reinterpret_cast<const float2*>(bin + kBin * REC)[sp & 63];
+			f.row[0]	   = t.x;
+			f.row[1]	   = t.y;
+		}
+	};
+	Prefetch pf[2];
+	fetch(r_cur.rec[0], pf[0]);
+	fetch(r_cur.rec[1], pf[1]);
+#pragma unroll
+	for(int lb = 0; lb < 8; ++lb) {
+		const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
+		const int ax = cx + ((lb & 4) ? 4 : 0) - 1, ay = cy + ((lb & 2) ? 4 : 0) - 1, az = cz + ((lb & 1) ? 4 : 0) - 1;
+		if(((unsigned) ax < 6u) & ((unsigned) ay < 6u) & ((unsigned) az < 6u)) g2p[ax * kG2PStrideX + ay * kG2PStrideY + az * kG2PStrideZ] = gv[lb];
+	}
+	__syncthreads();
+	constexpr bool kThreaded = MPM_PAIR_THREADED != 0;
+	constexpr bool kSharedGather = ((MPM_PAIR_SHARED_GATHER >> MAT) & 1) != 0;
+	P2GPayload pv[2];
+	int pv_code[2] = {-1, -1};
+	int qn		   = 0;
+	bool settled   = true;
+#ifdef MPM_G2P2G_STATS
+	int st_iter = 0, st_losers = 0, st_edge = 0, st_retry_iters = 0, st_partial = 0, st_split = 0;
+#endif
+	for(int idx0 = 0;; idx0 += 128) {
+		const bool drain = idx0 >= size;
+		bool win		 = false;
+		bool merge_b	 = false;
+		bool pv_in[2] = {pv_code[0] >= 0, pv_code[1] >= 0};
+		float contrib[2][9];// -P F^T vol new_dt D^-1 dx of this iteration's particles (the payload is formed at the hand-over)
+		float vel[2][3], A[2][9], nfd[2][3];
+		int ncode[2] = {-1, -1};
+		if(!drain) {
+		MPM_MARK("P_top");
+		const bool active[2] = {lane < r_cur.cnt[0], lane < r_cur.cnt[1]};
+		const int pidib[2]	 = {idx0 + lane, r_cur.has_b ? idx0 + 64 + lane : idx0 + lane};// slot in the destination bins == position in the sorted order
+#ifdef MPM_G2P2G_STATS
+		st_partial += __popcll(__ballot(!active[0])) + __popcll(__ballot(!active[1]));
+#endif
+		float pos[2][3], st[2][7];
+		int okey[2];
+#pragma unroll
+		for(int h = 0; h < 2; ++h) {
+			pos[h][0] = pf[h].q[0].x, pos[h][1] = pf[h].q[0].y, pos[h][2] = pf[h].q[0].z;
+			st[h][0] = pf[h].q[0].w;
+			if constexpr(MAT != 0) {
+				st[h][1] = pf[h].q[1].x;
+				st[h][2] = pf[h].q[1].y;
+				st[h][3] = pf[h].q[1].z;
+				st[h][4] = pf[h].q[1].w;
+				st[h][5] = pf[h].row[0];
+				if constexpr(ROW == 2) st[h][6] = pf[h].row[1];
+			}
+			okey[h] = pf[h].key;
+		}
+		// the list records two iterations ahead, the particle records one iteration ahead
+		Recs r_nn;
+		load_recs(idx0 + 256, r_nn);
+		fetch(r_next.rec[0], pf[0]);
+		fetch(r_next.rec[1], pf[1]);
+		const int hasb_now = r_cur.has_b;
+		r_cur			   = r_next;
+		r_next			   = r_nn;
+		MPM_MARK("P_gather");
+		// ---- stencil bases + weights (:774-797), gather: the nodes are read once when every lane's pair shares its base
+		int base[2][3], arena[2][3];
+		{
+			float fd[2][3], w[2][3][3];
+			bool same = true;
+#pragma unroll
+			for(int h = 0; h < 2; ++h)
+#pragma unroll
+				for(int d = 0; d < 3; ++d) {
+					const float p = pos[h][d];
+					base[h][d]	  = lround_pos(p) - 1;
+					fd[h][d]	  = p - (float) base[h][d];
+					bspline_weight_cells(fd[h][d], w[h][d]);
+					arena[h][d] = ((base[h][d] - 1) & 3) + 1;
+				}
+#pragma unroll
+			for(int d = 0; d < 3; ++d) same &= arena[0][d] == arena[1][d];
+			if(kSharedGather && __all(same)) {
+				gather_apic_shared(g2p + (arena[0][0] - 1) * kG2PStrideX + (arena[0][1] - 1) * kG2PStrideY + (arena[0][2] - 1) * kG2PStrideZ, w, fd, vel, A);
+			} else {
+#pragma unroll
+				for(int h = 0; h < 2; ++h) gather_apic(g2p + (arena[h][0] - 1) * kG2PStrideX + (arena[h][1] - 1) * kG2PStrideY + (arena[h][2] - 1) * kG2PStrideZ, w[h], fd[h], vel[h], A[h]);
+			}
+		}
+		// ---- claim the stencil base of the pair in flight: A claims; B rides with A when it has A's base
+		MPM_MARK("P_claim");
+		constexpr int kPreSites	   = 6;// chain sites in the re-bucketing of both particles
+		constexpr int kStressSites = MAT == 0 ? 1 : (MAT == 1 ? kFcSites : (MAT == 2 ? kSandSites : kNaccSites));
+		constexpr int kMatSites	   = kStressSites + 1;// per particle
+		constexpr int kSites	   = kPreSites + 2 * kMatSites + 1;
+		auto make_chain = [&]() {
+			if constexpr(kThreaded) {
+				const int pv_key = (pv_in[0] ? code_key(pv_code[0]) : 0) + (lane & 1) * 216;
+				if(pv_in[0]) s_owner[pv_key] = (unsigned char) lane;
+				__asm__ volatile("" ::: "memory");
+				win		= pv_in[0] && !code_edge(pv_code[0]) && (int) s_owner[pv_key] == lane;
+				merge_b = win && pv_in[1] && pv_code[1] == pv_code[0];
+				return ScatterChain2<kSites>(p2g + (win ? code_off(pv_code[0]) + (lane & 1) * kP2GArena2 : 0), pv[0], pv[1], mass, win, merge_b);
+			} else {
+				return NoHook {};
+			}
+		};
+		auto chain = make_chain();
+		MPM_MARK("P_rebucket");
+		// ---- advect (:838), new base, re-bucket (:852-866, add_advection particle_buffer.cuh:100-135)
+		int narena[2][3], dirv[2][3], pk[2][3];
+		bool in_arena[2];
+		const float pred = sk.pred;
+#pragma unroll
+		for(int h = 0; h < 2; ++h) {
+			in_arena[h] = active[h];
+#pragma unroll
+			for(int d = 0; d < 3; ++d) {
+				pos[h][d]		= fmaf(vel[h][d], sk.dtp, pos[h][d]);
+				const float p	= pos[h][d];
+				const int nbase = lround_pos(p) - 1;
+				nfd[h][d]		= p - (float) nbase;
+				narena[h][d]	= arena[h][d] + (nbase - base[h][d]);
+				in_arena[h] &= (narena[h][d] >= 0) & (narena[h][d] <= 5);
+				dirv[h][d]	   = -((narena[h][d] - 1) >> 2);
+				const int step = (int) __builtin_rintf(fmaf(vel[h][d], pred, nfd[h][d]));
+				pk[h][d]	   = min(max(((narena[h][d] - 1) & 3) + step, 0), 5);
+			}
+			if(h == 0)
+				chain.template at<0>();
+			else
+				chain.template at<1>();
+		}
+		int ntag[2], dno[2], stay_rank[2], raw_move[2] = {0, 0};
+		bool stay[2];
+		int stay_leader, raw_stay = 0;
+		int b_opaque = b;
+		__asm__("" : "+v"(b_opaque));
+		if(__all((dirv[0][0] | dirv[0][1] | dirv[0][2] | dirv[1][0] | dirv[1][1] | dirv[1][2]) == 0)) {
+			// every particle of the iteration stays in this block: one atomic for all of them
+			const int n_a = __popcll(__ballot(active[0])), n_b = __popcll(__ballot(active[1]));
+#pragma unroll
+			for(int h = 0; h < 2; ++h) {
+				ntag[h] = kStay;
+				dno[h]	= active[h] ? b : -1;
+				stay[h] = active[h];
+			}
+			stay_leader	 = 0;
+			stay_rank[0] = lane;// (the active lanes are the first lanes of a slice)
+			stay_rank[1] = n_a + lane;
+			if(lane == 0) raw_stay = atomicAdd(&mv.out_count[b_opaque], n_a + n_b);
+		} else {
+			unsigned long long stay_m[2];
+#pragma unroll
+			for(int h = 0; h < 2; ++h) {
+				const bool dir_ok = ((unsigned) (dirv[h][0] + 1) < 3u) & ((unsigned) (dirv[h][1] + 1) < 3u) & ((unsigned) (dirv[h][2] + 1) < 3u);
+				ntag[h]			  = dir_ok ? (dirv[h][0] + 1) * 9 + (dirv[h][1] + 1) * 3 + dirv[h][2] + 1 : kStay;
+				const int dno_raw = __shfl(info, 27 + ntag[h]);
+				dno[h]			  = (active[h] && dir_ok) ? dno_raw : -1;
+				stay[h]			  = dno[h] >= 0 && ntag[h] == kStay;
+				stay_m[h]		  = __ballot(stay[h]);
+				stay_rank[h]	  = (int) __builtin_amdgcn_mbcnt_hi((unsigned) (stay_m[h] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) stay_m[h], 0u));
+			}
+			stay_rank[1] += __popcll(stay_m[0]);
+			const unsigned long long any_m = stay_m[0] | stay_m[1];
+			stay_leader					   = any_m ? __ffsll((long long) any_m) - 1 : 0;
+			if(any_m != 0ull && lane == stay_leader) raw_stay = atomicAdd(&mv.out_count[b_opaque], __popcll(stay_m[0]) + __popcll(stay_m[1]));
+#pragma unroll
+			for(int h = 0; h < 2; ++h) {
+				if(dno[h] >= 0 && !stay[h]) raw_move[h] = atomicAdd(&mv.out_count[dno[h]], 1);
+				if(active[h]) {
+					if(dno[h] < 0) atomicAdd(&status[ST_LOST], 1);
+					if(!in_arena[h]) atomicAdd(&status[ST_ARENA], 1);
+				}
+			}
+		}
+		chain.template at<2>();
+		chain.template at<3>();
+		int pkey[2], rec[2];
+#pragma unroll
+		for(int h = 0; h < 2; ++h) {
+			pkey[h] = pk[h][1] * 36 + pk[h][0] * 6 + pk[h][2];
+			rec[h]	= (ntag[h] << tag_shift) | (pkey[h] << key_shift) | pidib[h];
+		}
+		settled = settled && __all((!active[0] || (stay[0] && pkey[0] == okey[0])) && (!active[1] || (stay[1] && pkey[1] == okey[1])));
+		chain.template at<4>();
+		chain.template at<5>();
+		MPM_MARK("P_material");
+		// ---- material update, store to the destination bin (:470-663); B absent: same slot, same values as A
+		auto material = [&](auto hc) {
+			constexpr int H	   = decltype(hc)::value;
+			constexpr int BASE = kPreSites + H * kMatSites;
+			float* dbin		   = mv.bins_dst + (size_t) (binoff_dst + (pidib[H] >> 6)) * (kBin * NCH);
+			float4* dst		   = reinterpret_cast<float4*>(dbin + (pidib[H] & 63) * REC);
+			if constexpr(MAT == 0) {
+				chain.template at<BASE + 0>();
+				const float J = stress_jfluid(mv.mc, sk.ss.vol, sk.jdiv, sk.jvisc, st[H][0], A[H], contrib[H]);
+				chain.template at<BASE + 1>();
+				dst[0] = make_float4(pos[H][0], pos[H][1], pos[H][2], J);
+			} else {
+				float G[9], bo[6], bn[6];
+#pragma unroll
+				for(int d = 0; d < 9; ++d) G[d] = A[H][d] * sk.dts + ((d & 0x3) != 0 ? 0.f : 1.f);
+				bool refl = (__float_as_uint(st[H][0]) & kReflBit) != 0u;
+				bo[0]	  = fabsf(st[H][0]);
+#pragma unroll
+				for(int d = 1; d < 6; ++d) bo[d] = st[H][d];
+				{
+					const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(fabsf(A[H][0]), fabsf(A[H][1])), fabsf(A[H][2])), __builtin_fmaxf(__builtin_fmaxf(fabsf(A[H][3]), fabsf(A[H][4])), fabsf(A[H][5]))),
+													   __builtin_fmaxf(__builtin_fmaxf(fabsf(A[H][6]), fabsf(A[H][7])), fabsf(A[H][8])));
+					const bool wild	 = !(amax < sk.refl_lim);
+					if(__any(wild)) {
+						if(wild) refl ^= det3(G) < 0.f;
+					}
+				}
+				push_forward(G, bo, bn);
+				chain.template at<BASE + 0>();
+				float lj = 0.f;
+				if constexpr(MAT == 1) {
+					stress_fixed_corotated<BASE + 1>(sk.ss, bn, refl, contrib[H], chain);
+				} else if constexpr(MAT == 2) {
+					lj = st[H][6];
+					stress_sand<BASE + 1>(mv.mc, sk.ss, bn, refl, lj, contrib[H], chain);
+				} else {
+					lj = st[H][6];
+					stress_nacc<BASE + 1>(mv.mc, sk.ss, bn, refl, lj, contrib[H], chain);
+				}
+				dst[0] = make_float4(pos[H][0], pos[H][1], pos[H][2], refl ? -bn[0] : bn[0]);
+				dst[1] = make_float4(bn[1], bn[2], bn[3], bn[4]);
+				if constexpr(ROW == 1) dbin[kBin * REC + (pidib[H] & 63)] = bn[5];
+				if constexpr(ROW == 2) reinterpret_cast<float2*>(dbin + kBin * REC)[pidib[H] & 63] = make_float2(bn[5], lj);
+			}
+		};
+		material(std::integral_constant<int, 0> {});
+		material(std::integral_constant<int, 1> {});
+		MPM_MARK("P_contrib");
+		chain.template at<kSites - 1>();
+#pragma unroll
+		for(int h = 0; h < 2; ++h) ncode[h] = in_arena[h] ? (narena[h][0] | (narena[h][1] << 4) | (narena[h][2] << 8)) : -1;
+		(void) hasb_now;
+		MPM_MARK("P_append");
+		{
+			const int basev = __shfl(raw_stay, stay_leader);
+#pragma unroll
+			for(int h = 0; h < 2; ++h) {
+				if(dno[h] >= 0) {
+					const int slot = stay[h] ? basev + stay_rank[h] : raw_move[h];
+					if(slot >= cfg.ppb)
+						atomicOr(&status[ST_OVERFLOW], 2);
+					else
+						mv.list_out[((size_t) dno[h] << cfg.pid_bits) + slot] = rec[h];
+				}
+			}
+		}
+		if constexpr(!kThreaded) {
+			// ---- the pair scatters now: payload (:850), claim, 27 steps back to back
+			const float am = sk.am;
+#pragma unroll
+			for(int h = 0; h < 2; ++h) {
+#pragma unroll
+				for(int d = 0; d < 3; ++d) {
+					pv[h].fd[d] = nfd[h][d];
+					pv[h].mv[d] = mass * vel[h][d];
+				}
+#pragma unroll
+				for(int d = 0; d < 9; ++d) pv[h].contrib[d] = fmaf(A[h][d], am, contrib[h][d]);
+				pv_code[h] = ncode[h];
+				pv_in[h]   = ncode[h] >= 0;
+			}
+			const int pv_key = (pv_in[0] ? code_key(pv_code[0]) : 0) + (lane & 1) * 216;
+			if(pv_in[0]) s_owner[pv_key] = (unsigned char) lane;
+			__asm__ volatile("" ::: "memory");
+			win		= pv_in[0] && !code_edge(pv_code[0]) && (int) s_owner[pv_key] == lane;
+			merge_b = win && pv_in[1] && pv_code[1] == pv_code[0];
+			ScatterChain2<1> now(p2g + (win ? code_off(pv_code[0]) + (lane & 1) * kP2GArena2 : 0), pv[0], pv[1], mass, win, merge_b);
+			now.template at<0>();
+		}
+		} else if(kThreaded && pv_in[0]) {
+			// draining pass: the last pairs' winners run the 27 steps back to back
+			const int pv_key = code_key(pv_code[0]) + (lane & 1) * 216;
+			s_owner[pv_key]	 = (unsigned char) lane;
+			__asm__ volatile("" ::: "memory");
+			win		= !code_edge(pv_code[0]) && (int) s_owner[pv_key] == lane;
+			merge_b = win && pv_in[1] && pv_code[1] == pv_code[0];
+			ScatterChain2<1> chain(p2g + (win ? code_off(pv_code[0]) + (lane & 1) * kP2GArena2 : 0), pv[0], pv[1], mass, win, merge_b);
+			chain.template at<0>();
+		}
+		MPM_MARK("P_serial");
+		// ---- what the chain did not take: A without a claim or on the cube's edge, B split from its A
+		{
+			const bool left_a = pv_in[0] && !win;
+			const bool left_b = pv_in[1] && !merge_b;
+#ifdef MPM_G2P2G_STATS
+			if(!drain) {
+				st_iter += 1;
+				st_losers += __popcll(__ballot(left_a && !code_edge(pv_code[0]))) + __popcll(__ballot(left_b && !code_edge(pv_code[1]) && !left_a));
+				st_edge += __popcll(__ballot(pv_in[0] && code_edge(pv_code[0]))) + __popcll(__ballot(pv_in[1] && code_edge(pv_code[1])));
+				st_split += __popcll(__ballot(left_b && win));
+				st_retry_iters += __any(left_a || left_b) ? 1 : 0;
+			}
+#endif
+			if(__any(left_a)) {
+				if constexpr(kQueue)
+					serial_push(p2g, s_queue, qn, left_a, pv_code[0], pv[0], mass, lane, info, next_grid);
+				else
+					p2g_serial(p2g, left_a, pv_code[0], pv[0], mass, lane, info, next_grid);
+			}
+			if(__any(left_b)) {
+				if constexpr(kQueue)
+					serial_push(p2g, s_queue, qn, left_b, pv_code[1], pv[1], mass, lane, info, next_grid);
+				else
+					p2g_serial(p2g, left_b, pv_code[1], pv[1], mass, lane, info, next_grid);
+			}
+		}
+		if(drain) break;
+		if constexpr(!kThreaded) {
+			if(idx0 + 128 >= size) break;// (no draining pass)
+		}
+		MPM_MARK("P_handoff");
+		if constexpr(kThreaded) {
+			const float am = sk.am;
+#pragma unroll
+			for(int h = 0; h < 2; ++h) {
+#pragma unroll
+				for(int d = 0; d < 3; ++d) {
+					pv[h].fd[d] = nfd[h][d];
+					pv[h].mv[d] = mass * vel[h][d];
+				}
+#pragma unroll
+				for(int d = 0; d < 9; ++d) pv[h].contrib[d] = fmaf(A[h][d], am, contrib[h][d]);
+				pv_code[h] = ncode[h];
+			}
+		}
+	}
+#ifdef MPM_G2P2G_STATS
+	if(lane == 0) {
+		atomicAdd(&status[24], st_iter);
+		atomicAdd(&status[25], st_losers);
+		atomicAdd(&status[26], st_edge);
+		atomicAdd(&status[27], st_split);// (the pair kernel reports its split pairs where the one-particle kernel reports its iterations with a retry)
+		atomicAdd(&status[28], st_partial);
+		atomicAdd(&status[41], st_retry_iters);
+	}
+#endif
+	if constexpr(kQueue) {
+		if(qn) serial_flush(p2g, s_queue, qn, mass, lane, info, next_grid);
+	}
+	if(lane == 0) mv.keep[b] = settled ? size : -1;
+	__syncthreads();
+	int lane_wb = lane;
+	__asm__ volatile("" : "+v"(lane_wb));
+	const int cx = lane_wb >> 4, cy = (lane_wb >> 2) & 3, cz = lane_wb & 3;
+#pragma unroll
+	for(int lb = 0; lb < 8; ++lb) {
+		int sel = 54 + lb;
+		__asm__ volatile("" : "+s"(sel));
+		const int nb = __shfl(info, sel);
+		const int ax = cx + ((lb & 4) ? 4 : 0) - 1, ay = cy + ((lb & 2) ? 4 : 0) - 1, az = cz + ((lb & 1) ? 4 : 0) - 1;
+		const bool in = ((unsigned) ax < 6u) & ((unsigned) ay < 6u) & ((unsigned) az < 6u);
+		const int n	  = in ? ax * kP2GStrideX + ay * kP2GStrideY + az : 0;
+		const float4 va = p2g[n], vb = p2g[kP2GArena2 + n];
+		const float4 v	= make_float4(va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w);
+		if(in && nb >= 0) {
+			float* g = next_grid + (size_t) nb * 256 + lane_wb;
+			if(v.x != 0.f) unsafeAtomicAdd(g, v.x);
+			if(v.y != 0.f) unsafeAtomicAdd(g + 64, v.y);
+			if(v.z != 0.f) unsafeAtomicAdd(g + 128, v.z);
+			if(v.w != 0.f) unsafeAtomicAdd(g + 192, v.w);
+		}
+	}
+	__syncthreads();
+	}
+}
+
+}// namespace mpm

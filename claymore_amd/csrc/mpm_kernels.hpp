@@ -447,6 +447,7 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 
 }// namespace mpm
 #include "mpm_g2p2g.hpp"
+#include "mpm_g2p2g_pair.hpp"
 namespace mpm {
 
 // ------------------------------------------------------------------------------------------------------
