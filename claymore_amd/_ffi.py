@@ -110,6 +110,7 @@ HIP_ONLY = {
     "group_create_local": (_i, [_P(_vp), _i, _P(_vp)]),
     "group_destroy": (None, [_vp]),
     "group_last_error": (C.c_char_p, [_vp]),
+    "group_transport": (C.c_char_p, [_vp]),
     "group_initial_setup": (_i, [_vp]),
     "group_resume": (_i, [_vp]),
     "group_substep": (_i, [_vp, _f, _f, _fp]),

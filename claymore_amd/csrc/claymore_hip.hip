@@ -49,6 +49,8 @@ struct Model {
 	int* out_count	 = nullptr;
 	int* keep		 = nullptr;// per block of the numbering G2P2G ran in: its particle count if every particle stayed with an unchanged sort key, else -1
 	int* blockinfo	 = nullptr;// [block][kInfoRow], written by prepare_blocks_kernel
+	bool pair		 = false;  // the lists are in the pair layout (mpm_kernels.hpp) and G2P2G carries two particles per lane (mpm_g2p2g_pair.hpp)
+	int* pairinfo[2] = {nullptr, nullptr};// pair layout only, [block][kPairChunks]: [0] full pairs per chunk of a block's sorted list (written by the sort, read by G2P2G), [1] what G2P2G hands on to the next sort
 	int64_t bincount = 0;
 	int64_t bincount_src = 0;// bins in use in bins[rollid] (the source of the next g2p2g): the previous bincount
 	int64_t bucketed = 0;// particles currently in the advection lists (device-counted at each rebuild)
@@ -142,6 +144,22 @@ static float host_maxvel(const mpm_ctx* ctx) {
 	float m = 0.f;
 	for(int i = 0; i < kMaxVelSlots; ++i) m = std::max(m, ctx->h_maxvel[i * kMaxVelStride]);
 	return m;
+}
+
+// Which materials' G2P2G runs two particles per lane (bit m = material m; mpm_g2p2g_pair.hpp).  MPM_PAIR_BUILD: the instantiations compiled in;
+// MPM_PAIR_DEFAULT: the ones used unless the environment says otherwise (MPM_G2P2G_PAIRS=<mask>, read once: same-library A/B and tests).
+#ifndef MPM_PAIR_BUILD
+#define MPM_PAIR_BUILD 0xF
+#endif
+#ifndef MPM_PAIR_DEFAULT
+#define MPM_PAIR_DEFAULT 0xF
+#endif
+static int pair_mask() {
+	static const int mask = [] {
+		const char* e = std::getenv("MPM_G2P2G_PAIRS");
+		return (e && *e ? (int) std::strtol(e, nullptr, 0) : MPM_PAIR_DEFAULT) & MPM_PAIR_BUILD;
+	}();
+	return mask;
 }
 
 static int launch_prepare(mpm_ctx* ctx, int cur, int prev, bool list_is_out, int binoff_sel, const int* pbc_ptr, int nblocks_est, bool sort, bool publish);
@@ -320,6 +338,8 @@ void mpm_destroy(mpm_ctx* ctx) {
 	for(auto& m: ctx->models) {
 		hipFree(m.d_xyz);
 		hipFree(m.blockinfo);
+		hipFree(m.pairinfo[0]);
+		hipFree(m.pairinfo[1]);
 		for(int i = 0; i < 2; ++i) {
 			hipFree(m.bins[i]);
 			hipFree(m.binoff[i]);
@@ -516,6 +536,9 @@ int mpm_initial_setup(mpm_ctx* ctx) {
 		HIP_TRY(dalloc(&m.keep, cap + 1));
 		HIP_TRY(hipMemsetAsync(m.keep, 0xff, sizeof(int) * (cap + 1), s));
 		HIP_TRY(dalloc(&m.blockinfo, cap * (size_t) kInfoRow));
+		m.pair = ((pair_mask() >> m.material) & 1) != 0 && g.ppb <= kPairChunks * kListChunk;
+		if(m.pair)
+			for(int i = 0; i < 2; ++i) HIP_TRY(dalloc(&m.pairinfo[i], (cap + 1) * (size_t) kPairChunks));
 		HIP_TRY(hipMemsetAsync(m.out_count, 0, sizeof(int) * (cap + 1), s));
 		HIP_TRY(hipMemsetAsync(m.size, 0, sizeof(int) * (cap + 1), s));
 		if(m.n) bucket_particles_kernel<<<cdiv(m.n, 256), 256, 0, s>>>(g, m.n, m.d_xyz, P.table, m.out_count, m.list[1], ctx->d_status);
@@ -611,24 +634,10 @@ static ModelView make_view(mpm_ctx* ctx, Model& m) {
 	v.out_count	 = m.out_count;
 	v.keep		 = m.keep;
 	v.blockinfo	 = m.blockinfo;
+	v.pairinfo_in  = m.pairinfo[0];
+	v.pairinfo_out = m.pairinfo[1];
 	v.mc		 = m.mc;
 	return v;
-}
-
-// Which materials' G2P2G runs two particles per lane (bit m = material m; mpm_g2p2g_pair.hpp).  MPM_PAIR_BUILD: the instantiations compiled in;
-// MPM_PAIR_DEFAULT: the ones used unless the environment says otherwise (MPM_G2P2G_PAIRS=<mask>, read once: same-library A/B and tests).
-#ifndef MPM_PAIR_BUILD
-#define MPM_PAIR_BUILD 0xF
-#endif
-#ifndef MPM_PAIR_DEFAULT
-#define MPM_PAIR_DEFAULT 0x1
-#endif
-static int pair_mask() {
-	static const int mask = [] {
-		const char* e = std::getenv("MPM_G2P2G_PAIRS");
-		return (e && *e ? (int) std::strtol(e, nullptr, 0) : MPM_PAIR_DEFAULT) & MPM_PAIR_BUILD;
-	}();
-	return mask;
 }
 
 // a launch size for `n` (an estimate that may be a few substeps old) particle blocks: margin for growth, a multiple of 8 (XCDs)
@@ -656,10 +665,9 @@ static void launch_g2p2g_model(mpm_ctx* ctx, Model& m, const int* block_list, co
 	sk.jvisc	= g.dx * g.d_inv * m.mc.viscosity;
 	const int nwg = nblocks_ptr ? hint_blocks(ctx, nblocks) : nblocks;
 	// two particles per lane (mpm_g2p2g_pair.hpp) for the materials of pair_mask(); the others one particle per lane
-	const int pairs = pair_mask();
 #define MPM_LAUNCH_PAIR(M)                                                                                                                                                                      \
 	if constexpr((MPM_PAIR_BUILD >> M) & 1) {                                                                                                                                                   \
-		if((pairs >> M) & 1) {                                                                                                                                                                  \
+		if(m.pair) {                                                                                                                                                                            \
 			g2p2g_pair_kernel<M><<<nwg, kG2P2GThreads, 0, s>>>(ctx->g, v, cur_keys, ctx->grid[0], ctx->grid[1], block_list, only_flag, nblocks_ptr, nblocks, dt, next_dt, sk, ctx->d_status); \
 			return;                                                                                                                                                                             \
 		}                                                                                                                                                                                       \
@@ -749,6 +757,8 @@ static int launch_prepare(mpm_ctx* ctx, int cur, int prev, bool list_is_out, int
 		pm.binoff_src[mi] = m.binoff[binoff_sel];
 		pm.blockinfo[mi]  = m.blockinfo;
 		pm.keep[mi]		  = sort && list_is_out ? m.keep : nullptr;// (only the rebuild's call sorts lists G2P2G has just written)
+		pm.pairinfo[mi]	  = m.pair ? m.pairinfo[0] : nullptr;
+		pm.pairhand[mi]	  = m.pairinfo[1];
 	}
 	const int nwg = std::max(1, std::min(ctx->g.cap, nblocks_est + nblocks_est / 16 + 64));
 	int* pub	  = publish ? ctx->d_status : nullptr;
@@ -835,6 +845,8 @@ static int grow_capacity(mpm_ctx* ctx) {
 			HIP_TRY(regrow(&m.out_count, cap + 1, ncap + 1, s));
 			HIP_TRY(regrow(&m.keep, cap + 1, ncap + 1, s));
 			HIP_TRY(regrow(&m.blockinfo, cap * (size_t) kInfoRow, ncap * (size_t) kInfoRow, s));
+			if(m.pair)
+				for(int i = 0; i < 2; ++i) HIP_TRY(regrow(&m.pairinfo[i], (cap + 1) * (size_t) kPairChunks, (ncap + 1) * (size_t) kPairChunks, s));
 		}
 		if(ctx->d_overlap) {
 			HIP_TRY(regrow(&ctx->d_overlap, cap + 1, ncap + 1, s));
@@ -1201,7 +1213,7 @@ int mpm_retrieve_state(mpm_ctx* ctx, int model, float* xyz, float* state9, float
 	if(logjp) HIP_TRY(b_lj.alloc(cap));
 	float *d_state = b_state.p, *d_lj = b_lj.p;
 	HIP_TRY(hipMemsetAsync(ctx->d_counter, 0, sizeof(unsigned long long), s));
-	if(ctx->pbc) retrieve_kernel<<<ctx->pbc, 256, 0, s>>>(ctx->g, m.nch, ctx->part[r].keys, ctx->part[nn].table, m.size, m.row_of, m.list[m.list_in], m.binoff[r], m.bins[r], m.d_xyz, d_state, d_lj, (unsigned long long) cap, ctx->d_counter);
+	if(ctx->pbc) retrieve_kernel<<<ctx->pbc, 256, 0, s>>>(ctx->g, m.nch, ctx->part[r].keys, ctx->part[nn].table, m.size, m.row_of, m.list[m.list_in], m.binoff[r], m.bins[r], m.d_xyz, d_state, d_lj, (unsigned long long) cap, ctx->d_counter, m.pair ? 1 : 0);
 	unsigned long long count = 0;
 	HIP_TRY(hipMemcpyAsync(&count, ctx->d_counter, sizeof(count), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));

@@ -63,6 +63,8 @@ struct ModelView {
 	int* out_count;		  // append counters of list_out
 	int* keep;			  // per block: its size if every particle stayed with an unchanged sort key, else -1 (prepare_blocks_kernel skips the sort)
 	const int* blockinfo; // [block][kInfoRow]: source bin offsets, destination / grid block numbers (prepare_blocks_kernel)
+	const int* pairinfo_in;// pair layout (mpm_kernels.hpp): full pairs per chunk of a block's list, [block][kPairChunks]; null for the sliced layout
+	int* pairinfo_out;	   // a block hands its own on under its number (prepare_blocks_kernel: the next sort is skipped for a settled block)
 	MaterialConst mc;
 };
 

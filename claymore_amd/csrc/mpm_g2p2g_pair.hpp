@@ -1,16 +1,19 @@
-// mpm_g2p2g_pair.hpp — G2P2G with TWO particles of one stencil base per lane (round 6; the structural step DESIGN.md 7 / VERDICT r5 #1 ask for).
+// mpm_g2p2g_pair.hpp — G2P2G with TWO particles of one stencil base per lane (round 6; the structural step DESIGN.md 7 / VERDICT r5 #1 asked for).
 //
 // Same fused G2P + particle update + P2G as g2p2g_kernel (mpm_g2p2g.hpp; reference g2p2g, Projects/GMPM/mgmpm_kernels.cuh:665-937 with the
-// per-material bodies :422-663), same one-wave-per-block structure, same arenas, same list / bin formats.  What changes is the unit of an
-// iteration: a lane carries the records of TWO consecutive 64-slot slices of the block's sorted list - particle A = slot (2d, lane), particle
-// B = slot (2d + 1, lane).  The sort deals the records of one predicted stencil base to consecutive slices of one lane (wrap-around rule,
-// mpm_kernels.hpp), so A and B share their base wherever a cell holds an even run of particles - all of a resting lattice.  Then
-//   * the 27 gather nodes are read ONCE for both (27 ds_read_b128 per 128 particles instead of 54), when the whole wave's pairs share their base;
+// per-material bodies :422-663), same one-wave-per-block structure, same arenas and bin formats.  What changes is the unit of an iteration: a
+// lane carries a PAIR - two records of one predicted stencil base, which the sort hands out two by two (the pair layout of the advection lists,
+// mpm_kernels.hpp: pair slices, then the odd records of the keys as single slices).  Then
 //   * the two P2G contributions are summed in registers and take ONE read-modify-write per node: 27 pairs of ds_read_b128 / ds_write_b128 per 128
-//     particles instead of 54 - the scatter chain's 27 ordered LDS round trips serve twice the particles;
+//     particles instead of 54;
+//   * the 27 gather nodes are read ONCE for both when the whole wave's pairs share their base (J-fluid; the solid models' second set of gather
+//     accumulators does not fit 168 registers);
 //   * claims, exec brackets, slice arithmetic, list prefetch: once per 128 particles.
-// A pair whose members END the step with different bases (or whose B lost its A) splits: A takes the chain, B the serial path.
-// Cost: a second set of gather accumulators, payload and chain registers - the instantiation runs at two waves per SIMD.
+// A pair whose members END the step with different bases splits: A takes the chain, B the serial path (mispredictions only: < 1 %).
+// The pair scatters at the end of its OWN iteration, 27 steps back to back: no loop-carried payload, no chain state beside the gather, and so
+// 147-168 registers = three waves per SIMD.  (Measured, profiles/r06_ab_pairs_phase1.txt: the chain of pair i - 1 threaded through the update of
+// pair i, as g2p2g_kernel does for single particles, needs 231 registers = two waves per SIMD and is 8 % SLOWER than one particle per lane at four
+// waves; the unthreaded pair at three waves is 11 % faster - J-fluid, fixed-corotated and sand alike.)
 #pragma once
 #include "mpm_g2p2g.hpp"
 
@@ -19,15 +22,12 @@ namespace mpm {
 #if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_WAVES))
 #define MPM_PAIR_WAVES 3
 #endif
-// MPM_PAIR_THREADED 1: the scatter chain of pair i - 1 is threaded through the update of pair i (payloads and chain state are loop-carried:
-// 231 VGPRs for the J-fluid, two waves per SIMD); 0: the pair scatters at the end of its own iteration, 27 steps back to back (no loop-carried
-// payload, no chain state beside the gather: fewer registers, more waves to cover the exposed round trips)
-#if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_THREADED))
-#define MPM_PAIR_THREADED 0
-#endif
 // bit m: material m reads the 27 gather nodes once for both particles when the wave's pairs share their bases (else: one gather per particle)
+#if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_ONE_CHAIN))
+#define MPM_PAIR_ONE_CHAIN 1// 1: a single slice (no B) runs the pair chain with B weighted zero instead of its own one-particle chain (less code)
+#endif
 #if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_SHARED_GATHER))
-#define MPM_PAIR_SHARED_GATHER 0x1// (the solid models' second set of gather accumulators does not fit 168 registers: spills inside the loop, +60 %)
+#define MPM_PAIR_SHARED_GATHER 0x0// (the second set of gather accumulators does not fit 168 registers beside the slice bookkeeping: scratch operations inside the loop - every one drains the record prefetch - cost more than 27 LDS reads)
 #endif
 
 // Tensor-product APIC gather (gather_apic, mpm_g2p2g.hpp) for two particles that share their stencil base: every node is loaded once.
@@ -119,8 +119,8 @@ MPM_DEV void gather_apic_shared(const float4* __restrict__ gbase, const float (&
 // (ScatterChain, mpm_g2p2g.hpp).  `on` = false zeroes the x weights: the particle contributes nothing (its pair split).
 struct ChainHalf {
 	float pw[3][3];
-	float cx0, cy0, cz0, cz0x2;
-	v2f_ cx12, cy12, cz12, cz12x2;
+	float cx0, cy0, cz0;
+	v2f_ cx12, cy12, cz12;
 	float slab0, pen0, wij;
 	v2f_ slab12, pen12;
 	MPM_DEV void init(const P2GPayload& p, bool on) {
@@ -131,8 +131,6 @@ struct ChainHalf {
 		cx12 = (v2f_) {p.contrib[1], p.contrib[2]}, cy12 = (v2f_) {p.contrib[4], p.contrib[5]}, cz12 = (v2f_) {p.contrib[7], p.contrib[8]};
 		slab0  = p.mv[0] - cx0 * p.fd[0] - cy0 * p.fd[1] - cz0 * p.fd[2];
 		slab12 = (v2f_) {p.mv[1], p.mv[2]} - cx12 * p.fd[0] - cy12 * p.fd[1] - cz12 * p.fd[2];
-		cz0x2  = cz0 + cz0;
-		cz12x2 = cz12 + cz12;
 	}
 	MPM_DEV void add(int o, float mass, v2f_& a01, v2f_& a23) {// o: compile-time after unrolling
 		const int i = o / 9, j = (o / 3) % 3, k = o % 3;
@@ -151,8 +149,9 @@ struct ChainHalf {
 			wij = pw[0][i] * pw[1][j];
 		}
 		const float W  = wij * pw[2][k];
-		const v2f_ m0  = {mass, k == 0 ? pen0 : (k == 1 ? pen0 + cz0 : pen0 + cz0x2)};
-		const v2f_ t12 = k == 0 ? pen12 : (k == 1 ? pen12 + cz12 : pen12 + cz12x2);
+		// (k = 2: fma with the constant 2 - the doubled z row of ScatterChain would cost three registers per particle)
+		const v2f_ m0  = {mass, k == 0 ? pen0 : (k == 1 ? pen0 + cz0 : fmaf(2.f, cz0, pen0))};
+		const v2f_ t12 = k == 0 ? pen12 : (k == 1 ? pen12 + cz12 : cz12 * 2.f + pen12);
 		a01			   = m0 * W + a01;
 		a23			   = t12 * W + a23;
 	}
@@ -201,6 +200,7 @@ template<int MAT>
 __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_keys, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, const int* __restrict__ only_flag, const int* __restrict__ nblocks_ptr, int nblocks, float dt, float new_dt, StepConst sk, int* __restrict__ status) {
 	constexpr int NCH = MatTraits<MAT>::nch;
 	constexpr int REC = MatTraits<MAT>::rec;
+	constexpr bool kSharedGather = ((MPM_PAIR_SHARED_GATHER >> MAT) & 1) != 0;
 	__shared__ float4 g2p[kG2PNodes];
 	__shared__ float4 p2g[kP2GArena2 + kP2GNodes];
 	__shared__ unsigned char s_owner[2 * 216];
@@ -227,25 +227,49 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 	const int key_shift = cfg.pid_bits;
 	const int tag_shift = cfg.pid_bits + kKeyBits;
 	const int info		= mv.blockinfo[(size_t) b * kInfoRow + lane];
-	// ---- the list records of a pair iteration: slices (idx, idx + 64) of the sorted list.  B is absent when the block's last chunk has an odd
-	//      number of slices: the lane then re-reads A's record (same inputs, same results, stored to the same slot; never active).
-	struct Recs {
-		int rec[2];
-		int cnt[2];
-		int has_b;
+	const int pinfo		= mv.pairinfo_in[(size_t) b * kPairChunks + (lane & (kPairChunks - 1))];// full pairs of chunk (lane & 15); by block number: the same round trip as the scalars above
+	// ---- the slices of the block in the pair layout (mpm_kernels.hpp).  Lane t forms the descriptor of slice t (of slice 64 k + t in the k-th batch of
+	//      a block with more than 64 slices) once per block: position of A's first record in the block's list, lanes in use (0: beyond the end), pair
+	//      slice or single slice.  The loop reads the descriptor two slices ahead with v_readlane: no scalar cursor to carry (a scalar one took ~100
+	//      scalar instructions per iteration and ~25 live scalar registers, i.e. spills into vector registers).
+	const int nchunks = (size + kListChunk - 1) / kListChunk;
+	int d_pos = 0, d_cnt = 0;// d_cnt = lanes in use | pair slice << 8
+	auto form_slices = [&](int first) {// descriptors of slices first .. first + 63
+		int before = 0;// slices of the chunks before c (wave-uniform)
+		d_pos = 0, d_cnt = 0;
+		for(int c = 0; c < nchunks; ++c) {
+			const PairChunk pc = pair_chunk(chunk_records(size, c), __builtin_amdgcn_readlane(pinfo, c));
+			const int t		   = first + lane - before;
+			if(t >= 0 && t < pc.slices()) {
+				int pos, cnt, hb;
+				pair_slice(pc, t, pos, cnt, hb);
+				d_pos = c * kListChunk + pos;
+				d_cnt = cnt | (hb << 8);
+			}
+			before += pc.slices();
+		}
 	};
-	auto load_recs = [&](int idx, Recs& r) {
-		const bool in = idx < size;// (beyond the end: a harmless dummy, never processed)
-		const int ia  = in ? idx : 0;
-		r.cnt[0]	  = in ? slice_records_at(size, idx) : 1;
-		r.has_b		  = in && idx + 64 < size;
-		r.cnt[1]	  = r.has_b ? slice_records_at(size, idx + 64) : 0;
-		r.rec[0]	  = list[ia + min(lane, r.cnt[0] - 1)];
-		r.rec[1]	  = list[r.has_b ? ia + 64 + min(lane, r.cnt[1] - 1) : ia + min(lane, r.cnt[0] - 1)];
+	form_slices(0);
+	struct Slice {
+		int pos, cnt, has_b;// position of A's first record in the block's list; lanes in use (0: beyond the end); pair slice (B's records `cnt` behind A's)
 	};
-	Recs r_cur, r_next;
-	load_recs(0, r_cur);
-	load_recs(128, r_next);
+	auto read_slice = [&](int t, Slice& sl) {// t wave-uniform, inside the current batch
+		const int p = __builtin_amdgcn_readlane(d_pos, t & 63), c = __builtin_amdgcn_readlane(d_cnt, t & 63);
+		sl			= Slice {p, c & 255, c >> 8};
+	};
+	// (idle lanes re-read the slice's last record: same inputs, nothing stored; a single slice has no B: the lane re-reads A's record;
+	//  beyond the end: the block's first record, never processed)
+	auto load_recs = [&](const Slice& sl, int (&rec)[2]) {
+		const int l = min(lane, max(sl.cnt, 1) - 1);
+		rec[0]		= list[sl.pos + l];
+		rec[1]		= list[sl.pos + (sl.has_b ? sl.cnt : 0) + l];
+	};
+	Slice s_cur, s_next;
+	int rec_cur[2], rec_next[2];
+	read_slice(0, s_cur);
+	read_slice(1, s_next);
+	load_recs(s_cur, rec_cur);
+	load_recs(s_next, rec_next);
 	for(int i = lane; i < kP2GArena2 + kP2GNodes; i += 64) p2g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 	__syncthreads();
 	float4 gv[8];
@@ -282,8 +306,8 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 		}
 	};
 	Prefetch pf[2];
-	fetch(r_cur.rec[0], pf[0]);
-	fetch(r_cur.rec[1], pf[1]);
+	fetch(rec_cur[0], pf[0]);
+	fetch(rec_cur[1], pf[1]);
 #pragma unroll
 	for(int lb = 0; lb < 8; ++lb) {
 		const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
@@ -291,29 +315,18 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 		if(((unsigned) ax < 6u) & ((unsigned) ay < 6u) & ((unsigned) az < 6u)) g2p[ax * kG2PStrideX + ay * kG2PStrideY + az * kG2PStrideZ] = gv[lb];
 	}
 	__syncthreads();
-	constexpr bool kThreaded = MPM_PAIR_THREADED != 0;
-	constexpr bool kSharedGather = ((MPM_PAIR_SHARED_GATHER >> MAT) & 1) != 0;
-	P2GPayload pv[2];
-	int pv_code[2] = {-1, -1};
-	int qn		   = 0;
-	bool settled   = true;
+	int qn		 = 0;
+	bool settled = true;
 #ifdef MPM_G2P2G_STATS
 	int st_iter = 0, st_losers = 0, st_edge = 0, st_retry_iters = 0, st_partial = 0, st_split = 0;
 #endif
-	for(int idx0 = 0;; idx0 += 128) {
-		const bool drain = idx0 >= size;
-		bool win		 = false;
-		bool merge_b	 = false;
-		bool pv_in[2] = {pv_code[0] >= 0, pv_code[1] >= 0};
-		float contrib[2][9];// -P F^T vol new_dt D^-1 dx of this iteration's particles (the payload is formed at the hand-over)
-		float vel[2][3], A[2][9], nfd[2][3];
-		int ncode[2] = {-1, -1};
-		if(!drain) {
+	for(int t_cur = 0;; ++t_cur) {
 		MPM_MARK("P_top");
-		const bool active[2] = {lane < r_cur.cnt[0], lane < r_cur.cnt[1]};
-		const int pidib[2]	 = {idx0 + lane, r_cur.has_b ? idx0 + 64 + lane : idx0 + lane};// slot in the destination bins == position in the sorted order
+		const int has_b		 = s_cur.has_b;// (wave-uniform)
+		const bool active[2] = {lane < s_cur.cnt, has_b && lane < s_cur.cnt};
+		const int pidib[2]	 = {s_cur.pos + lane, s_cur.pos + s_cur.cnt + lane};// slot in the destination bins == position in the sorted order (B: pair slices only)
 #ifdef MPM_G2P2G_STATS
-		st_partial += __popcll(__ballot(!active[0])) + __popcll(__ballot(!active[1]));
+		st_partial += 64 - s_cur.cnt;
 #endif
 		float pos[2][3], st[2][7];
 		int okey[2];
@@ -331,17 +344,18 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 			}
 			okey[h] = pf[h].key;
 		}
-		// the list records two iterations ahead, the particle records one iteration ahead
-		Recs r_nn;
-		load_recs(idx0 + 256, r_nn);
-		fetch(r_next.rec[0], pf[0]);
-		fetch(r_next.rec[1], pf[1]);
-		const int hasb_now = r_cur.has_b;
-		r_cur			   = r_next;
-		r_next			   = r_nn;
+		// the list records two slices ahead, the particle records one slice ahead
+		Slice s_nn;
+		int rec_nn[2];
+		if(((t_cur + 2) & 63) == 0) form_slices(t_cur + 2);// (a block with more than 64 slices: the next batch of descriptors)
+		read_slice(t_cur + 2, s_nn);
+		load_recs(s_nn, rec_nn);
+		fetch(rec_next[0], pf[0]);
+		if(s_next.has_b) fetch(rec_next[1], pf[1]);
 		MPM_MARK("P_gather");
-		// ---- stencil bases + weights (:774-797), gather: the nodes are read once when every lane's pair shares its base
+		// ---- stencil bases + weights (:774-797), gather (:801-835)
 		int base[2][3], arena[2][3];
+		float vel[2][3], A[2][9];
 		{
 			float fd[2][3], w[2][3][3];
 			bool same = true;
@@ -357,39 +371,27 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 				}
 #pragma unroll
 			for(int d = 0; d < 3; ++d) same &= arena[0][d] == arena[1][d];
-			if(kSharedGather && __all(same)) {
+			if(kSharedGather && has_b && __all(same)) {
 				gather_apic_shared(g2p + (arena[0][0] - 1) * kG2PStrideX + (arena[0][1] - 1) * kG2PStrideY + (arena[0][2] - 1) * kG2PStrideZ, w, fd, vel, A);
 			} else {
+				gather_apic(g2p + (arena[0][0] - 1) * kG2PStrideX + (arena[0][1] - 1) * kG2PStrideY + (arena[0][2] - 1) * kG2PStrideZ, w[0], fd[0], vel[0], A[0]);
+				if(has_b) {
+					gather_apic(g2p + (arena[1][0] - 1) * kG2PStrideX + (arena[1][1] - 1) * kG2PStrideY + (arena[1][2] - 1) * kG2PStrideZ, w[1], fd[1], vel[1], A[1]);
+				} else {// a single slice: B is nobody - a payload of zeros (the pair chain multiplies it by a zero weight: it must be finite)
 #pragma unroll
-				for(int h = 0; h < 2; ++h) gather_apic(g2p + (arena[h][0] - 1) * kG2PStrideX + (arena[h][1] - 1) * kG2PStrideY + (arena[h][2] - 1) * kG2PStrideZ, w[h], fd[h], vel[h], A[h]);
+					for(int d = 0; d < 3; ++d) vel[1][d] = 0.f;
+#pragma unroll
+					for(int d = 0; d < 9; ++d) A[1][d] = 0.f;
+				}
 			}
 		}
-		// ---- claim the stencil base of the pair in flight: A claims; B rides with A when it has A's base
-		MPM_MARK("P_claim");
-		constexpr int kPreSites	   = 6;// chain sites in the re-bucketing of both particles
-		constexpr int kStressSites = MAT == 0 ? 1 : (MAT == 1 ? kFcSites : (MAT == 2 ? kSandSites : kNaccSites));
-		constexpr int kMatSites	   = kStressSites + 1;// per particle
-		constexpr int kSites	   = kPreSites + 2 * kMatSites + 1;
-		auto make_chain = [&]() {
-			if constexpr(kThreaded) {
-				const int pv_key = (pv_in[0] ? code_key(pv_code[0]) : 0) + (lane & 1) * 216;
-				if(pv_in[0]) s_owner[pv_key] = (unsigned char) lane;
-				__asm__ volatile("" ::: "memory");
-				win		= pv_in[0] && !code_edge(pv_code[0]) && (int) s_owner[pv_key] == lane;
-				merge_b = win && pv_in[1] && pv_code[1] == pv_code[0];
-				return ScatterChain2<kSites>(p2g + (win ? code_off(pv_code[0]) + (lane & 1) * kP2GArena2 : 0), pv[0], pv[1], mass, win, merge_b);
-			} else {
-				return NoHook {};
-			}
-		};
-		auto chain = make_chain();
 		MPM_MARK("P_rebucket");
 		// ---- advect (:838), new base, re-bucket (:852-866, add_advection particle_buffer.cuh:100-135)
+		float nfd[2][3];
 		int narena[2][3], dirv[2][3], pk[2][3];
 		bool in_arena[2];
 		const float pred = sk.pred;
-#pragma unroll
-		for(int h = 0; h < 2; ++h) {
+		auto rebucket = [&](int h) {
 			in_arena[h] = active[h];
 #pragma unroll
 			for(int d = 0; d < 3; ++d) {
@@ -403,10 +405,14 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 				const int step = (int) __builtin_rintf(fmaf(vel[h][d], pred, nfd[h][d]));
 				pk[h][d]	   = min(max(((narena[h][d] - 1) & 3) + step, 0), 5);
 			}
-			if(h == 0)
-				chain.template at<0>();
-			else
-				chain.template at<1>();
+		};
+		rebucket(0);
+		if(has_b) {
+			rebucket(1);
+		} else {
+			in_arena[1] = false;
+#pragma unroll
+			for(int d = 0; d < 3; ++d) dirv[1][d] = 0, pk[1][d] = 0, narena[1][d] = 0, nfd[1][d] = 0.f;
 		}
 		int ntag[2], dno[2], stay_rank[2], raw_move[2] = {0, 0};
 		bool stay[2];
@@ -414,8 +420,8 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 		int b_opaque = b;
 		__asm__("" : "+v"(b_opaque));
 		if(__all((dirv[0][0] | dirv[0][1] | dirv[0][2] | dirv[1][0] | dirv[1][1] | dirv[1][2]) == 0)) {
-			// every particle of the iteration stays in this block: one atomic for all of them
-			const int n_a = __popcll(__ballot(active[0])), n_b = __popcll(__ballot(active[1]));
+			// every particle of the iteration stays in this block: one atomic for all of them (the active lanes are the first lanes)
+			const int n_a = s_cur.cnt, n_b = has_b ? s_cur.cnt : 0;
 #pragma unroll
 			for(int h = 0; h < 2; ++h) {
 				ntag[h] = kStay;
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 				stay[h] = active[h];
 			}
 			stay_leader	 = 0;
-			stay_rank[0] = lane;// (the active lanes are the first lanes of a slice)
+			stay_rank[0] = lane;
 			stay_rank[1] = n_a + lane;
 			if(lane == 0) raw_stay = atomicAdd(&mv.out_count[b_opaque], n_a + n_b);
 		} else {
@@ -446,13 +452,11 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 			for(int h = 0; h < 2; ++h) {
 				if(dno[h] >= 0 && !stay[h]) raw_move[h] = atomicAdd(&mv.out_count[dno[h]], 1);
 				if(active[h]) {
-					if(dno[h] < 0) atomicAdd(&status[ST_LOST], 1);
-					if(!in_arena[h]) atomicAdd(&status[ST_ARENA], 1);
+					if(dno[h] < 0) atomicAdd(&status[ST_LOST], 1);// reference: particle silently lost (particle_buffer.cuh:105-113)
+					if(!in_arena[h]) atomicAdd(&status[ST_ARENA], 1);// (:877-885) contribution discarded
 				}
 			}
 		}
-		chain.template at<2>();
-		chain.template at<3>();
 		int pkey[2], rec[2];
 #pragma unroll
 		for(int h = 0; h < 2; ++h) {
@@ -460,20 +464,17 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 			rec[h]	= (ntag[h] << tag_shift) | (pkey[h] << key_shift) | pidib[h];
 		}
 		settled = settled && __all((!active[0] || (stay[0] && pkey[0] == okey[0])) && (!active[1] || (stay[1] && pkey[1] == okey[1])));
-		chain.template at<4>();
-		chain.template at<5>();
 		MPM_MARK("P_material");
-		// ---- material update, store to the destination bin (:470-663); B absent: same slot, same values as A
+		// ---- material update, store to the destination bin (:470-663)
+		float contrib[2][9];// -P F^T vol new_dt D^-1 dx
+		NoHook nohook;
 		auto material = [&](auto hc) {
-			constexpr int H	   = decltype(hc)::value;
-			constexpr int BASE = kPreSites + H * kMatSites;
-			float* dbin		   = mv.bins_dst + (size_t) (binoff_dst + (pidib[H] >> 6)) * (kBin * NCH);
-			float4* dst		   = reinterpret_cast<float4*>(dbin + (pidib[H] & 63) * REC);
+			constexpr int H = decltype(hc)::value;
+			float* dbin		= mv.bins_dst + (size_t) (binoff_dst + (pidib[H] >> 6)) * (kBin * NCH);
+			float4* dst		= reinterpret_cast<float4*>(dbin + (pidib[H] & 63) * REC);
 			if constexpr(MAT == 0) {
-				chain.template at<BASE + 0>();
 				const float J = stress_jfluid(mv.mc, sk.ss.vol, sk.jdiv, sk.jvisc, st[H][0], A[H], contrib[H]);
-				chain.template at<BASE + 1>();
-				dst[0] = make_float4(pos[H][0], pos[H][1], pos[H][2], J);
+				if(active[H]) dst[0] = make_float4(pos[H][0], pos[H][1], pos[H][2], J);
 			} else {
 				float G[9], bo[6], bn[6];
 #pragma unroll
@@ -491,30 +492,26 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 					}
 				}
 				push_forward(G, bo, bn);
-				chain.template at<BASE + 0>();
 				float lj = 0.f;
 				if constexpr(MAT == 1) {
-					stress_fixed_corotated<BASE + 1>(sk.ss, bn, refl, contrib[H], chain);
+					stress_fixed_corotated<0>(sk.ss, bn, refl, contrib[H], nohook);
 				} else if constexpr(MAT == 2) {
 					lj = st[H][6];
-					stress_sand<BASE + 1>(mv.mc, sk.ss, bn, refl, lj, contrib[H], chain);
+					stress_sand<0>(mv.mc, sk.ss, bn, refl, lj, contrib[H], nohook);
 				} else {
 					lj = st[H][6];
-					stress_nacc<BASE + 1>(mv.mc, sk.ss, bn, refl, lj, contrib[H], chain);
+					stress_nacc<0>(mv.mc, sk.ss, bn, refl, lj, contrib[H], nohook);
 				}
-				dst[0] = make_float4(pos[H][0], pos[H][1], pos[H][2], refl ? -bn[0] : bn[0]);
-				dst[1] = make_float4(bn[1], bn[2], bn[3], bn[4]);
-				if constexpr(ROW == 1) dbin[kBin * REC + (pidib[H] & 63)] = bn[5];
-				if constexpr(ROW == 2) reinterpret_cast<float2*>(dbin + kBin * REC)[pidib[H] & 63] = make_float2(bn[5], lj);
+				if(active[H]) {
+					dst[0] = make_float4(pos[H][0], pos[H][1], pos[H][2], refl ? -bn[0] : bn[0]);
+					dst[1] = make_float4(bn[1], bn[2], bn[3], bn[4]);
+					if constexpr(ROW == 1) dbin[kBin * REC + (pidib[H] & 63)] = bn[5];
+					if constexpr(ROW == 2) reinterpret_cast<float2*>(dbin + kBin * REC)[pidib[H] & 63] = make_float2(bn[5], lj);
+				}
 			}
 		};
 		material(std::integral_constant<int, 0> {});
-		material(std::integral_constant<int, 1> {});
-		MPM_MARK("P_contrib");
-		chain.template at<kSites - 1>();
-#pragma unroll
-		for(int h = 0; h < 2; ++h) ncode[h] = in_arena[h] ? (narena[h][0] | (narena[h][1] << 4) | (narena[h][2] << 8)) : -1;
-		(void) hasb_now;
+		if(has_b) material(std::integral_constant<int, 1> {});
 		MPM_MARK("P_append");
 		{
 			const int basev = __shfl(raw_stay, stay_leader);
@@ -523,14 +520,18 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 				if(dno[h] >= 0) {
 					const int slot = stay[h] ? basev + stay_rank[h] : raw_move[h];
 					if(slot >= cfg.ppb)
-						atomicOr(&status[ST_OVERFLOW], 2);
+						atomicOr(&status[ST_OVERFLOW], 2);// reference drops beyond 128 per cell (:122-130)
 					else
 						mv.list_out[((size_t) dno[h] << cfg.pid_bits) + slot] = rec[h];
 				}
 			}
 		}
-		if constexpr(!kThreaded) {
-			// ---- the pair scatters now: payload (:850), claim, 27 steps back to back
+		MPM_MARK("P_scatter");
+		// ---- the pair scatters now (:887-905): payload ((:850) contrib = (A m - stress new_dt) D^-1, times dx: cell units), claim, 27 steps back to back
+		P2GPayload pv[2];
+		int pv_code[2];
+		bool pv_in[2];
+		{
 			const float am = sk.am;
 #pragma unroll
 			for(int h = 0; h < 2; ++h) {
@@ -540,74 +541,73 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 					pv[h].mv[d] = mass * vel[h][d];
 				}
 #pragma unroll
-				for(int d = 0; d < 9; ++d) pv[h].contrib[d] = fmaf(A[h][d], am, contrib[h][d]);
-				pv_code[h] = ncode[h];
-				pv_in[h]   = ncode[h] >= 0;
+				for(int d = 0; d < 9; ++d) pv[h].contrib[d] = h == 0 || has_b ? fmaf(A[h][d], am, contrib[h][d]) : 0.f;// (contrib[1] is not formed in a single slice)
+				pv_code[h] = in_arena[h] ? (narena[h][0] | (narena[h][1] << 4) | (narena[h][2] << 8)) : -1;
+				pv_in[h]   = pv_code[h] >= 0;
 			}
-			const int pv_key = (pv_in[0] ? code_key(pv_code[0]) : 0) + (lane & 1) * 216;
-			if(pv_in[0]) s_owner[pv_key] = (unsigned char) lane;
-			__asm__ volatile("" ::: "memory");
-			win		= pv_in[0] && !code_edge(pv_code[0]) && (int) s_owner[pv_key] == lane;
-			merge_b = win && pv_in[1] && pv_code[1] == pv_code[0];
-			ScatterChain2<1> now(p2g + (win ? code_off(pv_code[0]) + (lane & 1) * kP2GArena2 : 0), pv[0], pv[1], mass, win, merge_b);
-			now.template at<0>();
 		}
-		} else if(kThreaded && pv_in[0]) {
-			// draining pass: the last pairs' winners run the 27 steps back to back
-			const int pv_key = code_key(pv_code[0]) + (lane & 1) * 216;
-			s_owner[pv_key]	 = (unsigned char) lane;
-			__asm__ volatile("" ::: "memory");
-			win		= !code_edge(pv_code[0]) && (int) s_owner[pv_key] == lane;
-			merge_b = win && pv_in[1] && pv_code[1] == pv_code[0];
-			ScatterChain2<1> chain(p2g + (win ? code_off(pv_code[0]) + (lane & 1) * kP2GArena2 : 0), pv[0], pv[1], mass, win, merge_b);
-			chain.template at<0>();
-		}
+		const int pv_key = (pv_in[0] ? code_key(pv_code[0]) : 0) + (lane & 1) * 216;// even / odd lanes: separate arenas, separate claims
+		if(pv_in[0]) s_owner[pv_key] = (unsigned char) lane;
+		__asm__ volatile("" ::: "memory");// another lane may have written the same byte: no store-to-load forwarding
+		const bool win	   = pv_in[0] && !code_edge(pv_code[0]) && (int) s_owner[pv_key] == lane;
+		const bool merge_b = win && pv_in[1] && pv_code[1] == pv_code[0];
 		MPM_MARK("P_serial");
-		// ---- what the chain did not take: A without a claim or on the cube's edge, B split from its A
+		// ---- what the chain will not take - A without a claim or on the cube's edge, B split from its A - goes first: the payloads are dead once the
+		//      chain is set up (both add into the arenas with plain read-modify-writes; a single wave's LDS operations execute in program order)
 		{
 			const bool left_a = pv_in[0] && !win;
 			const bool left_b = pv_in[1] && !merge_b;
 #ifdef MPM_G2P2G_STATS
-			if(!drain) {
-				st_iter += 1;
-				st_losers += __popcll(__ballot(left_a && !code_edge(pv_code[0]))) + __popcll(__ballot(left_b && !code_edge(pv_code[1]) && !left_a));
-				st_edge += __popcll(__ballot(pv_in[0] && code_edge(pv_code[0]))) + __popcll(__ballot(pv_in[1] && code_edge(pv_code[1])));
-				st_split += __popcll(__ballot(left_b && win));
-				st_retry_iters += __any(left_a || left_b) ? 1 : 0;
-			}
+			st_iter += 1;
+			st_losers += __popcll(__ballot(left_a && !code_edge(pv_code[0]))) + __popcll(__ballot(left_b && !code_edge(pv_code[1]) && !win));
+			st_edge += __popcll(__ballot(pv_in[0] && code_edge(pv_code[0]))) + __popcll(__ballot(pv_in[1] && code_edge(pv_code[1])));
+			st_split += __popcll(__ballot(left_b && win && !code_edge(pv_code[1])));
+			st_retry_iters += __any(left_a || left_b) ? 1 : 0;
 #endif
-			if(__any(left_a)) {
+#if defined(MPM_EXPERIMENT) && defined(MPM_HACK_NOSERIAL)// timing experiment only: what the chain does not take is dropped (wrong physics)
+			if(false)
+#else
+			if(__any(left_a))
+#endif
+			{
 				if constexpr(kQueue)
 					serial_push(p2g, s_queue, qn, left_a, pv_code[0], pv[0], mass, lane, info, next_grid);
 				else
 					p2g_serial(p2g, left_a, pv_code[0], pv[0], mass, lane, info, next_grid);
 			}
-			if(__any(left_b)) {
+#if defined(MPM_EXPERIMENT) && defined(MPM_HACK_NOSERIAL)
+			if(false)
+#else
+			if(__any(left_b))
+#endif
+			{
 				if constexpr(kQueue)
 					serial_push(p2g, s_queue, qn, left_b, pv_code[1], pv[1], mass, lane, info, next_grid);
 				else
 					p2g_serial(p2g, left_b, pv_code[1], pv[1], mass, lane, info, next_grid);
 			}
 		}
-		if(drain) break;
-		if constexpr(!kThreaded) {
-			if(idx0 + 128 >= size) break;// (no draining pass)
+		MPM_MARK("P_chain");
+		float4* const node0 = p2g + (win ? code_off(pv_code[0]) + (lane & 1) * kP2GArena2 : 0);
+#if MPM_PAIR_ONE_CHAIN
+		{
+			ScatterChain2<1> chain(node0, pv[0], pv[1], mass, win, merge_b);
+			chain.template at<0>();
 		}
-		MPM_MARK("P_handoff");
-		if constexpr(kThreaded) {
-			const float am = sk.am;
-#pragma unroll
-			for(int h = 0; h < 2; ++h) {
-#pragma unroll
-				for(int d = 0; d < 3; ++d) {
-					pv[h].fd[d] = nfd[h][d];
-					pv[h].mv[d] = mass * vel[h][d];
-				}
-#pragma unroll
-				for(int d = 0; d < 9; ++d) pv[h].contrib[d] = fmaf(A[h][d], am, contrib[h][d]);
-				pv_code[h] = ncode[h];
-			}
+#else
+		if(has_b) {
+			ScatterChain2<1> chain(node0, pv[0], pv[1], mass, win, merge_b);
+			chain.template at<0>();
+		} else {
+			ScatterChain<1> chain(node0, pv[0], mass, win);
+			chain.template at<0>();
 		}
+#endif
+		if(s_next.cnt == 0) break;
+		s_cur  = s_next;
+		s_next = s_nn;
+#pragma unroll
+		for(int h = 0; h < 2; ++h) rec_next[h] = rec_nn[h];
 	}
 #ifdef MPM_G2P2G_STATS
 	if(lane == 0) {
@@ -623,7 +623,10 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 		if(qn) serial_flush(p2g, s_queue, qn, mass, lane, info, next_grid);
 	}
 	if(lane == 0) mv.keep[b] = settled ? size : -1;
+	// if nobody leaves or arrives, row b of list_out holds the records in THIS layout: hand the pair counts on under the block's number
+	if(lane < kPairChunks) mv.pairinfo_out[(size_t) b * kPairChunks + lane] = pinfo;
 	__syncthreads();
+	// ---- arena -> next grid (:907-936), as in g2p2g_kernel
 	int lane_wb = lane;
 	__asm__ volatile("" : "+v"(lane_wb));
 	const int cx = lane_wb >> 4, cy = (lane_wb >> 2) & 3, cz = lane_wb & 3;

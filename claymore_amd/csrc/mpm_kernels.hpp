@@ -140,6 +140,21 @@ __device__ __forceinline__ int block_append(int* counter, int amount) {
 // The slots behind a slice's records are holes (never read); a block still occupies ceil(size / 64) * 64 slots.
 // ------------------------------------------------------------------------------------------------------
 constexpr int kListChunk = 512;
+// The PAIR layout (round 6; models whose G2P2G carries two particles per lane, mpm_g2p2g_pair.hpp).  A chunk with n records of which Pf
+// are full pairs - two records of one sort key - and n1 = n - 2 Pf singles (the odd record of a key) is laid out DENSE, in this order:
+//   S2 = ceil(Pf / 64) pair slices, slice d holding c_d = Pf / S2 + (d < Pf % S2) pairs: the c_d first members, then the c_d second members
+//       (pair q in key-major order goes to slice q mod S2, lane q / S2: the wrap-around rule on pairs - a key's pairs land in consecutive
+//       slices, a slice holds a key twice only if the key has more than S2 pairs, and then in neighbouring lanes);
+//   S1 = ceil(n1 / 64) single slices, slice s holding n1 / S1 + (s < n1 % S1) records (distinct keys by construction).
+// No holes: position == slot in the destination bins == slot in the list, a block occupies exactly `size` slots, and the order G2P2G
+// appends the staying particles in IS this layout whatever the shape of the chunk (the sort is skipped for every settled block).
+// The one number a reader needs beside the block's size is Pf per chunk: pairinfo[block][chunk], kPairChunks ints per block, indexed by the
+// block's number like the look-up row (G2P2G fetches both in its first round trip; indexed by the list row it would be a round trip later).
+constexpr int kPairChunks = 16;// chunks per list row the pair layout supports (ppb <= 8192 = the reference's 128 particles per cell)
+struct PairChunk {// the slices of one chunk in the pair layout (all wave-uniform)
+	int n, pf, n1, s2, s1, qp, rp, q1, r1;
+	__device__ __forceinline__ int slices() const { return s2 + s1; }
+};
 __device__ __forceinline__ int div_small(int n, int d) {// n / d for 0 <= n <= 512, 1 <= d <= 8 (exact, checked exhaustively)
 	// ceil(65536 / d) for d = 2..8 as 16-bit fields of two constants: a division by a run-time d, even a wave-uniform one, is ~40 scalar
 	// instructions of reciprocal refinement, and G2P2G forms a slice length in every iteration
@@ -149,6 +164,33 @@ __device__ __forceinline__ int div_small(int n, int d) {// n / d for 0 <= n <= 5
 }
 __device__ __forceinline__ int chunk_records(int size, int chunk) {
 	return min(kListChunk, size - chunk * kListChunk);
+}
+__device__ __forceinline__ PairChunk pair_chunk(int n, int pf) {
+	PairChunk c;
+	c.n	 = n;
+	c.pf = pf;
+	c.n1 = n - 2 * pf;
+	c.s2 = (pf + 63) >> 6;
+	c.s1 = (c.n1 + 63) >> 6;
+	c.qp = c.s2 ? div_small(pf, c.s2) : 0;
+	c.rp = pf - c.qp * c.s2;
+	c.q1 = c.s1 ? div_small(c.n1, c.s1) : 0;
+	c.r1 = c.n1 - c.q1 * c.s1;
+	return c;
+}
+// slice t of the chunk: position of its first record relative to the chunk, lanes in use, and whether it is a pair slice (the second
+// members then sit `cnt` slots behind the first)
+__device__ __forceinline__ void pair_slice(const PairChunk& c, int t, int& pos, int& cnt, int& has_b) {
+	if(t < c.s2) {
+		cnt	  = c.qp + (t < c.rp ? 1 : 0);
+		pos	  = 2 * (t * c.qp + min(t, c.rp));
+		has_b = 1;
+	} else {
+		const int s = t - c.s2;
+		cnt			= c.q1 + (s < c.r1 ? 1 : 0);
+		pos			= 2 * c.pf + s * c.q1 + min(s, c.r1);
+		has_b		= 0;
+	}
 }
 __device__ __forceinline__ int slice_records(int n, int s) {// records in slice s of a chunk with n records
 	const int S = (n + 63) >> 6;
@@ -271,23 +313,29 @@ __global__ __launch_bounds__(256) void grid_update_collision_kernel(GridCfg cfg,
 
 // ---- checkpoint helpers (mpm_checkpoint.inc) ----
 // advection-list rows <-> one packed array: block b's size[b] records live at packed[offset[b] ...)
-__global__ __launch_bounds__(64) void pack_lists_kernel(int ppb, const int* __restrict__ size, const int* __restrict__ row_of, const long long* __restrict__ offset, const int* __restrict__ list, int* __restrict__ packed) {
+// (dense: the pair layout, whose rows have no holes; pairinfo: its per-chunk pair counts, kPairChunks ints per row)
+__global__ __launch_bounds__(64) void pack_lists_kernel(int ppb, const int* __restrict__ size, const int* __restrict__ row_of, const long long* __restrict__ offset, const int* __restrict__ list, int* __restrict__ packed, int dense, const int* __restrict__ pairinfo, int* __restrict__ packed_info) {
 	const int b = blockIdx.x;
 	const int n = size[b];
 	const int* row = list + (size_t) row_of[b] * ppb;
 	for(int i = threadIdx.x; i < n; i += 64) {
 		const int chunk = i / kListChunk;
-		packed[offset[b] + i] = row[chunk * kListChunk + chunk_slot(chunk_records(n, chunk), i - chunk * kListChunk)];
+		packed[offset[b] + i] = dense ? row[i] : row[chunk * kListChunk + chunk_slot(chunk_records(n, chunk), i - chunk * kListChunk)];
 	}
+	if(dense && threadIdx.x < kPairChunks) packed_info[(size_t) b * kPairChunks + threadIdx.x] = pairinfo[(size_t) b * kPairChunks + threadIdx.x];
 }
-__global__ __launch_bounds__(64) void unpack_lists_kernel(int ppb, const int* __restrict__ size, int* __restrict__ row_of, const long long* __restrict__ offset, int* __restrict__ list, const int* __restrict__ packed) {
+__global__ __launch_bounds__(64) void unpack_lists_kernel(int ppb, const int* __restrict__ size, int* __restrict__ row_of, const long long* __restrict__ offset, int* __restrict__ list, const int* __restrict__ packed, int dense, int* __restrict__ pairinfo, const int* __restrict__ packed_info) {
 	const int b = blockIdx.x;
 	const int n = size[b];
 	int* row	= list + (size_t) b * ppb;// rows are re-seated at their own block number
 	for(int i = threadIdx.x; i < n; i += 64) {
 		const int chunk = i / kListChunk;
-		row[chunk * kListChunk + chunk_slot(chunk_records(n, chunk), i - chunk * kListChunk)] = packed[offset[b] + i];
+		if(dense)
+			row[i] = packed[offset[b] + i];
+		else
+			row[chunk * kListChunk + chunk_slot(chunk_records(n, chunk), i - chunk * kListChunk)] = packed[offset[b] + i];
 	}
+	if(dense && threadIdx.x < kPairChunks) pairinfo[(size_t) b * kPairChunks + threadIdx.x] = packed_info[(size_t) b * kPairChunks + threadIdx.x];
 	if(threadIdx.x == 0) row_of[b] = b;
 }
 // dense table from a key list (the inverse of what compact / register build incrementally)
@@ -329,6 +377,8 @@ struct PrepareModels {
 	const int* binoff_src[kMaxModels];	// bin offsets in the numbering the particle data is laid out in (previous partition)
 	int* blockinfo[kMaxModels];
 	const int* keep[kMaxModels];// (may be null) G2P2G's verdict per block of the PREVIOUS numbering: see prepare_blocks_kernel
+	int* pairinfo[kMaxModels];	// non-null: the model's lists are in the pair layout; [block][kPairChunks] full pairs per chunk, written with the sort
+	const int* pairhand[kMaxModels];// ... and what G2P2G handed on under the block's PREVIOUS number (a settled block keeps its order and its pair counts)
 };
 // The launch is sized by a host-side ESTIMATE of the particle block count (the host does not wait for the rebuild's counts,
 // mpm_run_fixed); the true count is read from device memory and a workgroup walks over blocks b, b + gridDim.x, ... (one trip
@@ -341,6 +391,8 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 	__shared__ int s_sorted[kPrepChunk];
 	__shared__ int s_cnt[256];// per key (216 used): count, then first position of the key in key-major order
 	const int lane = threadIdx.x;
+	// (MPM_GROUP_OVERLAP_TAG=1 runs the tagging kernels - halo_mark_all / halo_split_dev - on the comm stream BESIDE this kernel: they read
+	//  ST_NBC / ST_PBC only and must never read what is published here, ST_EBC and *part_count)
 	if(publish && blockIdx.x == 0 && lane == 0) {
 		const int ebc	 = publish[ST_CNT_P] + publish[ST_CNT_N] + publish[ST_CNT_E];
 		publish[ST_EBC] = ebc;
@@ -377,7 +429,8 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 		// number), and the order G2P2G appended them in IS the sliced layout: slice after slice without holes, i.e. full chunks and a last
 		// chunk of full slices or of a single one.  A column at rest is all such blocks but its surface.
 		const int tail	= size & (kPrepChunk - 1);
-		const bool same = pm.keep[m] && size > 0 && pm.keep[m][row] == size && (tail <= 64 || (tail & 63) == 0);
+		int* pairinfo	= pm.pairinfo[m] ? pm.pairinfo[m] + (size_t) b * kPairChunks : nullptr;// (pair layout: settled blocks keep their order whatever their shape)
+		const bool same = pm.keep[m] && size > 0 && pm.keep[m][row] == size && (pairinfo || tail <= 64 || (tail & 63) == 0);
 		constexpr int NIT = kPrepChunk / 64;
 		unsigned recs[NIT];
 		auto load_chunk = [&](int chunk0, int nrec) {// unconditional, clamped: all loads of a chunk are in flight together
@@ -432,9 +485,80 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 				if(it < S && lane < slice_records(nrec, it)) list[chunk0 + it * 64 + lane] = s_sorted[it * 64 + lane];
 			__syncthreads();
 		};
+		// The pair layout (top of this file): records of one key are dealt out two by two, the odd one of a key goes to the single slices.
+		auto sort_chunk_pairs = [&](int chunk0, int nrec) {
+#pragma unroll
+			for(int q = 0; q < 4; ++q) s_cnt[lane + 64 * q] = 0;
+			__syncthreads();
+			int rank[NIT];
+#pragma unroll
+			for(int it = 0; it < NIT; ++it) {
+				rank[it] = 0;
+				if(it * 64 + lane < nrec) rank[it] = atomicAdd(&s_cnt[(recs[it] >> key_shift) & 255], 1);
+			}
+			__syncthreads();
+			int pf, n1;
+			{// per key: its count, and the exclusive prefix sums of the full pairs and the singles before it (one packed scan)
+				int c[4], v[4];
+#pragma unroll
+				for(int i = 0; i < 4; ++i) {
+					c[i] = s_cnt[4 * lane + i];
+					v[i] = (c[i] >> 1) | ((c[i] & 1) << 16);
+				}
+				int incl = v[0] + v[1] + v[2] + v[3];
+#pragma unroll
+				for(int off = 1; off < 64; off <<= 1) {
+					const int u = __shfl_up(incl, off);
+					if(lane >= off) incl += u;
+				}
+				const int tot = __shfl(incl, 63);
+				pf			  = tot & 0xffff;
+				n1			  = tot >> 16;
+				int excl	  = incl - (v[0] + v[1] + v[2] + v[3]);
+#pragma unroll
+				for(int i = 0; i < 4; ++i) {
+					s_cnt[4 * lane + i] = (excl & 0x3ff) | ((excl >> 16) << 10) | (c[i] << 18);// full pairs before the key (<= 256) | singles before it (<= 216) | records of the key (<= 512)
+					excl += v[i];
+				}
+			}
+			__syncthreads();
+			const PairChunk pc = pair_chunk(nrec, pf);
+			(void) n1;
+#pragma unroll
+			for(int it = 0; it < NIT; ++it) {
+				if(it * 64 + lane < nrec) {
+					const unsigned rec = recs[it] & rec_mask;
+					const int e		   = s_cnt[(rec >> key_shift) & 255];
+					const int nk	   = e >> 18;
+					const int r		   = rank[it];
+					int pos;
+					if(r < (nk & ~1)) {
+						const int q	 = (e & 0x3ff) + (r >> 1);
+						const int ln = div_small(q, pc.s2), d = q - ln * pc.s2;
+						const int cd = pc.qp + (d < pc.rp ? 1 : 0);
+						pos			 = 2 * (d * pc.qp + min(d, pc.rp)) + (r & 1) * cd + ln;
+					} else {
+						const int j	 = (e >> 10) & 0xff;
+						const int ln = div_small(j, pc.s1), sl = j - ln * pc.s1;
+						pos			 = 2 * pc.pf + sl * pc.q1 + min(sl, pc.r1) + ln;
+					}
+					s_sorted[pos] = (int) rec;
+				}
+			}
+			__syncthreads();
+#pragma unroll
+			for(int it = 0; it < NIT; ++it)
+				if(it * 64 + lane < nrec) list[chunk0 + it * 64 + lane] = s_sorted[it * 64 + lane];
+			if(lane == 0) pairinfo[chunk0 / kPrepChunk] = pf;
+			__syncthreads();
+		};
+		if(pairinfo && same && lane < kPairChunks) pairinfo[lane] = pm.pairhand[m][(size_t) row * kPairChunks + lane];
 		for(int chunk0 = 0; chunk0 < size && !same; chunk0 += kPrepChunk) {
 			if(chunk0) load_chunk(chunk0, min(kPrepChunk, size - chunk0));
-			sort_chunk(chunk0, min(kPrepChunk, size - chunk0));
+			if(pairinfo)
+				sort_chunk_pairs(chunk0, min(kPrepChunk, size - chunk0));
+			else
+				sort_chunk(chunk0, min(kPrepChunk, size - chunk0));
 		}
 		}
 		if constexpr(!SORT) {
@@ -781,14 +905,14 @@ __global__ void rasterize_kernel(GridCfg cfg, size_t n, const float* __restrict_
 // ------------------------------------------------------------------------------------------------------
 // Output: retrieve_particle_buffer, mgmpm_kernels.cuh:1087-1122 (+ state for the parity tests)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void retrieve_kernel(GridCfg cfg, int nch, const int* __restrict__ cur_keys, const int* __restrict__ prev_table, const int* __restrict__ size, const int* __restrict__ row_of, const int* __restrict__ list_in, const int* __restrict__ binoff_src, const float* __restrict__ bins_src, float* xyz, float* state9, float* logjp, unsigned long long capacity, unsigned long long* counter) {
+__global__ __launch_bounds__(256) void retrieve_kernel(GridCfg cfg, int nch, const int* __restrict__ cur_keys, const int* __restrict__ prev_table, const int* __restrict__ size, const int* __restrict__ row_of, const int* __restrict__ list_in, const int* __restrict__ binoff_src, const float* __restrict__ bins_src, float* xyz, float* state9, float* logjp, unsigned long long capacity, unsigned long long* counter, int dense) {
 	const int b = blockIdx.x;
 	const int n = size[b];
 	if(n == 0) return;
 	const int kx = cur_keys[3 * b], ky = cur_keys[3 * b + 1], kz = cur_keys[3 * b + 2];
 	const int* list = list_in + (size_t) row_of[b] * cfg.ppb;
 	for(int pidib = threadIdx.x; pidib < ((n + 63) & ~63); pidib += blockDim.x) {
-		if((pidib & 63) >= slice_records_at(n, pidib & ~63)) continue;// a hole of the sliced list layout
+		if(dense ? pidib >= n : (pidib & 63) >= slice_records_at(n, pidib & ~63)) continue;// a hole of the sliced list layout (the pair layout has none)
 		const int rec = list[pidib];
 		int ox, oy, oz;
 		dir_components((rec >> (cfg.pid_bits + kKeyBits)) & 31, ox, oy, oz);

@@ -302,6 +302,10 @@ int mpm_group_create(mpm_ctx* ctx, int rank, int world, const void* id128, mpm_g
 int mpm_group_create_local(mpm_ctx* const* ctxs, int world, mpm_group** out /* [world] */);
 void mpm_group_destroy(mpm_group* g);
 const char* mpm_group_last_error(const mpm_group* g);
+/* The transport the group ended up with: "rccl", "peer-direct" (one process, several devices, hipMemcpyPeerAsync behind the peer's events:
+ * the reference's own mechanism, halo_buffer.cuh:54-59) or "device-copy" (contexts of one device, or a pair of devices without peer access:
+ * synchronous copies behind host barriers).  A caller that asked for peer-direct reports the fall-back with it. */
+const char* mpm_group_transport(const mpm_group* g);
 /* initial_setup of every rank + first tagging + one exchange that sums the rasterised grids (mgsp_benchmark.cuh:561-659). */
 int mpm_group_initial_setup(mpm_group* g);
 /* Restart (row f4 for the multi-GPU loop; the reference has none): after EVERY rank has loaded its own checkpoint with

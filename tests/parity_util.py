@@ -100,3 +100,29 @@ def grid_compare(res):
             continue
         worst = max(worst, float((np.abs(bh[i] - bo[j]) / scale[:, None]).max()))
     return worst
+
+
+def grid_velocity_compare(res, mass_floor=1e-3):
+    """Node-by-node comparison of the grid VELOCITIES (momentum / mass per node, keys matched; north_star: "positions/velocities ... within
+    1e-5"; the reference's particles carry no velocity, it lives on the grid: mgmpm_kernels.cuh:325-420).  Nodes lighter than mass_floor of
+    the heaviest node are skipped (a quotient of two rounding residues); the result is relative to the largest |v| on the oracle's grid."""
+    kh, bh = res["hip"]["grid"]
+    ko, bo = res["oracle"]["grid"]
+    mh = {tuple(k): i for i, k in enumerate(kh)}
+    mmax = float(np.abs(bo[:, 0]).max())
+    heavy_o = bo[:, 0] > mass_floor * mmax                                       # (blocks, 64 cells)
+    vo_all = bo[:, 1:].astype(np.float64) / np.where(heavy_o, bo[:, 0], 1.0).astype(np.float64)[:, None, :]
+    vmax = float(np.abs(np.where(heavy_o[:, None, :], vo_all, 0.0)).max())
+    worst = 0.0
+    for j, k in enumerate(ko):
+        i = mh.get(tuple(k))
+        if i is None:
+            assert np.all(bo[j] == 0), "oracle has a non-empty grid block the HIP grid lacks"
+            continue
+        heavy = heavy_o[j]
+        if not heavy.any():
+            continue
+        vo = bo[j][1:][:, heavy].astype(np.float64) / bo[j][0][heavy].astype(np.float64)
+        vh = bh[i][1:][:, heavy].astype(np.float64) / bh[i][0][heavy].astype(np.float64)
+        worst = max(worst, float(np.abs(vh - vo).max()))
+    return worst / max(vmax, 1e-30)

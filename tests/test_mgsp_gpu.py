@@ -413,9 +413,11 @@ def test_full_size_c5_fluid_dam_8_ranks():
     assert abs(com[0] - com0[0]) < 2e-8 and abs(com[2] - com0[2]) < 2e-8
 
 
-@pytest.mark.parametrize("material,transport", [(_ffi.SAND, "in-process"), (_ffi.FIXED_COROTATED, "in-process"), (_ffi.SAND, "peer")])
+@pytest.mark.parametrize("material,transport", [(_ffi.SAND, "in-process"), (_ffi.FIXED_COROTATED, "in-process"), (_ffi.SAND, "peer"), (_ffi.SAND, "peer-tightpad")])
 def test_cpp_group_equals_single_engine(material, transport, monkeypatch):
-    """("peer": the peer-direct transport's code path - hipMemcpyPeerAsync behind the peer's event on the comm stream, no host
+    """("peer-tightpad", ADVICE r5: the recovery of a truncated key list - re-tag behind the two G2P2G passes, collect again - on the hub's ASYNCHRONOUS
+    exchange and key all-gather, where the ev_done / ev_kdone ordering matters as well; until now only the rccl double ran it.)
+    ("peer": the peer-direct transport's code path - hipMemcpyPeerAsync behind the peer's event on the comm stream, no host
     synchronisation in the exchange or the key all-gather - with all contexts on the one GPU; MPM_GROUP_TRANSPORT is read when the group is made.)
     N ranks against ONE rank of the same engine: the static particle partition changes block numbering, sort order and the
     order of the float additions on shared grid blocks, and nothing else - every per-particle decision (Jacobi sweeps included: the
@@ -425,10 +427,14 @@ def test_cpp_group_equals_single_engine(material, transport, monkeypatch):
     if material == _ffi.SAND:
         for m in sc["models"]:
             m["params"] = {}
-    if transport == "peer":
+    if transport.startswith("peer"):
         monkeypatch.setenv("MPM_GROUP_TRANSPORT", "peer")
     else:
         monkeypatch.delenv("MPM_GROUP_TRANSPORT", raising=False)
+    if transport.endswith("tightpad"):
+        monkeypatch.setenv("MPM_GROUP_PAD_TIGHT", "1")
+    else:
+        monkeypatch.delenv("MPM_GROUP_PAD_TIGHT", raising=False)
     nsteps = 150
     one = run_engine(sc, nsteps, 1e-4)
     for world in (2, 3):
@@ -487,7 +493,7 @@ def rccl_double_library(tmp_path_factory):
 
 
 @pytest.mark.parametrize("world,kind", [(2, "fixed"), (3, "substeps"), (4, "fixed"), (2, "adaptive"), (3, "fixed-nodefer"), (4, "fixed-big"), (8, "fixed-big"), (4, "fixed-big-sync"), (8, "fixed-big-sync"), (2, "plate"), (2, "plate-fall"), (3, "resume"),
-                                        (4, "fixed-big-tightpad"), (4, "fixed-big-tightpad-nodefer")])
+                                        (4, "fixed-big-tightpad"), (4, "fixed-big-tightpad-nodefer"), (4, "fixed-big-overlaptag")])
 def test_rccl_transport_with_several_ranks_through_the_rccl_double(world, kind, rccl_double_library):
     """The RCCL branch of the group driver with world > 1 (RCCL itself cannot host two ranks on one device, the box has one GPU):
     every rank a thread with its own context, mpm_group_create with a unique id, the grouped ncclSend / ncclRecv of the halo exchange,
@@ -501,6 +507,9 @@ def test_rccl_transport_with_several_ranks_through_the_rccl_double(world, kind, 
     import subprocess
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, MPM_RCCL_LIBRARY=rccl_double_library)
+    if kind.endswith("-overlaptag"):   # the optional overlap of the tagging chain with the rebuild's last kernel (MPM_GROUP_OVERLAP_TAG=1) ran in no test
+        env["MPM_GROUP_OVERLAP_TAG"] = "1"
+        kind = kind[:-11]
     if kind.endswith("-sync"):    # the double's other mode: every call synchronises the host (a mutant of the driver without the comm stream's wait for the
         env["RCCL_DOUBLE_SYNC"] = "1"   # collect kernel fails here at once, in the stream-ordered mode only sometimes: profiles/r04_double_mutants.txt)
         kind = kind[:-5]
