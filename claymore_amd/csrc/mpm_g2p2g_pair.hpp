@@ -23,9 +23,6 @@ namespace mpm {
 #define MPM_PAIR_WAVES 3
 #endif
 // bit m: material m reads the 27 gather nodes once for both particles when the wave's pairs share their bases (else: one gather per particle)
-#if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_ONE_CHAIN))
-#define MPM_PAIR_ONE_CHAIN 1// 1: a single slice (no B) runs the pair chain with B weighted zero instead of its own one-particle chain (less code)
-#endif
 #if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_SHARED_GATHER))
 #define MPM_PAIR_SHARED_GATHER 0x0// (the second set of gather accumulators does not fit 168 registers beside the slice bookkeeping: scratch operations inside the loop - every one drains the record prefetch - cost more than 27 LDS reads)
 #endif
@@ -233,36 +230,35 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 	//      slice or single slice.  The loop reads the descriptor two slices ahead with v_readlane: no scalar cursor to carry (a scalar one took ~100
 	//      scalar instructions per iteration and ~25 live scalar registers, i.e. spills into vector registers).
 	const int nchunks = (size + kListChunk - 1) / kListChunk;
-	int d_pos = 0, d_cnt = 0;// d_cnt = lanes in use | pair slice << 8
+	int d_pos = 0, d_cnt = 0;// d_cnt = lanes with an A | lanes with a B << 8
 	auto form_slices = [&](int first) {// descriptors of slices first .. first + 63
 		int before = 0;// slices of the chunks before c (wave-uniform)
 		d_pos = 0, d_cnt = 0;
 		for(int c = 0; c < nchunks; ++c) {
 			const PairChunk pc = pair_chunk(chunk_records(size, c), __builtin_amdgcn_readlane(pinfo, c));
 			const int t		   = first + lane - before;
-			if(t >= 0 && t < pc.slices()) {
-				int pos, cnt, hb;
-				pair_slice(pc, t, pos, cnt, hb);
+			if(t >= 0 && t < pc.S) {
+				int pos, ca, cb;
+				pair_slice(pc, t, pos, ca, cb);
 				d_pos = c * kListChunk + pos;
-				d_cnt = cnt | (hb << 8);
+				d_cnt = ca | (cb << 8);
 			}
-			before += pc.slices();
+			before += pc.S;
 		}
 	};
 	form_slices(0);
 	struct Slice {
-		int pos, cnt, has_b;// position of A's first record in the block's list; lanes in use (0: beyond the end); pair slice (B's records `cnt` behind A's)
+		int pos, cnt, cnt_b;// position of A's first record in the block's list; lanes with an A (0: beyond the end); lanes with a B (the first ones; B's records `cnt` behind A's)
 	};
 	auto read_slice = [&](int t, Slice& sl) {// t wave-uniform, inside the current batch
 		const int p = __builtin_amdgcn_readlane(d_pos, t & 63), c = __builtin_amdgcn_readlane(d_cnt, t & 63);
 		sl			= Slice {p, c & 255, c >> 8};
 	};
-	// (idle lanes re-read the slice's last record: same inputs, nothing stored; a single slice has no B: the lane re-reads A's record;
+	// (idle lanes re-read the last record of their member's run: same inputs, nothing stored; a slice without B's: the lane re-reads A's record;
 	//  beyond the end: the block's first record, never processed)
 	auto load_recs = [&](const Slice& sl, int (&rec)[2]) {
-		const int l = min(lane, max(sl.cnt, 1) - 1);
-		rec[0]		= list[sl.pos + l];
-		rec[1]		= list[sl.pos + (sl.has_b ? sl.cnt : 0) + l];
+		rec[0] = list[sl.pos + min(lane, max(sl.cnt, 1) - 1)];
+		rec[1] = list[sl.pos + (sl.cnt_b ? sl.cnt + min(lane, sl.cnt_b - 1) : min(lane, max(sl.cnt, 1) - 1))];
 	};
 	Slice s_cur, s_next;
 	int rec_cur[2], rec_next[2];
@@ -295,7 +291,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 		const int sbin	  = __shfl(info, tag) + (sp >> 6);
 		const float* bin  = mv.bins_src + (size_t) sbin * (kBin * NCH);
 		const float4* src = reinterpret_cast<const float4*>(bin + (sp & 63) * REC);
-		f.key			  = (rec >> key_shift) & 255;
+		f.key			  = ((rec >> key_shift) & 255) | ((rec >> kArenaBit) & 1) << 8;// sort key | the slot's scatter arena (pair layout, mpm_kernels.hpp)
 #pragma unroll
 		for(int d = 0; d < REC / 4; ++d) f.q[d] = src[d];
 		if constexpr(ROW == 1) f.row[0] = bin[kBin * REC + (sp & 63)];
@@ -322,11 +318,13 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 #endif
 	for(int t_cur = 0;; ++t_cur) {
 		MPM_MARK("P_top");
-		const int has_b		 = s_cur.has_b;// (wave-uniform)
-		const bool active[2] = {lane < s_cur.cnt, has_b && lane < s_cur.cnt};
-		const int pidib[2]	 = {s_cur.pos + lane, s_cur.pos + s_cur.cnt + lane};// slot in the destination bins == position in the sorted order (B: pair slices only)
+		const bool active[2] = {lane < s_cur.cnt, lane < s_cur.cnt_b};
+		// slot in the destination bins == position in the sorted order.  An idle lane carries a copy of the last record of its member's run (of A's, in a
+		// slice without B's) and stores the same values to the same slot: the stores stay out of divergent control flow, and A's and B's instruction
+		// streams stay in ONE basic block - the scheduler interleaves them (with B's half behind wave-uniform branches the kernel was 8 % slower at rest)
+		const int pidib[2] = {s_cur.pos + min(lane, s_cur.cnt - 1), s_cur.pos + (s_cur.cnt_b ? s_cur.cnt + min(lane, s_cur.cnt_b - 1) : min(lane, s_cur.cnt - 1))};
 #ifdef MPM_G2P2G_STATS
-		st_partial += 64 - s_cur.cnt;
+		st_partial += 128 - s_cur.cnt - s_cur.cnt_b;
 #endif
 		float pos[2][3], st[2][7];
 		int okey[2];
@@ -342,8 +340,9 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 				st[h][5] = pf[h].row[0];
 				if constexpr(ROW == 2) st[h][6] = pf[h].row[1];
 			}
-			okey[h] = pf[h].key;
+			okey[h] = pf[h].key & 255;
 		}
+		const int arena_sel = pf[0].key >> 8;// the slot's scatter arena
 		// the list records two slices ahead, the particle records one slice ahead
 		Slice s_nn;
 		int rec_nn[2];
@@ -351,7 +350,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 		read_slice(t_cur + 2, s_nn);
 		load_recs(s_nn, rec_nn);
 		fetch(rec_next[0], pf[0]);
-		if(s_next.has_b) fetch(rec_next[1], pf[1]);
+		fetch(rec_next[1], pf[1]);
 		MPM_MARK("P_gather");
 		// ---- stencil bases + weights (:774-797), gather (:801-835)
 		int base[2][3], arena[2][3];
@@ -371,18 +370,11 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 				}
 #pragma unroll
 			for(int d = 0; d < 3; ++d) same &= arena[0][d] == arena[1][d];
-			if(kSharedGather && has_b && __all(same)) {
+			if(kSharedGather && __all(same)) {
 				gather_apic_shared(g2p + (arena[0][0] - 1) * kG2PStrideX + (arena[0][1] - 1) * kG2PStrideY + (arena[0][2] - 1) * kG2PStrideZ, w, fd, vel, A);
 			} else {
-				gather_apic(g2p + (arena[0][0] - 1) * kG2PStrideX + (arena[0][1] - 1) * kG2PStrideY + (arena[0][2] - 1) * kG2PStrideZ, w[0], fd[0], vel[0], A[0]);
-				if(has_b) {
-					gather_apic(g2p + (arena[1][0] - 1) * kG2PStrideX + (arena[1][1] - 1) * kG2PStrideY + (arena[1][2] - 1) * kG2PStrideZ, w[1], fd[1], vel[1], A[1]);
-				} else {// a single slice: B is nobody - a payload of zeros (the pair chain multiplies it by a zero weight: it must be finite)
 #pragma unroll
-					for(int d = 0; d < 3; ++d) vel[1][d] = 0.f;
-#pragma unroll
-					for(int d = 0; d < 9; ++d) A[1][d] = 0.f;
-				}
+				for(int h = 0; h < 2; ++h) gather_apic(g2p + (arena[h][0] - 1) * kG2PStrideX + (arena[h][1] - 1) * kG2PStrideY + (arena[h][2] - 1) * kG2PStrideZ, w[h], fd[h], vel[h], A[h]);
 			}
 		}
 		MPM_MARK("P_rebucket");
@@ -391,7 +383,8 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 		int narena[2][3], dirv[2][3], pk[2][3];
 		bool in_arena[2];
 		const float pred = sk.pred;
-		auto rebucket = [&](int h) {
+#pragma unroll
+		for(int h = 0; h < 2; ++h) {
 			in_arena[h] = active[h];
 #pragma unroll
 			for(int d = 0; d < 3; ++d) {
@@ -405,14 +398,6 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 				const int step = (int) __builtin_rintf(fmaf(vel[h][d], pred, nfd[h][d]));
 				pk[h][d]	   = min(max(((narena[h][d] - 1) & 3) + step, 0), 5);
 			}
-		};
-		rebucket(0);
-		if(has_b) {
-			rebucket(1);
-		} else {
-			in_arena[1] = false;
-#pragma unroll
-			for(int d = 0; d < 3; ++d) dirv[1][d] = 0, pk[1][d] = 0, narena[1][d] = 0, nfd[1][d] = 0.f;
 		}
 		int ntag[2], dno[2], stay_rank[2], raw_move[2] = {0, 0};
 		bool stay[2];
@@ -421,7 +406,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 		__asm__("" : "+v"(b_opaque));
 		if(__all((dirv[0][0] | dirv[0][1] | dirv[0][2] | dirv[1][0] | dirv[1][1] | dirv[1][2]) == 0)) {
 			// every particle of the iteration stays in this block: one atomic for all of them (the active lanes are the first lanes)
-			const int n_a = s_cur.cnt, n_b = has_b ? s_cur.cnt : 0;
+			const int n_a = s_cur.cnt, n_b = s_cur.cnt_b;
 #pragma unroll
 			for(int h = 0; h < 2; ++h) {
 				ntag[h] = kStay;
@@ -461,7 +446,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 #pragma unroll
 		for(int h = 0; h < 2; ++h) {
 			pkey[h] = pk[h][1] * 36 + pk[h][0] * 6 + pk[h][2];
-			rec[h]	= (ntag[h] << tag_shift) | (pkey[h] << key_shift) | pidib[h];
+			rec[h]	= (ntag[h] << tag_shift) | (pkey[h] << key_shift) | pidib[h] | (arena_sel << kArenaBit);// (the arena bit matters only if the block stays settled: the next sort is then skipped)
 		}
 		settled = settled && __all((!active[0] || (stay[0] && pkey[0] == okey[0])) && (!active[1] || (stay[1] && pkey[1] == okey[1])));
 		MPM_MARK("P_material");
@@ -474,7 +459,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 			float4* dst		= reinterpret_cast<float4*>(dbin + (pidib[H] & 63) * REC);
 			if constexpr(MAT == 0) {
 				const float J = stress_jfluid(mv.mc, sk.ss.vol, sk.jdiv, sk.jvisc, st[H][0], A[H], contrib[H]);
-				if(active[H]) dst[0] = make_float4(pos[H][0], pos[H][1], pos[H][2], J);
+				dst[0] = make_float4(pos[H][0], pos[H][1], pos[H][2], J);
 			} else {
 				float G[9], bo[6], bn[6];
 #pragma unroll
@@ -502,16 +487,14 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 					lj = st[H][6];
 					stress_nacc<0>(mv.mc, sk.ss, bn, refl, lj, contrib[H], nohook);
 				}
-				if(active[H]) {
-					dst[0] = make_float4(pos[H][0], pos[H][1], pos[H][2], refl ? -bn[0] : bn[0]);
-					dst[1] = make_float4(bn[1], bn[2], bn[3], bn[4]);
-					if constexpr(ROW == 1) dbin[kBin * REC + (pidib[H] & 63)] = bn[5];
-					if constexpr(ROW == 2) reinterpret_cast<float2*>(dbin + kBin * REC)[pidib[H] & 63] = make_float2(bn[5], lj);
-				}
+				dst[0] = make_float4(pos[H][0], pos[H][1], pos[H][2], refl ? -bn[0] : bn[0]);
+				dst[1] = make_float4(bn[1], bn[2], bn[3], bn[4]);
+				if constexpr(ROW == 1) dbin[kBin * REC + (pidib[H] & 63)] = bn[5];
+				if constexpr(ROW == 2) reinterpret_cast<float2*>(dbin + kBin * REC)[pidib[H] & 63] = make_float2(bn[5], lj);
 			}
 		};
 		material(std::integral_constant<int, 0> {});
-		if(has_b) material(std::integral_constant<int, 1> {});
+		material(std::integral_constant<int, 1> {});
 		MPM_MARK("P_append");
 		{
 			const int basev = __shfl(raw_stay, stay_leader);
@@ -541,12 +524,12 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 					pv[h].mv[d] = mass * vel[h][d];
 				}
 #pragma unroll
-				for(int d = 0; d < 9; ++d) pv[h].contrib[d] = h == 0 || has_b ? fmaf(A[h][d], am, contrib[h][d]) : 0.f;// (contrib[1] is not formed in a single slice)
+				for(int d = 0; d < 9; ++d) pv[h].contrib[d] = fmaf(A[h][d], am, contrib[h][d]);
 				pv_code[h] = in_arena[h] ? (narena[h][0] | (narena[h][1] << 4) | (narena[h][2] << 8)) : -1;
 				pv_in[h]   = pv_code[h] >= 0;
 			}
 		}
-		const int pv_key = (pv_in[0] ? code_key(pv_code[0]) : 0) + (lane & 1) * 216;// even / odd lanes: separate arenas, separate claims
+		const int pv_key = (pv_in[0] ? code_key(pv_code[0]) : 0) + arena_sel * 216;// two arenas, two claim tables: the sort says which one a slot uses
 		if(pv_in[0]) s_owner[pv_key] = (unsigned char) lane;
 		__asm__ volatile("" ::: "memory");// another lane may have written the same byte: no store-to-load forwarding
 		const bool win	   = pv_in[0] && !code_edge(pv_code[0]) && (int) s_owner[pv_key] == lane;
@@ -588,21 +571,11 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 			}
 		}
 		MPM_MARK("P_chain");
-		float4* const node0 = p2g + (win ? code_off(pv_code[0]) + (lane & 1) * kP2GArena2 : 0);
-#if MPM_PAIR_ONE_CHAIN
+		float4* const node0 = p2g + (win ? code_off(pv_code[0]) + arena_sel * kP2GArena2 : 0);
 		{
 			ScatterChain2<1> chain(node0, pv[0], pv[1], mass, win, merge_b);
 			chain.template at<0>();
 		}
-#else
-		if(has_b) {
-			ScatterChain2<1> chain(node0, pv[0], pv[1], mass, win, merge_b);
-			chain.template at<0>();
-		} else {
-			ScatterChain<1> chain(node0, pv[0], mass, win);
-			chain.template at<0>();
-		}
-#endif
 		if(s_next.cnt == 0) break;
 		s_cur  = s_next;
 		s_next = s_nn;

@@ -140,20 +140,26 @@ __device__ __forceinline__ int block_append(int* counter, int amount) {
 // The slots behind a slice's records are holes (never read); a block still occupies ceil(size / 64) * 64 slots.
 // ------------------------------------------------------------------------------------------------------
 constexpr int kListChunk = 512;
-// The PAIR layout (round 6; models whose G2P2G carries two particles per lane, mpm_g2p2g_pair.hpp).  A chunk with n records of which Pf
-// are full pairs - two records of one sort key - and n1 = n - 2 Pf singles (the odd record of a key) is laid out DENSE, in this order:
-//   S2 = ceil(Pf / 64) pair slices, slice d holding c_d = Pf / S2 + (d < Pf % S2) pairs: the c_d first members, then the c_d second members
-//       (pair q in key-major order goes to slice q mod S2, lane q / S2: the wrap-around rule on pairs - a key's pairs land in consecutive
-//       slices, a slice holds a key twice only if the key has more than S2 pairs, and then in neighbouring lanes);
-//   S1 = ceil(n1 / 64) single slices, slice s holding n1 / S1 + (s < n1 % S1) records (distinct keys by construction).
-// No holes: position == slot in the destination bins == slot in the list, a block occupies exactly `size` slots, and the order G2P2G
-// appends the staying particles in IS this layout whatever the shape of the chunk (the sort is skipped for every settled block).
-// The one number a reader needs beside the block's size is Pf per chunk: pairinfo[block][chunk], kPairChunks ints per block, indexed by the
-// block's number like the look-up row (G2P2G fetches both in its first round trip; indexed by the list row it would be a round trip later).
+// The PAIR layout (round 6; models whose G2P2G carries two particles per lane, mpm_g2p2g_pair.hpp).  A chunk with n records is cut into
+// S = ceil(n / 128) slices - one G2P2G iteration each, the fewest there can be - of up to 64 LANE SLOTS; a slot holds a first member A and, most
+// of them, a second member B.  With Pf full pairs (two records of one sort key) and n1 = n - 2 Pf singles (the odd record of a key) the slots are,
+// in this order:
+//   Pf pair slots        in key-major order: both members share their predicted stencil base, G2P2G sums their P2G contributions in registers;
+//   X  mismatched slots  X = max(0, Pf + n1 - 64 S): when the singles do not all fit a slot of their own, the last 2 X of them share slots two by
+//                        two (different keys: the second member splits from the first and takes the serial path);
+//   n1 - 2 X single slots (A only).
+// Slot p goes to slice p mod S, lane p / S (the wrap-around rule on slots: a key's pairs land in consecutive slices, a slice holds a key twice only
+// if the key has more than S pairs), so in every slice the lanes with a B are the first ones.  A slice is stored DENSE: its A records, then its B
+// records; slices one behind the other.  No holes: position == slot in the destination bins == slot in the list, a block occupies exactly `size`
+// slots, and the order G2P2G appends the staying particles in IS this layout whatever the shape of the chunk (the sort is skipped for every
+// settled block).  The scatter arena of a slot is a bit of its records (kArenaBit): lane parity for the pair slots (a key's two pair slots of one
+// slice sit in neighbouring lanes), and for a single the arena its key's pair slot of the same slice does NOT use - a key's single never competes
+// with its own pairs.  The one number a reader needs beside the block's size is Pf per chunk: pairinfo[block][chunk], kPairChunks ints per block,
+// indexed by the block's number like the look-up row (G2P2G fetches both in its first round trip).
 constexpr int kPairChunks = 16;// chunks per list row the pair layout supports (ppb <= 8192 = the reference's 128 particles per cell)
+constexpr int kArenaBit	  = 30;// (records are {tag 5, key 8, slot <= 13} = 26 bits)
 struct PairChunk {// the slices of one chunk in the pair layout (all wave-uniform)
-	int n, pf, n1, s2, s1, qp, rp, q1, r1;
-	__device__ __forceinline__ int slices() const { return s2 + s1; }
+	int n, pf, S, px, L, qb, rb, qa, ra;// px = slots with a B (Pf + X), L = slots; q / r: quotient and remainder of px and L by S
 };
 __device__ __forceinline__ int div_small(int n, int d) {// n / d for 0 <= n <= 512, 1 <= d <= 8 (exact, checked exhaustively)
 	// ceil(65536 / d) for d = 2..8 as 16-bit fields of two constants: a division by a run-time d, even a wave-uniform one, is ~40 scalar
@@ -167,30 +173,26 @@ __device__ __forceinline__ int chunk_records(int size, int chunk) {
 }
 __device__ __forceinline__ PairChunk pair_chunk(int n, int pf) {
 	PairChunk c;
-	c.n	 = n;
-	c.pf = pf;
-	c.n1 = n - 2 * pf;
-	c.s2 = (pf + 63) >> 6;
-	c.s1 = (c.n1 + 63) >> 6;
-	c.qp = c.s2 ? div_small(pf, c.s2) : 0;
-	c.rp = pf - c.qp * c.s2;
-	c.q1 = c.s1 ? div_small(c.n1, c.s1) : 0;
-	c.r1 = c.n1 - c.q1 * c.s1;
+	c.n			 = n;
+	c.pf		 = pf;
+	c.S			 = (n + 127) >> 7;
+	const int n1 = n - 2 * pf;
+	const int x	 = max(0, pf + n1 - 64 * c.S);
+	c.px		 = pf + x;
+	c.L			 = pf + n1 - x;
+	c.qb		 = div_small(c.px, c.S);
+	c.rb		 = c.px - c.qb * c.S;
+	c.qa		 = div_small(c.L, c.S);
+	c.ra		 = c.L - c.qa * c.S;
 	return c;
 }
-// slice t of the chunk: position of its first record relative to the chunk, lanes in use, and whether it is a pair slice (the second
-// members then sit `cnt` slots behind the first)
-__device__ __forceinline__ void pair_slice(const PairChunk& c, int t, int& pos, int& cnt, int& has_b) {
-	if(t < c.s2) {
-		cnt	  = c.qp + (t < c.rp ? 1 : 0);
-		pos	  = 2 * (t * c.qp + min(t, c.rp));
-		has_b = 1;
-	} else {
-		const int s = t - c.s2;
-		cnt			= c.q1 + (s < c.r1 ? 1 : 0);
-		pos			= 2 * c.pf + s * c.q1 + min(s, c.r1);
-		has_b		= 0;
-	}
+// slice t of the chunk: position of its first record relative to the chunk, lanes with an A, lanes with a B (the first ones; their records sit
+// `cnt_a` slots behind the A records)
+template<class I>
+__device__ __forceinline__ void pair_slice(const PairChunk& c, I t, I& pos, I& cnt_a, I& cnt_b) {
+	cnt_a = c.qa + (t < c.ra ? 1 : 0);
+	cnt_b = c.qb + (t < c.rb ? 1 : 0);
+	pos	  = t * (c.qa + c.qb) + min(t, (I) c.ra) + min(t, (I) c.rb);
 }
 __device__ __forceinline__ int slice_records(int n, int s) {// records in slice s of a chunk with n records
 	const int S = (n + 63) >> 6;
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 				if(it * 64 + lane < nrec) rank[it] = atomicAdd(&s_cnt[(recs[it] >> key_shift) & 255], 1);
 			}
 			__syncthreads();
-			int pf, n1;
+			int pf;
 			{// per key: its count, and the exclusive prefix sums of the full pairs and the singles before it (one packed scan)
 				int c[4], v[4];
 #pragma unroll
@@ -513,7 +515,6 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 				}
 				const int tot = __shfl(incl, 63);
 				pf			  = tot & 0xffff;
-				n1			  = tot >> 16;
 				int excl	  = incl - (v[0] + v[1] + v[2] + v[3]);
 #pragma unroll
 				for(int i = 0; i < 4; ++i) {
@@ -523,26 +524,41 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 			}
 			__syncthreads();
 			const PairChunk pc = pair_chunk(nrec, pf);
-			(void) n1;
+			const int n1s	   = pc.L - pc.px;// singles with a slot of their own (the last n1 - n1s singles share the mismatched slots two by two)
 #pragma unroll
 			for(int it = 0; it < NIT; ++it) {
 				if(it * 64 + lane < nrec) {
-					const unsigned rec = recs[it] & rec_mask;
-					const int e		   = s_cnt[(rec >> key_shift) & 255];
-					const int nk	   = e >> 18;
-					const int r		   = rank[it];
-					int pos;
-					if(r < (nk & ~1)) {
-						const int q	 = (e & 0x3ff) + (r >> 1);
-						const int ln = div_small(q, pc.s2), d = q - ln * pc.s2;
-						const int cd = pc.qp + (d < pc.rp ? 1 : 0);
-						pos			 = 2 * (d * pc.qp + min(d, pc.rp)) + (r & 1) * cd + ln;
+					unsigned rec = recs[it] & rec_mask;
+					const int e	 = s_cnt[(rec >> key_shift) & 255];
+					const int nk = e >> 18, pp = e & 0x3ff;// records of the key, full pairs before it
+					const int r	 = rank[it];
+					int p, member;
+					const bool paired = r < (nk & ~1);
+					if(paired) {
+						p	   = pp + (r >> 1);
+						member = r & 1;
 					} else {
-						const int j	 = (e >> 10) & 0xff;
-						const int ln = div_small(j, pc.s1), sl = j - ln * pc.s1;
-						pos			 = 2 * pc.pf + sl * pc.q1 + min(sl, pc.r1) + ln;
+						const int j = (e >> 10) & 0xff;// singles before this one
+						if(j < n1s) {
+							p	   = pc.px + j;
+							member = 0;
+						} else {
+							p	   = pc.pf + ((j - n1s) >> 1);
+							member = (j - n1s) & 1;
+						}
 					}
-					s_sorted[pos] = (int) rec;
+					const int ln = div_small(p, pc.S), d = p - ln * pc.S;
+					int pos, ca, cb;
+					pair_slice(pc, d, pos, ca, cb);
+					// the slot's scatter arena: lane parity - but a single takes the arena its key's pair slot of this slice does not use
+					int arena = ln & 1;
+					if(!paired) {
+						int i0 = d - (pp - div_small(pp, pc.S) * pc.S);// the key's i0-th pair slot is the first one in slice d
+						i0 += i0 < 0 ? pc.S : 0;
+						if(i0 < (nk >> 1)) arena = 1 ^ (div_small(pp + i0, pc.S) & 1);
+					}
+					rec |= (unsigned) arena << kArenaBit;
+					s_sorted[pos + (member ? ca : 0) + ln] = (int) rec;
 				}
 			}
 			__syncthreads();
