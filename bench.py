@@ -20,7 +20,10 @@ Extra objects on the JSON line:
                  substeps themselves (the column in free fall, the kernel's cheapest regime) are roofline.rest.  `traffic` and
                  `valu_executed` come from the PMC profile of the MATCHING window (profiles/rNN_pmc.json) and are attached only
                  when that file's stamp is the sha256 of the library this run loaded; physical_frac = those counter bytes /
-                 this run's kernel time / 8 TB/s (what the memory system really moved, beside the algorithmic figure)
+                 this run's kernel time / 8 TB/s (what the memory system really moved, beside the algorithmic figure).
+                 NOTE: `value` and `ms_per_step` are ALWAYS the timed K substeps; when `headline_window` is "flow", roofline.frac /
+                 kernel_ms describe ANOTHER window of the same run - the pair that belongs to `value` is roofline.rest
+                 (roofline.timed_frac repeats its fraction)
   cpu_baseline - the CPU oracle ("port" of the reference pipeline) timed on this host on the same input, outside the timed
                  region (rank 0, N = 1 only): OpenMP over G2P2G's particle blocks, the grid update and the rebuild's
                  order-independent loops; `cores` = the threads it ran on
@@ -208,6 +211,9 @@ def main():
     ap.add_argument("--max-ppc", type=int, default=0, help="debug: override the scene's particles-per-cell capacity (reference: 128)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="N > 1: strong (BASELINE's metric) = the one C3 column cut N ways, weak = one C3 column per rank (N x 40.1 M particles)")
+    ap.add_argument("--partition", default="longest-axis", choices=["longest-axis", "y", "x", "z", "octants", "xz-columns", "y-x"],
+                    help="--gpus N > 1, strong scaling: the shape of the static particle partition (claymore_amd.scenes.PARTITION_SHAPES; "
+                         "profiles/r06_mgsp_partition.txt: slabs along the longest axis are the best cut while the column stands, x slabs once it has collapsed)")
     ap.add_argument("--flow-start", type=int, default=3000,
                     help="N = 1, default scene: after the timed window the run goes on to this substep and a second short window is timed "
                          "inside the flow (reported as roofline.flow; 0 = skip)")
@@ -371,6 +377,9 @@ def main():
             return objs[0]
 
         stage["at"] = "ncclCommInitRank"
+        if args.partition != "longest-axis":
+            from claymore_amd import mgsp as _mgsp
+            _mgsp.PARTITION_SHAPE = args.partition
         sim = MgspGroupRank(sc, rank, world, device=local_rank, bootstrap=bootstrap, prepartitioned=weak)
         if rank == 0:
             sys.stderr.write(f"bench.py: RCCL communicator up, world {world} (this rank {rank})\n")
@@ -415,8 +424,9 @@ def main():
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "particles": n_total, "dt": dt,
                        "parallelism": "single GPU" if not use_mgsp else
-                       f"mgsp static particle partition x{world} ({'one column per rank' if weak else 'equal-count slabs of the one column'}), C++ driver on RCCL",
+                       f"mgsp static particle partition x{world} ({'one column per rank' if weak else 'equal-count pieces of the one column, shape ' + (args.partition if args.partition != 'longest-axis' else 'slabs along the longest axis (y)')}), C++ driver on RCCL",
                        "blocks": blocks, "phases_ms": phases, **({"oversubscribed": "ranks share GPUs (debug launch, not a measurement)"} if args.oversubscribe else {})},
+            "headline_window": "timed",   # which window roofline.frac / kernel_ms describe: "flow" once the flow window has run (below); `value` / ms_per_step are ALWAYS the timed K substeps (= roofline.rest then)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "g2p2g_kernel", "bytes_per_particle": bpp, "particles_per_launch": n_rank,
@@ -466,7 +476,9 @@ def main():
                             "note": "algorithmic FLOPs of the reference formulation (SURVEY.md 8d), not executed instructions"}
             attach(head, "flow", flow["kernel_ms"])
             head["rest"] = rest
+            head["timed_frac"] = rest["frac"]      # the fraction that belongs to `value` / ms_per_step (a consumer must not pair `value` with roofline.frac of another window)
             out["roofline"] = head
+            out["headline_window"] = "flow"
 
         def emit():
             sys.stdout.flush()

@@ -74,6 +74,7 @@ SIGNATURES = {
     "get_timers": (_i, [_vp, _P(Timers)]),
     "grid_totals": (_i, [_vp, _P(C.c_double)]),
     "dump_grid": (_i, [_vp, _vp, _vp, _P(_sz)]),
+    "check_table": (_i, [_vp]),
     "default_collision_object": (_i, [_P(CollisionObject)]),
     "set_collision_object": (_i, [_vp, _P(CollisionObject), _vp, _vp, _vp, _vp]),
     "test_eig": (_i, [_vp, _sz, _vp, _i]),

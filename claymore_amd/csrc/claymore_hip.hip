@@ -1241,6 +1241,25 @@ int mpm_grid_totals(mpm_ctx* ctx, double out[4]) {
 	return MPM_OK;
 }
 
+int mpm_check_table(mpm_ctx* ctx) {
+	if(!ctx || !ctx->ready) return -1;
+	if(hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->s_compute) != hipSuccess) return -1;
+	const Partition& P = ctx->part[ctx->rollid];
+	const size_t table = (size_t) ctx->g.G * ctx->g.G * ctx->g.G;
+	std::vector<int> t(table), k(3 * (size_t) ctx->ebc);
+	if(hipMemcpy(t.data(), P.table, sizeof(int) * table, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	if(ctx->ebc && hipMemcpy(k.data(), P.keys, sizeof(int) * k.size(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	long long bad = 0, set = 0;
+	for(int v: t) set += v != -1;
+	for(int i = 0; i < ctx->ebc; ++i) {
+		const int x = k[3 * i], y = k[3 * i + 1], z = k[3 * i + 2];
+		const bool in = x >= 0 && y >= 0 && z >= 0 && x < ctx->g.G && y < ctx->g.G && z < ctx->g.G;
+		if(!in || t[((size_t) x << (2 * ctx->g.gbits)) | ((size_t) y << ctx->g.gbits) | (size_t) z] != i) ++bad;
+	}
+	bad += std::llabs(set - (long long) ctx->ebc);
+	return (int) std::min<long long>(bad, 0x7fffffff);
+}
+
 int mpm_dump_grid(mpm_ctx* ctx, int* keys, float* blocks, size_t* nblocks) {
 	if(!ctx || !ctx->ready || !nblocks) return MPM_ERR_NOT_READY;
 	if(*nblocks < (size_t) ctx->nbc) return fail(ctx, MPM_ERR_CAPACITY, "grid dump too small");

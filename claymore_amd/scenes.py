@@ -143,6 +143,24 @@ def split_slabs(xyz, parts, axis=0):
     return [np.ascontiguousarray(xyz[idx]) for idx in np.array_split(order, parts)]
 
 
+def split_boxes(xyz, shape):
+    """Static particle partition into shape = (nx, ny, nz) equal-count boxes of the initial lattice: nx slabs along x, each cut into ny along
+    y, each of those into nz along z (the reference's scenarios put their per-GPU bodies side by side in x and z, Projects/MGSP/mgsp.cu:52-57,
+    :67-72; SURVEY 8(e): "slabs / octants").  Returns the nx * ny * nz particle arrays, x-major."""
+    parts = [xyz]
+    for axis, n in enumerate(shape):
+        parts = [q for p in parts for q in split_slabs(p, n, axis)] if n > 1 else parts
+    return parts
+
+
+PARTITION_SHAPES = {  # name -> world size -> (nx, ny, nz); "octants" halves every axis it can (x first: 2 -> x, 4 -> x z, 8 -> x y z)
+    "y": lambda w: (1, w, 1), "x": lambda w: (w, 1, 1), "z": lambda w: (1, 1, w),
+    "octants": lambda w: {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 1, 2), 8: (2, 2, 2)}[w],
+    "xz-columns": lambda w: {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 1, 2), 8: (4, 1, 2)}[w],
+    "y-x": lambda w: {1: (1, 1, 1), 2: (1, 2, 1), 4: (2, 2, 1), 8: (2, 4, 1)}[w],
+}
+
+
 def total_particles(scene):
     return int(sum(m["xyz"].shape[0] for m in scene["models"]))
 

@@ -221,6 +221,9 @@ int mpm_get_diagnostics(mpm_ctx* ctx, mpm_diagnostics* d);
 /* Sum over the current grid of {mass, momentum x, y, z} (the reference's sum_grid_mass debug kernel,
  * mgmpm_kernels.cuh:1034-1037, extended to momentum); valid between rebuild and the next grid update. */
 int mpm_grid_totals(mpm_ctx* ctx, double out[4]);
+/* Table consistency of the current partition (the reference's check_table debug kernel, mgmpm_kernels.cuh:1022-1032): the number of blocks i
+ * with query(active_keys[i]) != i plus the number of table entries that belong to no block; 0 = consistent; negative = error. */
+int mpm_check_table(mpm_ctx* ctx);
 /* Dense dump of the current grid for parity tests: for every neighbor block, key (3 ints) and 256 floats
  * {mass[64], mvx[64], mvy[64], mvz[64]} (grid_buffer.cuh:12-14 layout). *nblocks in = capacity, out = count. */
 int mpm_dump_grid(mpm_ctx* ctx, int* keys, float* blocks, size_t* nblocks);

@@ -1345,6 +1345,47 @@ int mpmo_check_table(mpmo_ctx* c) {
 	return bad;
 }
 
+/* ---- G20 hooks (tests/test_oracle_golden.py): the integer bookkeeping of the particle path against the reference's own statements ----
+ * book_dump: the partition (keys in block order, {particle, neighbour, exterior} block counts) and one buffer's buckets (sizes, entries, bin
+ * offsets); which = 0: buf[rollid] (what initial_setup filled: entries are particle ids), 1: buf[rollid ^ 1] (what the last rebuild filled:
+ * entries are (dirtag * ppb) | particle_id_in_block of the source block).
+ * book_advect: what g2p2g hands to add_advection (mgmpm_kernels.cuh:852-866) without the physics - every bucketed particle's cell moved by
+ * delta[particle id] in {-1,0,1}^3; valid right after initial_setup (the buckets of buf[rollid] still hold particle ids). */
+int mpmo_fn_book_dump(mpmo_ctx* c, int model, int which, int* counts3, int* keys, int* sizes, int* buckets, int* binoff) {
+	if(!c || !c->ready || model < 0 || model >= c->nmodels) return MPM_ERR_NOT_READY;
+	const orc_partition* P = &c->part[c->rollid];
+	const orc_pbuf* b	   = &c->models[model].buf[which ? c->rollid ^ 1 : c->rollid];
+	counts3[0] = c->pbc, counts3[1] = c->nbc, counts3[2] = c->ebc;
+	memcpy(keys, P->keys, sizeof(int) * 3 * (size_t) c->ebc);
+	size_t o = 0;
+	for(int blk = 0; blk < c->pbc; ++blk) {
+		sizes[blk] = b->bucket_sizes[blk];
+		for(int i = 0; i < b->bucket_sizes[blk]; ++i) buckets[o++] = b->blockbuckets[(size_t) blk * c->ppb + i];
+	}
+	for(int blk = 0; blk <= c->pbc; ++blk) binoff[blk] = b->bin_offsets[blk];
+	return MPM_OK;
+}
+int mpmo_fn_book_advect(mpmo_ctx* c, int model, const int* delta) {
+	if(!c || !c->ready || model < 0 || model >= c->nmodels) return MPM_ERR_NOT_READY;
+	const int r = c->rollid, n = r ^ 1;
+	orc_model* m	   = &c->models[model];
+	const orc_pbuf* br = &m->buf[r];
+	orc_pbuf* bn	   = &m->buf[n];
+	memset(bn->cell_counts, 0, sizeof(int) * (size_t) c->ebc * ORC_BLOCKVOL);
+	for(int blk = 0; blk < c->pbc; ++blk)
+		for(int pidib = 0; pidib < br->bucket_sizes[blk]; ++pidib) {
+			const int pid = br->blockbuckets[(size_t) blk * c->ppb + pidib];
+			int cell[3], nc[3], bd[3];
+			for(int d = 0; d < 3; ++d) {
+				cell[d] = orc_node_index(m->xyz[3 * (size_t) pid + d], c->dx_inv) - 2; /* base_index - 1, :774-777 */
+				nc[d]	= cell[d] + delta[3 * (size_t) pid + d];
+				bd[d]	= cell[d] / 4 - nc[d] / 4; /* :860-862 (C++ truncating division) */
+			}
+			add_advection(c, bn, &c->part[r], nc[0], nc[1], nc[2], orc_dir_offset(bd[0], bd[1], bd[2]), pidib);
+		}
+	return MPM_OK;
+}
+
 /* ---- function-level entry points for the golden-vector tests ---- */
 void mpmo_fn_bspline(const float* p, size_t n, float dx_inv, float* out3) {
 	for(size_t i = 0; i < n; ++i) orc_bspline_weight(p[i], dx_inv, out3 + 3 * i);

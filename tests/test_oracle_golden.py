@@ -420,3 +420,116 @@ def test_g19_grid_update_cell_arithmetic_bit_exact():
     assert same_bits(got[live][:, :3], want[live][:, :3])
     assert same_bits(got[:, 3], want[:, 3])     # |v|^2, +inf where the arithmetic produced a NaN (:380-383)
     assert np.isinf(want[:, 3]).sum() >= 6 and (cells[:, 0] <= 0).sum() >= 100 and (cells[:, 4] > 0).sum() > 400
+
+
+# ---- G20: the INTEGER BOOKKEEPING of the particle path at statement level (tests/golden/gen/gen_golden_book.sh / .cpp) ----------------
+# Partition::insert / query / reinsert (hash_table.cuh:118-135), add_advection (particle_buffer.cuh:100-135), activate_blocks,
+# build_particle_cell_buckets, cell_bucket_to_block, compute_bin_capacity, register_neighbor / exterior_blocks, mark_active_particle_blocks,
+# update_partition, update_buckets (mgmpm_kernels.cuh:21-151, :954-1000) and exclusive_scan_inverse (MappingKernels.cuh:44-55), cut out of the
+# reference AS TEXT and run over a serial thread loop on 174 particles / 9 -> 25 particle blocks.  A serial loop fixes one of the orders the
+# GPU's atomics may produce: block keys and per-block particle sets are compared as SETS, everything order-free exactly.
+def book_tables():
+    hdr = i32("g20_hdr.i32")
+    names = "n pbc0 nbc0 ebc0 pbc1 nbc1 ebc1 ncalls".split()
+    T = dict(zip(names, [int(v) for v in hdr]))
+    T["xyz"] = f32("g20_xyz.f32").reshape(-1, 3)
+    T["delta"] = i32("g20_delta.i32").reshape(-1, 3)
+    for k, w in (("keys0", 3), ("keys1", 3), ("adv", 7)):
+        T[k] = i32(f"g20_{k}.i32").reshape(-1, w)
+    for k in ("sizes0", "buckets0", "binoff0", "marks", "scan", "scan_inverse", "sizes1", "buckets1", "binoff1"):
+        T[k] = i32(f"g20_{k}.i32")
+    return T
+
+
+def book_groups(keys, sizes, buckets):
+    """{block key: list of bucket entries}"""
+    out, o = {}, 0
+    for b, n in enumerate(sizes):
+        out[tuple(int(v) for v in keys[b])] = [int(v) for v in buckets[o:o + n]]
+        o += n
+    assert o == len(buckets)
+    return out
+
+
+def book_resolve(groups1, groups0, ppb=8192):
+    """The particle ids behind the rebuilt buckets: an entry (dirtag * ppb) | particle_id_in_block names slot particle_id_in_block of the SOURCE
+    block, which lies at the new block's key + dir_components(dirtag) (mgmpm_kernels.cuh:860-862: dirtag = dir_offset(old block - new block))."""
+    out = {}
+    for key, entries in groups1.items():
+        pids = []
+        for e in entries:
+            tag, pidib = e // ppb, e % ppb
+            d = (tag // 9 - 1, (tag // 3) % 3 - 1, tag % 3 - 1)
+            src = tuple(key[i] + d[i] for i in range(3))
+            pids.append(groups0[src][pidib])
+        out[key] = sorted(pids)
+    return out
+
+
+def test_g20_integer_bookkeeping_against_the_references_own_statements():
+    T = book_tables()
+    assert (T["n"], T["pbc0"], T["pbc1"]) == (174, 9, 25) and T["ncalls"] == T["n"]
+    api = oracle_api()
+    cfg = _ffi.Config()
+    assert api.default_config(8, C.byref(cfg)) == 0          # the reference's compile-time grid: 256^3, 128 particles per cell, bins of 32
+    cfg.max_ppc = 128
+    ctx = C.c_void_p()
+    assert api.create(C.byref(cfg), 0, C.byref(ctx)) == 0
+    p = _ffi.MaterialParams()
+    assert api.default_material(_ffi.FIXED_COROTATED, 8, C.byref(p)) == 0
+    xyz = np.ascontiguousarray(T["xyz"])
+    v0 = (C.c_float * 3)(0, 0, 0)
+    assert api.add_model(ctx, _ffi.FIXED_COROTATED, C.byref(p), ptr(xyz), xyz.shape[0], v0, None) == 0
+    assert api.initial_setup(ctx) == 0
+    dump = api.raw.mpmo_fn_book_dump
+    dump.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
+    dump.restype = C.c_int
+    adv = api.raw.mpmo_fn_book_advect
+    adv.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    adv.restype = C.c_int
+
+    def state(which):
+        cnt, keys = np.zeros(3, np.int32), np.zeros((1024, 3), np.int32)
+        sizes, buckets, binoff = np.zeros(1024, np.int32), np.zeros(4096, np.int32), np.zeros(1025, np.int32)
+        assert dump(ctx, 0, which, ptr(cnt), ptr(keys), ptr(sizes), ptr(buckets), ptr(binoff)) == 0
+        pbc, nbc, ebc = (int(v) for v in cnt)
+        return pbc, nbc, ebc, keys[:ebc], sizes[:pbc], buckets[:int(sizes[:pbc].sum())], binoff[:pbc + 1]
+
+    def tiers(keys, pbc, nbc):
+        s = [set(map(tuple, keys[a:b].tolist())) for a, b in ((0, pbc), (pbc, nbc), (nbc, len(keys)))]
+        assert sum(len(t) for t in s) == len(keys)            # no key twice (Partition::insert claims a key once)
+        return s
+
+    # A + B: the initial partition and buckets (activate_blocks, register_*, build_particle_cell_buckets, cell_bucket_to_block)
+    pbc, nbc, ebc, keys, sizes, buckets, binoff = state(0)
+    assert (pbc, nbc, ebc) == (T["pbc0"], T["nbc0"], T["ebc0"])
+    assert tiers(keys, pbc, nbc) == tiers(T["keys0"], T["pbc0"], T["nbc0"])
+    g0o, g0g = book_groups(keys, sizes, buckets), book_groups(T["keys0"], T["sizes0"], T["buckets0"])
+    assert {k: sorted(v) for k, v in g0o.items()} == {k: sorted(v) for k, v in g0g.items()}      # per block: the same particle ids
+    # compute_bin_capacity + exclusive scan (bins of 32): a function of the sizes in the engine's own block order
+    assert np.array_equal(binoff, np.concatenate([[0], np.cumsum((sizes + 31) // 32)]))
+    assert np.array_equal(T["binoff0"], np.concatenate([[0], np.cumsum((T["sizes0"] + 31) // 32)]))
+    serial_order = np.array_equal(keys, T["keys0"])          # (a serial oracle and a serial thread loop happen to insert in the same order)
+    # C: add_advection for every bucketed particle, D: the rebuild
+    assert adv(ctx, 0, ptr(np.ascontiguousarray(T["delta"]))) == 0
+    assert api.rebuild_partition(ctx, None) == 0
+    assert api.raw.mpmo_check_table(ctx) == 0                 # query(active_keys[i]) == i (update_partition's reinsert + the two register passes)
+    pbc, nbc, ebc, keys, sizes, buckets, binoff = state(1)
+    assert (pbc, nbc, ebc) == (T["pbc1"], T["nbc1"], T["ebc1"])
+    assert tiers(keys, pbc, nbc) == tiers(T["keys1"], T["pbc1"], T["nbc1"])
+    r_o = book_resolve(book_groups(keys, sizes, buckets), g0o)
+    r_g = book_resolve(book_groups(T["keys1"], T["sizes1"], T["buckets1"]), g0g)
+    assert r_o == r_g and sum(len(v) for v in r_g.values()) == T["n"]        # every particle in the block the reference's statements put it in, none lost
+    # the direction tags themselves, per particle (a particle's entry carries dir_offset(old block - new block))
+    tags = lambda groups1, groups0: sorted((groups0[tuple(k[i] + (e // 8192 // 9 - 1, (e // 8192 // 3) % 3 - 1, e // 8192 % 3 - 1)[i] for i in range(3))][e % 8192], e // 8192) for k, es in groups1.items() for e in es)
+    assert tags(book_groups(keys, sizes, buckets), g0o) == tags(book_groups(T["keys1"], T["sizes1"], T["buckets1"]), g0g) == sorted((int(r[2]), int(r[6])) for r in T["adv"])
+    assert np.array_equal(binoff, np.concatenate([[0], np.cumsum((sizes + 31) // 32)]))
+    # mark_active_particle_blocks, the exclusive scan and exclusive_scan_inverse are functions of the OLD block order: internally consistent in the
+    # table, and equal to the oracle's whenever the two old orders coincide
+    marks, scan, inv = T["marks"], T["scan"], T["scan_inverse"]
+    assert np.array_equal(scan, np.concatenate([[0], np.cumsum(marks)[:-1]])) and scan[-1] == T["pbc1"]
+    assert np.array_equal(inv, np.flatnonzero(marks[:-1])) and len(inv) == T["pbc1"]
+    assert np.array_equal(T["keys1"][:T["pbc1"]], T["keys0"][inv])            # update_partition: new block i is old block sources[i]
+    if serial_order:
+        assert np.array_equal(keys[:pbc], T["keys1"][:T["pbc1"]])
+    api.destroy(ctx)

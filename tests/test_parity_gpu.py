@@ -9,7 +9,7 @@ import pytest
 
 from claymore_amd import _ffi, scenes
 from claymore_amd.engine import build_engine
-from parity_util import grid_compare, match_and_compare, run_engine, run_pair, to_b
+from parity_util import grid_compare, grid_velocity_compare, match_and_compare, run_engine, run_pair, to_b
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -252,7 +252,9 @@ def test_two_spheres_parity(nsteps):
     err = match_and_compare(res)
     assert err["pos_rel"] < POS_TOL, err
     assert err["state_rel"] < 1e-4, err
-    assert err["grid_mass_rel"] < 1e-5 and err["grid_mom_rel"] < 1e-3, err
+    # (grid momentum TOTAL: 3 x the largest value measured over 1 / 10 / 100 substeps of this scene and of C1, 3.9e-5 - the total of a symmetric
+    #  collision is a difference of two large sums, its scale the larger of |momentum| and 1e-3 of the mass; tools/probe_grid_parity.py)
+    assert err["grid_mass_rel"] < 1e-5 and err["grid_mom_rel"] < 1.2e-4, err
     ch, co = res["hip"]["counts"], res["oracle"]["counts"]
     assert (ch.particle_blocks, ch.neighbor_blocks, ch.exterior_blocks) == (co.particle_blocks, co.neighbor_blocks, co.exterior_blocks)
     assert [ch.particles[i] for i in range(2)] == [co.particles[i] for i in range(2)]
@@ -270,6 +272,23 @@ def test_grid_node_parity_after_one_step():
     sc = scenes.two_spheres(bits=6, radius_cells=5.0, gap_cells=1.0, speed=1.0)
     res = run_pair(sc, 1, 1e-4, collect_grid=True)
     assert grid_compare(res) < 2e-5
+
+
+@pytest.mark.parametrize("nsteps", [10, 100])
+def test_grid_velocity_parity_over_many_substeps(nsteps):
+    """north_star: "positions/velocities match ... within 1e-5".  The reference's particles carry no velocity - it lives on the grid
+    (update_grid_velocity_query_max, mgmpm_kernels.cuh:325-420) -, so velocity parity is GRID parity, node by node with the block keys matched,
+    after many substeps and not only one: C1 (BASELINE config 1, 48 840 particles, 128^3) after 10 and 100 substeps.
+    grid_compare: every node's {mass | momentum} within 1e-5 of the largest entry of its channel group (measured 1.2e-6 / 3.8e-6,
+    tools/probe_grid_parity.py -> profiles/r06_grid_parity_probe.txt); grid_velocity_compare: momentum / mass per node, nodes lighter than
+    1e-3 of the heaviest left out, relative to the largest |v| (measured 2.2e-6 / 7.9e-6: the quotient of two sums of ~27 x 8 float terms each)."""
+    sc = scenes.two_spheres()
+    res = run_pair(sc, nsteps, 1e-4, collect_grid=True)
+    assert grid_compare(res) < 1e-5, grid_compare(res)
+    v = grid_velocity_compare(res)
+    assert v < (1e-5 if nsteps <= 10 else 2.4e-5), v     # (100 substeps: 3 x the measured 7.9e-6)
+    err = match_and_compare(res)
+    assert err["pos_rel"] < POS_TOL, err
 
 
 @pytest.mark.parametrize("material,steps", [(_ffi.J_FLUID, 40), (_ffi.SAND, 40), (_ffi.NACC, 20)])
@@ -852,7 +871,7 @@ def test_one_particle_scenes_through_the_real_kernel_against_the_references_stat
     key into the current grid, whose momentum channels are exactly zero for a particle at rest), mpm_g2p2g(dt, new_dt), mpm_rebuild_partition -
     and what comes out (mpm_retrieve_state: position, b, log Jp; mpm_dump_grid: every node) is compared with what the REFERENCE'S OWN
     STATEMENTS of mgmpm_kernels.cuh:772-905 + :518-663 produced for that particle (tests/golden/gen/gen_golden_kernel.sh): position <= 1e-6
-    relative, state 2e-5, the 27 x {m, mv} node values 1e-5 of the stencil's largest, nothing anywhere else, a discarded particle
+    relative, b 1.2e-5 and log Jp 6e-6 absolute (3 x what was measured, on every arena), the 27 x {m, mv} node values 1e-5 of the stencil's largest, nothing anywhere else, a discarded particle
     (:877-885) counted and absent from the grid, the particle bucketed in the block add_advection was given (:863)."""
     import torch
     G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -878,6 +897,10 @@ def test_one_particle_scenes_through_the_real_kernel_against_the_references_stat
     if material == _ffi.NACC:
         prm.update(beta=P["beta_nacc"], xi=P["xi"], msqr=P["msqr"], hardening_on=int(P["hardening_on"]))
     bad, seen = [], dict(crossed=0, discarded=0, arenas=set())
+    worst = {}                                                     # measured deviations by (quantity, arena is CFL-abiding): printed with MPM_PRINT_WORST=1
+
+    def note(what, a, e):
+        worst[(what, a < 3)] = max(worst.get((what, a < 3), 0.0), float(e))
     for r in rows:
         a = int(rin[r, 1])
         pos = rin[r, 2:5].astype(np.float32)
@@ -916,12 +939,16 @@ def test_one_particle_scenes_through_the_real_kernel_against_the_references_stat
                 bad.append((tag, "J", float(st[0, 0]), float(want[15])))
         elif np.isfinite(F).all():
             e = np.abs(b - F @ F.T).max() / max(1.0, np.abs(F @ F.T).max())
-            if not e <= 2e-5:
+            note("b", a, e)
+            if not e <= 1.2e-5:                      # (3 x the largest deviation measured over all rows and materials, 3.9e-6: sand)
                 bad.append((tag, "b", e))
-            # log Jp: 5e-6 absolute (it is a difference of logarithms) + 1e-5 relative on the physical arenas; the two CFL-violating arenas (70 m/s
-            # noise, a 90 m/s stream: a particle is torn apart in ONE substep) drive NACC's hardening through exp / sinh of large arguments, where
-            # the reference's own float arithmetic ends in NaN for some rows (skipped) and the two agree to 5e-3 for the others
-            if material != _ffi.FIXED_COROTATED and np.isfinite(want[24]) and not abs(float(lj[0]) - float(want[24])) <= 5e-6 + (1e-5 if a < 3 else 5e-3) * abs(float(want[24])):
+            # log Jp: an ABSOLUTE bound (it is a sum of logarithms; rows with log Jp ~ 0 have no relative error to speak of), 3 x the largest deviation
+            # measured over all rows, 2.0e-6 - the two CFL-violating arenas (70 m/s noise, a 90 m/s stream: a particle torn apart in ONE substep, where
+            # the reference's own float arithmetic ends in NaN for some rows, which are skipped) included: round 5 allowed them 5e-3 relative, which
+            # the measurement (MPM_PRINT_WORST=1, profiles/r06_one_particle_worst.txt) shows was never needed
+            if material != _ffi.FIXED_COROTATED and np.isfinite(want[24]):
+                note("logjp_abs", a, abs(float(lj[0]) - float(want[24])))
+            if material != _ffi.FIXED_COROTATED and np.isfinite(want[24]) and not abs(float(lj[0]) - float(want[24])) <= 6e-6:
                 bad.append((tag, "logjp", float(lj[0]), float(want[24])))
         # the block the particle is bucketed in (add_advection's cell, :863)
         if cnt.particle_blocks != 1 or int(cnt.particles[0]) != 1:
@@ -954,6 +981,8 @@ def test_one_particle_scenes_through_the_real_kernel_against_the_references_stat
         seen["crossed"] += dirtag != 13
         seen["discarded"] += disc
         seen["arenas"].add(a)
+    if os.environ.get("MPM_PRINT_WORST"):
+        print("WORST", material, {f"{k[0]}{'' if k[1] else '_cfl_violating'}": v for k, v in sorted(worst.items())})
     assert not bad, (len(bad), bad[:12])
     assert len(seen["arenas"]) == arenas.shape[0] and seen["crossed"] >= 4 and seen["discarded"] >= 2, seen
 
@@ -963,7 +992,9 @@ def test_full_size_c3_parity_40m():
     cells of Drucker-Prager sand, 40 108 032 particles, 512^3) set down with its lowest layers inside the floor's wall zone and thrown at it at
     0.4 m/s - the grid update zeroes their vertical velocity from the first substep, the bottom of the column is compressed and yields -,
     8 substeps on both engines (the oracle with OpenMP over particle blocks), particles matched by the lattice site they started from:
-    positions within 1e-5 relative, b and log Jp within the test_parity bounds, block counts equal."""
+    positions within 1e-5 relative, b and log Jp within the test_parity bounds, block counts equal, and - round 6 - the GRID node by node
+    (mass / momentum within 3e-5 of the channel group's largest entry, velocity = momentum / mass within 1.1e-4 of the largest |v|: 3 x what was
+    measured, see below)."""
     bits = 9
     sc = scenes.sand_column(bits, min_corner=(192, 7, 192))
     v0 = -0.4
@@ -971,7 +1002,8 @@ def test_full_size_c3_parity_40m():
     n = scenes.total_particles(sc)
     assert n == 40108032
     nsteps, dt = 8, 1e-4
-    hip = run_engine(sc, nsteps, dt)
+    hip = run_engine(sc, nsteps, dt, collect_grid=True)
+    grid_h = hip["grid"]
     xh, bh, lh = hip["state"][0]
     oh = _lattice_order(xh - np.array([0.0, v0 * nsteps * dt, 0.0]), bits)
     xh, bh, lh = xh[oh], to_b(bh, True)[oh], lh[oh]
@@ -979,7 +1011,17 @@ def test_full_size_c3_parity_40m():
     hc = (ch.particle_blocks, ch.neighbor_blocks, ch.exterior_blocks)
     del hip, oh
     api = oracle_api_threads(64)
-    ora = run_engine(sc, nsteps, dt, api=api)
+    ora = run_engine(sc, nsteps, dt, api=api, collect_grid=True)
+    # velocity parity at size: the two grids node by node after the 8 substeps, ~94 k blocks with their keys matched
+    g = {"hip": {"grid": grid_h}, "oracle": {"grid": ora["grid"]}}
+    gc, gv = grid_compare(g), grid_velocity_compare(g)
+    # Measured (two runs): every node within 9.1 - 9.6e-6 of the largest mass / momentum, its velocity within 3.2 - 3.6e-5 of the largest |v| - NOT
+    # the 1e-5 the small scenes reach (test_grid_velocity_parity_over_many_substeps: 4e-6 / 8e-6).  In a column compressed against the floor a
+    # node's momentum change is the SUM of large stress terms of its ~200 particle-node pairs that cancel to almost nothing: each engine rounds
+    # that sum in its own order, and the residue is 1e-7 of the TERMS, not of the sum.  Positions integrate it harmlessly (1e-5 above).
+    # The bounds are 3 x the measurement.
+    assert gc < 3e-5 and gv < 1.1e-4, (gc, gv)
+    del g, grid_h
     xo, fo, lo = ora["state"][0]
     assert xh.shape == xo.shape == (n, 3)
     oo = _lattice_order(xo - np.array([0.0, v0 * nsteps * dt, 0.0]), bits)
@@ -1072,3 +1114,102 @@ def test_overflow_regime_drop_count_matches_the_oracle(material, speed):
     counts = np.unique(key, return_counts=True)[1]
     surplus = int(np.maximum(0, counts - cap).sum())
     assert surplus == lost_by_the_oracle, (onset, surplus, lost_by_the_oracle, int(counts.max()))   # (2)
+
+
+def _hip_block_sets(eng, nch, ppb, dx):
+    """The HIP engine's own bookkeeping read out of a checkpoint (mpm_checkpoint.inc: header 448 B, then 16-byte aligned sections): per particle
+    block its key and the POSITIONS of the particles its advection list names - record {dir tag 5 b, sort key 8 b, slot} -> the source block (the
+    block's key + the tag's direction, looked up in the previous numbering) -> that block's bins -> the record of the slot."""
+    buf = eng.save_checkpoint()
+    hdr = np.frombuffer(buf[:48].tobytes(), np.int32)
+    nmodels, pbc, nbc, ebc, prev_count = int(hdr[4]), int(hdr[6]), int(hdr[7]), int(hdr[8]), int(hdr[9])
+    assert nmodels == 1
+    m0 = np.frombuffer(buf[64:64 + 48].tobytes(), np.int64)           # models[0]: {material, nch | list_in, layout | n | bincount | bincount_src | bucketed}
+    bincount_src, bucketed, layout = int(m0[4]), int(m0[5]), int(np.frombuffer(buf[64 + 12:64 + 16].tobytes(), np.int32)[0])
+    o = [448]
+
+    def take(nbytes, dtype):
+        a = np.frombuffer(buf[o[0]:o[0] + nbytes].tobytes(), dtype)
+        o[0] += (nbytes + 15) & ~15
+        return a
+    cur_keys = take(4 * 3 * ebc, np.int32).reshape(-1, 3)
+    prev_keys = take(4 * 3 * prev_count, np.int32).reshape(-1, 3)
+    take(4 * 256 * nbc, np.float32)
+    size = take(4 * (ebc + 1), np.int32)
+    take(4 * (ebc + 1), np.int32)
+    binoff_src = take(4 * (prev_count + 1), np.int32)
+    take(4 * (ebc + 1), np.int32)
+    bins = take(4 * bincount_src * nch * 64, np.float32)
+    lists = take(4 * bucketed, np.int32)
+    if layout:
+        take(4 * pbc * 16, np.int32)
+    assert o[0] == buf.size, (o[0], buf.size)
+    prev = {tuple(int(v) for v in k): i for i, k in enumerate(prev_keys)}
+    pid_bits = int(np.log2(ppb))
+    rec_floats = 4 if nch == 4 else 8
+    out, at = {}, 0
+    for b in range(pbc):
+        key = tuple(int(v) for v in cur_keys[b])
+        pts = []
+        for rec in lists[at:at + int(size[b])]:
+            rec = int(rec) & 0xffffffff
+            tag, sp = (rec >> (pid_bits + 8)) & 31, rec & (ppb - 1)
+            src = prev[(key[0] + tag // 9 - 1, key[1] + (tag // 3) % 3 - 1, key[2] + tag % 3 - 1)]
+            base = (int(binoff_src[src]) + (sp >> 6)) * nch * 64 + (sp & 63) * rec_floats
+            pts.append(tuple(float(v) * dx for v in bins[base:base + 3]))
+        at += int(size[b])
+        out[key] = sorted(pts)
+    assert at == bucketed
+    return out, (pbc, nbc, ebc), cur_keys
+
+
+def test_g20_block_keys_particle_sets_and_table_against_the_references_statements():
+    """G20 on the GPU: the integer bookkeeping of the reference - Partition::insert / reinsert, activate_blocks, the bucket kernels,
+    register_neighbor / exterior_blocks, cut out of the reference as text (tests/golden/gen/gen_golden_book.sh) - against the HIP engine's own
+    bookkeeping, which is built differently on purpose (block-level advection lists, one compaction kernel, no scans: DESIGN.md 2): after
+    initial_setup on the G20 scene the same block counts, the same key SET per tier, per particle block the same SET of particles (read out of the
+    engine's lists and bins through a checkpoint), query(active_keys[i]) == i; then 40 substeps of a moving scene: the key sets of the oracle's
+    partition, block by block the particles the oracle has there, and the table still consistent."""
+    from test_oracle_golden import book_tables, book_groups
+    T = book_tables()
+    bits, dx = 8, 1.0 / 256.0
+    prm = {"volume": dx ** 3 / 8.0, "youngs_modulus": 5e3, "poisson_ratio": 0.4, "rho": 1e3}
+    sc = {"name": "g20", "bits": bits, "dt": 1e-4, "config": {"max_ppc": 128}, "models": [{"material": _ffi.FIXED_COROTATED, "xyz": np.ascontiguousarray(T["xyz"]), "v0": (0.0, 0.0, 0.0), "params": prm}]}
+    eng = build_engine(sc)
+    eng.initial_setup()
+    assert eng.api.check_table(eng.ctx) == 0
+    sets, counts, keys = _hip_block_sets(eng, 9, 8192, dx)
+    eng.close()
+    assert counts == (T["pbc0"], T["nbc0"], T["ebc0"])
+    tier = lambda k, a, b: set(map(tuple, np.asarray(k)[a:b].tolist()))
+    for a, b in ((0, T["pbc0"]), (T["pbc0"], T["nbc0"]), (T["nbc0"], T["ebc0"])):
+        assert tier(keys, a, b) == tier(T["keys0"], a, b)
+    want = {k: sorted(tuple(float(v) for v in T["xyz"][p]) for p in pids) for k, pids in book_groups(T["keys0"], T["sizes0"], T["buckets0"]).items()}
+    assert sets == want                                   # per block: exactly the particles build_particle_cell_buckets + cell_bucket_to_block put there
+    # a moving scene, HIP against the oracle driven through the same calls: two spheres in contact, 40 substeps (blocks appear and disappear)
+    sc = scenes.two_spheres(bits=6, radius_cells=6.0, gap_cells=0.5, speed=2.0, youngs=2e4)
+    eng = build_engine(sc)
+    eng.initial_setup()
+    eng.run_fixed(40, 1e-4)
+    assert eng.api.check_table(eng.ctx) == 0
+    ch = eng.counts()
+    kh, _ = eng.dump_grid()
+    xh = [eng.retrieve_state(m)[0] for m in range(2)]
+    eng.close()
+    from oracle_ffi import oracle_api
+    ora = build_engine(sc, api=oracle_api())
+    ora.initial_setup()
+    ora.run_fixed(40, 1e-4)
+    co = ora.counts()
+    ko, _ = ora.dump_grid()
+    xo = [ora.retrieve_state(m)[0] for m in range(2)]
+    ora.close()
+    assert (ch.particle_blocks, ch.neighbor_blocks, ch.exterior_blocks) == (co.particle_blocks, co.neighbor_blocks, co.exterior_blocks)
+    assert tier(kh, 0, ch.particle_blocks) == tier(ko, 0, co.particle_blocks) and tier(kh, 0, len(kh)) == tier(ko, 0, len(ko))
+    # per block the same particles: the block a particle is bucketed in is a function of its position (get_block_id - 2 over the block size)
+    dxs = 1.0 / 64.0
+    blk = lambda x: [tuple(v) for v in ((np.rint(x.astype(np.float64) / dxs).astype(np.int64) - 2) >> 2).tolist()]
+    for m in range(2):
+        from parity_util import match
+        idx, _ = match(xo[m].astype(np.float64), xh[m].astype(np.float64))
+        assert blk(xh[m][idx]) == blk(xo[m])
