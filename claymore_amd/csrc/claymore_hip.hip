@@ -568,8 +568,8 @@ int mpm_initial_setup(mpm_ctx* ctx) {
 	HIP_TRY(hipMemcpyAsync(ctx->part[r].count, P.count, sizeof(int), hipMemcpyDeviceToDevice, s));
 	// rasterize (gmpm_simulator.cuh:763-771)
 	HIP_TRY(hipMemsetAsync(ctx->grid[0], 0, sizeof(float) * 256 * (size_t) ctx->nbc, s));
-	for(auto& m: ctx->models)
-		if(m.n) rasterize_kernel<<<cdiv(m.n, 256), 256, 0, s>>>(g, m.n, m.d_xyz, ctx->part[r].table, ctx->grid[0], m.mc.mass, m.v0[0], m.v0[1], m.v0[2]);
+	for(auto& m: ctx->models)// (m.list[1] still holds the particle ids by block that bucket_particles_kernel wrote; every particle of the model is in a block: ST_LOST was checked above)
+		if(m.n && pbc) rasterize_blocks_kernel<<<pbc, 256, 0, s>>>(g, m.d_xyz, m.list[1], m.size, ctx->part[r].keys, ctx->part[r].table, ctx->grid[0], m.mc.mass, m.v0[0], m.v0[1], m.v0[2]);
 	// the first G2P2G: current == previous numbering (roll r), lists as filled above
 	rc = launch_prepare(ctx, r, n, false, r, &ctx->d_status[ST_PBC], ctx->pbc, true, false);
 	if(rc) return rc;
@@ -1061,7 +1061,7 @@ int mpm_state_kind(void) {
 }
 
 const char* mpm_build_info(void) {
-	return "claymore_hip abi6 state=b"
+	return "claymore_hip abi7 state=b"
 #ifdef MPM_EXPERIMENT
 		   " experiment=MPM_EXPERIMENT"
 #ifdef MPM_HACK_EDGEWIN

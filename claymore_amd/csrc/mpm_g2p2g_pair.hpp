@@ -23,6 +23,12 @@ namespace mpm {
 #define MPM_PAIR_WAVES 3
 #endif
 // bit m: material m reads the 27 gather nodes once for both particles when the wave's pairs share their bases (else: one gather per particle)
+#if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_WAVES_FLUID))
+#define MPM_PAIR_WAVES_FLUID 3
+#endif
+#if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_LATE_FETCH))
+#define MPM_PAIR_LATE_FETCH 0// 0: the next slice's particle records are requested at the top of the iteration; 1: behind the material update; 2: A's at the top, B's behind the material update
+#endif
 #if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_SHARED_GATHER))
 #define MPM_PAIR_SHARED_GATHER 0x0// (the second set of gather accumulators does not fit 168 registers beside the slice bookkeeping: scratch operations inside the loop - every one drains the record prefetch - cost more than 27 LDS reads)
 #endif
@@ -194,7 +200,7 @@ struct ScatterChain2 {
 };
 
 template<int MAT>
-__global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_keys, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, const int* __restrict__ only_flag, const int* __restrict__ nblocks_ptr, int nblocks, float dt, float new_dt, StepConst sk, int* __restrict__ status) {
+__global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MPM_PAIR_WAVES) void g2p2g_pair_kernel(GridCfg cfg, ModelView mv, const int* __restrict__ cur_keys, const float* __restrict__ grid, float* __restrict__ next_grid, const int* __restrict__ block_list, const int* __restrict__ only_flag, const int* __restrict__ nblocks_ptr, int nblocks, float dt, float new_dt, StepConst sk, int* __restrict__ status) {
 	constexpr int NCH = MatTraits<MAT>::nch;
 	constexpr int REC = MatTraits<MAT>::rec;
 	constexpr bool kSharedGather = ((MPM_PAIR_SHARED_GATHER >> MAT) & 1) != 0;
@@ -349,8 +355,12 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 		if(((t_cur + 2) & 63) == 0) form_slices(t_cur + 2);// (a block with more than 64 slices: the next batch of descriptors)
 		read_slice(t_cur + 2, s_nn);
 		load_recs(s_nn, rec_nn);
+#if MPM_PAIR_LATE_FETCH != 1
 		fetch(rec_next[0], pf[0]);
+#endif
+#if MPM_PAIR_LATE_FETCH == 0
 		fetch(rec_next[1], pf[1]);
+#endif
 		MPM_MARK("P_gather");
 		// ---- stencil bases + weights (:774-797), gather (:801-835)
 		int base[2][3], arena[2][3];
@@ -509,6 +519,16 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 				}
 			}
 		}
+#if MPM_PAIR_LATE_FETCH
+		// The next slice's particle records are requested HERE, behind the material update, not at the top of the iteration: requested at the top, their
+		// 22 destination registers (sand) are live through the gather and the material update, the allocator runs out, parks the loads in registers it
+		// needs again and waits for them - s_waitcnt vmcnt(0) in the re-bucketing, i.e. the whole HBM latency exposed in every iteration.  From here the
+		// loads have the scatter chain (27 LDS round trips) and the other two waves of the SIMD to arrive in.
+#if MPM_PAIR_LATE_FETCH == 1
+		fetch(rec_next[0], pf[0]);
+#endif
+		fetch(rec_next[1], pf[1]);
+#endif
 		MPM_MARK("P_scatter");
 		// ---- the pair scatters now (:887-905): payload ((:850) contrib = (A m - stress new_dt) D^-1, times dx: cell units), claim, 27 steps back to back
 		P2GPayload pv[2];
@@ -539,7 +559,11 @@ __global__ __launch_bounds__(kG2P2GThreads, MPM_PAIR_WAVES) void g2p2g_pair_kern
 		//      chain is set up (both add into the arenas with plain read-modify-writes; a single wave's LDS operations execute in program order)
 		{
 			const bool left_a = pv_in[0] && !win;
+#if defined(MPM_EXPERIMENT) && defined(MPM_HACK_NOSPLIT)// timing experiment only: a B that does not ride with its A is dropped (wrong physics)
+			const bool left_b = false;
+#else
 			const bool left_b = pv_in[1] && !merge_b;
+#endif
 #ifdef MPM_G2P2G_STATS
 			st_iter += 1;
 			st_losers += __popcll(__ballot(left_a && !code_edge(pv_code[0]))) + __popcll(__ballot(left_b && !code_edge(pv_code[1]) && !win));

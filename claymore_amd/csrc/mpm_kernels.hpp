@@ -892,7 +892,52 @@ __global__ __launch_bounds__(256) void fill_bins_kernel(GridCfg cfg, int nch, fl
 		list_in[(size_t) b * cfg.ppb + pidib] = (kStay << (cfg.pid_bits + kKeyBits)) | (key << cfg.pid_bits) | pidib;
 	}
 }
-// rasterize, mgmpm_kernels.cuh:153-219 (one-time, global atomics)
+// rasterize, mgmpm_kernels.cuh:153-219, block by block (round 6): one workgroup per particle block - the particles are bucketed by block when this
+// runs (ids[block][slot], size[block]) - sums the B-spline masses of the block's particles in an LDS image of the 8^3 node cube its stencils reach
+// (nodes 1..6 per axis, like G2P2G's arenas) and writes every touched node back with ONE global atomic per channel; the initial velocity is uniform
+// per model, so the three momentum channels are the mass times v0.  The per-particle version below (27 x 4 global atomics per particle) took 98.6 ms
+// at 40 M particles and 253.7 ms at 100 M - 40 % of a 110-substep profile run; it stays as the fall-back for a particle outside every block.
+__global__ __launch_bounds__(256) void rasterize_blocks_kernel(GridCfg cfg, const float* __restrict__ xyz, const int* __restrict__ ids, const int* __restrict__ size, const int* __restrict__ keys, const int* __restrict__ table, float* grid, float mass, float v0x, float v0y, float v0z) {
+	__shared__ float s_m[512];
+	const int b = blockIdx.x;
+	const int n = size[b];
+	if(n == 0) return;
+	const int kx = keys[3 * b], ky = keys[3 * b + 1], kz = keys[3 * b + 2];
+	for(int i = threadIdx.x; i < 512; i += 256) s_m[i] = 0.f;
+	__syncthreads();
+	for(int pidib = threadIdx.x; pidib < n; pidib += 256) {
+		const size_t pid = (size_t) ids[(size_t) b * cfg.ppb + pidib];
+		int base[3];
+		float w[3][3];
+#pragma unroll
+		for(int d = 0; d < 3; ++d) {
+			const float p = xyz[3 * pid + d] * cfg.dx_inv;
+			base[d]		  = lround_pos(p) - 1;
+			bspline_weight_cells(p - (float) base[d], w[d]);
+		}
+		const int lx = base[0] - 4 * kx, ly = base[1] - 4 * ky, lz = base[2] - 4 * kz;// 1..4: the block owns the cells base - 1
+#pragma unroll
+		for(int i = 0; i < 3; ++i)
+#pragma unroll
+			for(int j = 0; j < 3; ++j)
+#pragma unroll
+				for(int k = 0; k < 3; ++k) atomicAdd(&s_m[((lx + i) << 6) | ((ly + j) << 3) | (lz + k)], mass * (w[0][i] * w[1][j] * w[2][k]));
+	}
+	__syncthreads();
+	for(int i = threadIdx.x; i < 512; i += 256) {
+		const float m = s_m[i];
+		if(m == 0.f) continue;
+		const int x = i >> 6, y = (i >> 3) & 7, z = i & 7;
+		const int bno = table_query(cfg, table, kx + (x >> 2), ky + (y >> 2), kz + (z >> 2));
+		if(bno < 0) continue;
+		float* g = grid + (size_t) bno * 256 + (x & 3) * 16 + (y & 3) * 4 + (z & 3);
+		unsafeAtomicAdd(g, m);
+		if(v0x != 0.f) unsafeAtomicAdd(g + 64, m * v0x);
+		if(v0y != 0.f) unsafeAtomicAdd(g + 128, m * v0y);
+		if(v0z != 0.f) unsafeAtomicAdd(g + 192, m * v0z);
+	}
+}
+// (per particle, global atomics: the reference's form)
 __global__ void rasterize_kernel(GridCfg cfg, size_t n, const float* __restrict__ xyz, const int* __restrict__ table, float* grid, float mass, float v0x, float v0y, float v0z) {
 	const size_t pi = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if(pi >= n) return;

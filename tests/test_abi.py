@@ -80,7 +80,7 @@ def test_state_kind_says_what_retrieve_state_returns():
     mpm_state_kind() and the ABI number in mpm_build_info(); the CPU oracle still carries the reference's F."""
     from oracle_ffi import oracle_api
     hip = _ffi.load_hip()
-    assert hip.state_kind() == 1 and " abi6 " in hip.build_info().decode() and "state=b" in hip.build_info().decode()
+    assert hip.state_kind() == 1 and " abi7 " in hip.build_info().decode() and "state=b" in hip.build_info().decode()
     assert oracle_api().state_kind() == 0
 
 
