@@ -26,6 +26,9 @@ namespace mpm {
 #if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_WAVES_FLUID))
 #define MPM_PAIR_WAVES_FLUID 3
 #endif
+#if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_DUAL))
+#define MPM_PAIR_DUAL 0// 1: a B that cannot ride with its A claims the other arena and scatters in the same chain (ScatterChainDual) instead of the serial path - measured +6 % in the C3 flow (every iteration with such a lane pays two read-modify-writes per step): off, profiles/r06_ab_pairs_phase2.txt
+#endif
 #if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_LATE_FETCH))
 #define MPM_PAIR_LATE_FETCH 0// 0: the next slice's particle records are requested at the top of the iteration; 1: behind the material update; 2: A's at the top, B's behind the material update
 #endif
@@ -157,6 +160,56 @@ struct ChainHalf {
 		const v2f_ t12 = k == 0 ? pen12 : (k == 1 ? pen12 + cz12 : cz12 * 2.f + pen12);
 		a01			   = m0 * W + a01;
 		a23			   = t12 * W + a23;
+	}
+};
+
+// The chain for an iteration in which some lane's B could NOT ride with its A (another stencil base: the sort's mismatched slots, a misprediction, an A
+// on the cube's edge) but holds a claim of its own in the OTHER arena: such a lane does two read-modify-writes per step, A's node in its arena and B's
+// node in the other one (different arenas: the two may be in flight together), instead of sending B down the serial path - which costs five times a
+// chain particle (profiles/r06_ab_pairs_phase2.txt: 2 % of the particles of the C3 flow, 0.2 of 1.98 ms).  Lanes whose B rides with A (`merge`) add it
+// into A's accumulator as before.  Only instantiated behind a wave-uniform test: an iteration without such a lane runs ScatterChain2.
+struct ScatterChainDual {
+	float4 *node0, *node1;
+	float mass, merge_w, dual_w;// 1 / 0: B's contribution goes into A's node / into its own
+	int win, dual;
+	ChainHalf h[2];
+	float4 acc, acc2;
+	MPM_DEV ScatterChainDual(float4* n0, float4* n1, const P2GPayload& pa, const P2GPayload& pb, float m, bool w, bool merge, bool d)
+		: node0(n0)
+		, node1(n1)
+		, mass(m)
+		, merge_w(merge ? 1.f : 0.f)
+		, dual_w(d ? 1.f : 0.f)
+		, win(w)
+		, dual(d) {
+		h[0].init(pa, w);
+		h[1].init(pb, merge || d);
+		acc = acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
+		if(win) acc = node0[0];
+		if(dual) acc2 = node1[0];
+	}
+	MPM_DEV void run() {
+#pragma unroll
+		for(int o = 0; o < 27; ++o) {
+			v2f_ a01 = {acc.x, acc.y}, a23 = {acc.z, acc.w};
+			v2f_ b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
+			h[0].add(o, mass, a01, a23);
+			h[1].add(o, mass, b01, b23);
+			a01 = b01 * merge_w + a01;
+			a23 = b23 * merge_w + a23;
+			const v2f_ c01 = b01 * dual_w + (v2f_) {acc2.x, acc2.y}, c23 = b23 * dual_w + (v2f_) {acc2.z, acc2.w};
+			const int i = o / 9, j = (o / 3) % 3, k = o % 3;
+			const int off = i * kP2GStrideX + j * kP2GStrideY + k;
+			if(win) node0[off] = make_float4(a01.x, a01.y, a23.x, a23.y);
+			if(dual) node1[off] = make_float4(c01.x, c01.y, c23.x, c23.y);
+			__asm__ volatile("" ::: "memory");
+			if(o + 1 < 27) {
+				const int i1 = (o + 1) / 9, j1 = ((o + 1) / 3) % 3, k1 = (o + 1) % 3;
+				const int off1 = i1 * kP2GStrideX + j1 * kP2GStrideY + k1;
+				if(win) acc = node0[off1];
+				if(dual) acc2 = node1[off1];
+			}
+		}
 	}
 };
 
@@ -549,26 +602,41 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 				pv_in[h]   = pv_code[h] >= 0;
 			}
 		}
-		const int pv_key = (pv_in[0] ? code_key(pv_code[0]) : 0) + arena_sel * 216;// two arenas, two claim tables: the sort says which one a slot uses
-		if(pv_in[0]) s_owner[pv_key] = (unsigned char) lane;
+		// ---- claims: A for the slot's arena; a B with another base than its A (or without a chain-able A) for the OTHER arena, on its own
+		const bool a_ok	   = pv_in[0] && !code_edge(pv_code[0]);
+		const bool b_same  = pv_in[1] && pv_in[0] && pv_code[1] == pv_code[0];
+#if MPM_PAIR_DUAL
+		const bool b_own = pv_in[1] && !b_same && !code_edge(pv_code[1]);
+#else
+		const bool b_own = false;
+#endif
+		const int key_a = (a_ok ? code_key(pv_code[0]) : 0) + arena_sel * 216;// two arenas, two claim tables: the sort says which one a slot uses
+		const int key_b = (b_own ? code_key(pv_code[1]) : 0) + (arena_sel ^ 1) * 216;
+		// (B's claims are written FIRST: a single wave's LDS stores execute in program order, so an A that claims the same base in the same arena overwrites
+		//  them - a B never takes an arena away from a pair, it only uses one that would have stayed idle)
+		if(b_own) s_owner[key_b] = (unsigned char) (lane | 64);
+		__asm__ volatile("" ::: "memory");
+		if(a_ok) s_owner[key_a] = (unsigned char) lane;
 		__asm__ volatile("" ::: "memory");// another lane may have written the same byte: no store-to-load forwarding
-		const bool win	   = pv_in[0] && !code_edge(pv_code[0]) && (int) s_owner[pv_key] == lane;
-		const bool merge_b = win && pv_in[1] && pv_code[1] == pv_code[0];
+		const bool win	   = a_ok && (int) s_owner[key_a] == lane;
+		const bool dual	   = b_own && (int) s_owner[key_b] == (lane | 64);
+		const bool merge_b = win && b_same;
 		MPM_MARK("P_serial");
-		// ---- what the chain will not take - A without a claim or on the cube's edge, B split from its A - goes first: the payloads are dead once the
-		//      chain is set up (both add into the arenas with plain read-modify-writes; a single wave's LDS operations execute in program order)
+		// ---- what the chain will not take - A without a claim or on the cube's edge, B neither riding with its A nor holding a claim of its own - goes first:
+		//      the payloads are dead once the chain is set up (both add into the arenas with plain read-modify-writes; a single wave's LDS operations execute
+		//      in program order)
 		{
 			const bool left_a = pv_in[0] && !win;
 #if defined(MPM_EXPERIMENT) && defined(MPM_HACK_NOSPLIT)// timing experiment only: a B that does not ride with its A is dropped (wrong physics)
 			const bool left_b = false;
 #else
-			const bool left_b = pv_in[1] && !merge_b;
+			const bool left_b = pv_in[1] && !merge_b && !dual;
 #endif
 #ifdef MPM_G2P2G_STATS
 			st_iter += 1;
-			st_losers += __popcll(__ballot(left_a && !code_edge(pv_code[0]))) + __popcll(__ballot(left_b && !code_edge(pv_code[1]) && !win));
+			st_losers += __popcll(__ballot(left_a && !code_edge(pv_code[0]))) + __popcll(__ballot(left_b && !code_edge(pv_code[1])));
 			st_edge += __popcll(__ballot(pv_in[0] && code_edge(pv_code[0]))) + __popcll(__ballot(pv_in[1] && code_edge(pv_code[1])));
-			st_split += __popcll(__ballot(left_b && win && !code_edge(pv_code[1])));
+			st_split += __popcll(__ballot(dual));
 			st_retry_iters += __any(left_a || left_b) ? 1 : 0;
 #endif
 #if defined(MPM_EXPERIMENT) && defined(MPM_HACK_NOSERIAL)// timing experiment only: what the chain does not take is dropped (wrong physics)
@@ -596,7 +664,11 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 		}
 		MPM_MARK("P_chain");
 		float4* const node0 = p2g + (win ? code_off(pv_code[0]) + arena_sel * kP2GArena2 : 0);
-		{
+		if(__any(dual)) {
+			float4* const node1 = p2g + (dual ? code_off(pv_code[1]) + (arena_sel ^ 1) * kP2GArena2 : 0);
+			ScatterChainDual chain(node0, node1, pv[0], pv[1], mass, win, merge_b, dual);
+			chain.run();
+		} else {
 			ScatterChain2<1> chain(node0, pv[0], pv[1], mass, win, merge_b);
 			chain.template at<0>();
 		}
