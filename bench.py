@@ -45,6 +45,12 @@ BYTES_PER_PARTICLE = {0: 72, 1: 136, 2: 144, 3: 144}  # BASELINE.md section 4 / 
 # SURVEY.md 8(d) "ALGORITHMIC FLOPs (secondary)": the reference formulation (27-node G2P ~1.0 k, P2G ~0.75 k, F update
 # ~0.1 k, SVD ~0.8 k, stress 0.1-0.2 k); this engine executes fewer (tensor-product gather, eigen-decomposition)
 FLOPS_PER_PARTICLE = {0: 1800, 1: 2700, 2: 2700, 3: 2700}
+def _pair_kernel(material):
+    """Which G2P2G instantiation the library launches for a material (claymore_hip.hip: MPM_PAIR_DEFAULT 0x7 - two particles per lane for the
+    J-fluid, fixed-corotated and sand -, overridden by the environment's MPM_G2P2G_PAIRS)."""
+    return bool((int(os.environ.get("MPM_G2P2G_PAIRS", "0x7"), 0) >> int(material)) & 1)
+
+
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3                        # MI355X_MICROARCH.md: peak FP32 (vector)
 
@@ -429,7 +435,7 @@ def main():
             "headline_window": "timed",   # which window roofline.frac / kernel_ms describe: "flow" once the flow window has run (below); `value` / ms_per_step are ALWAYS the timed K substeps (= roofline.rest then)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "g2p2g_kernel", "bytes_per_particle": bpp, "particles_per_launch": n_rank,
+                         "kernel": "g2p2g_pair_kernel" if _pair_kernel(material) else "g2p2g_kernel", "bytes_per_particle": bpp, "particles_per_launch": n_rank,
                          "kernel_ms": g2p2g_ms},
         }
         # the kernel's arithmetic intensity sits at the fp32-vector ridge, so the VALU side is reported too: the
@@ -468,7 +474,7 @@ def main():
             rest = dict(out["roofline"])
             fa = (n_rank * bpp) / (flow["kernel_ms"] * 1e-3) / 1e9
             head = {"bound": "hbm", "achieved": fa, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fa / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": "g2p2g_kernel", "bytes_per_particle": bpp, "particles_per_launch": n_rank, "kernel_ms": flow["kernel_ms"],
+                    "kernel": "g2p2g_pair_kernel" if _pair_kernel(material) else "g2p2g_kernel", "bytes_per_particle": bpp, "particles_per_launch": n_rank, "kernel_ms": flow["kernel_ms"],
                     "window": f"flow: substeps {flow['start_step']}-{flow['start_step'] + flow['steps']} of the same run (the column is collapsing); the timed K substeps are roofline.rest",
                     "start_step": flow["start_step"], "steps": flow["steps"], "ms_per_step": flow["ms_per_step"], "blocks": flow["blocks"]}
             tflf = (n_rank * fpp) / (flow["kernel_ms"] * 1e-3) / 1e12

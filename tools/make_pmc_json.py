@@ -40,7 +40,7 @@ def main(src, dst):
                        "(profiles/rNN_c3_default_pmc.txt, rNN_c3_moving_pmc.txt of the same round as this file); FETCH_SIZE calibrated on carry_grid_kernel of the same pass (a streaming kernel: the counter tallies a "
                        "128-B request as 64 B), WRITE_SIZE as reported.  The calibration holds for the rest window, whose record reads are streams; the flow window reads scattered 32-B records and row entries "
                        "(64-B requests are tallied in full), so its true read volume lies between read_bytes_uncalibrated and read_bytes: traffic_bytes is an UPPER bound there, traffic_bytes_low the lower one",
-           "kernel": "g2p2g_kernel<2>", "particles": n, "stamp": stamp,
+           "kernel": "g2p2g_pair_kernel<2> (g2p2g_kernel<2> before round 6)", "particles": n, "stamp": stamp,
            "rest": window(f"{src}/c3_default_pmc.txt", n), "flow": window(f"{src}/c3_moving_pmc.txt", n)}
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
