@@ -1213,3 +1213,104 @@ def test_g20_block_keys_particle_sets_and_table_against_the_references_statement
         from parity_util import match
         idx, _ = match(xo[m].astype(np.float64), xh[m].astype(np.float64))
         assert blk(xh[m][idx]) == blk(xo[m])
+
+
+def _ckpt_lists(eng, ppb):
+    """(size, records per block, pair counts per block) of model 0 out of a checkpoint (layout: see _hip_block_sets)."""
+    buf = eng.save_checkpoint()
+    hdr = np.frombuffer(buf[:48].tobytes(), np.int32)
+    pbc, nbc, ebc, prev_count = int(hdr[6]), int(hdr[7]), int(hdr[8]), int(hdr[9])
+    m0 = np.frombuffer(buf[64:64 + 48].tobytes(), np.int64)
+    nch = int(np.frombuffer(buf[64 + 4:64 + 8].tobytes(), np.int32)[0])
+    bincount_src, bucketed, layout = int(m0[4]), int(m0[5]), int(np.frombuffer(buf[64 + 12:64 + 16].tobytes(), np.int32)[0])
+    nmodels = int(hdr[4])
+    assert nmodels == 1 and layout == 1, "the model is not in the pair layout"
+    o = [448]
+
+    def take(nbytes, dtype):
+        a = np.frombuffer(buf[o[0]:o[0] + nbytes].tobytes(), dtype)
+        o[0] += (nbytes + 15) & ~15
+        return a
+    take(4 * 3 * ebc, np.int32), take(4 * 3 * prev_count, np.int32), take(4 * 256 * nbc, np.float32)
+    size = take(4 * (ebc + 1), np.int32)
+    take(4 * (ebc + 1), np.int32), take(4 * (prev_count + 1), np.int32), take(4 * (ebc + 1), np.int32)
+    take(4 * bincount_src * nch * 64, np.float32)
+    lists = take(4 * bucketed, np.int32)
+    pinfo = take(4 * pbc * 16, np.int32).reshape(pbc, 16)
+    out, at = [], 0
+    for b in range(pbc):
+        out.append((int(size[b]), lists[at:at + int(size[b])].astype(np.int64) & 0xffffffff, pinfo[b]))
+        at += int(size[b])
+    return out
+
+
+def test_the_sort_writes_the_pair_layout_it_promises():
+    """White-box check of prepare_blocks_kernel's pair layout (claymore_amd/csrc/mpm_kernels.hpp) on a scene in motion - a sand block thrown
+    into a corner, 220 substeps: cells fill unevenly, keys have odd counts, chunks run full.  Read out of a checkpoint, for every 512-record chunk of every
+    particle block: with n records and Pf full pairs (pairinfo) the S = ceil(n / 128) slices hold L = min(Pf + n1, 64 S) slots, dense; every pair slot's two
+    members carry the SAME sort key and the keys of the pair slots ascend (key-major order, the wrap-around rule); the mismatched slots are exactly
+    X = max(0, Pf + n1 - 64 S) and hold two different keys; no key has two singles; both members of a pair slot carry the same arena bit - its lane
+    parity -, and a single never uses the arena its own key's pair slot of the same slice uses."""
+    bits = 6
+    sc = scenes.sphere_drop(bits=bits, radius_cells=7.0, center=(0.3, 0.3, 0.3), material=_ffi.SAND)
+    sc["models"][0]["params"] = {}
+    sc["models"][0]["v0"] = (-6.0, -8.0, -5.0)
+    sc.setdefault("config", {})["max_ppc"] = 128
+    eng = build_engine(sc)
+    eng.initial_setup()
+    eng.run_fixed(220, 1e-4)
+    ppb = 8192
+    blocks = _ckpt_lists(eng, ppb)
+    eng.close()
+    pid_bits = 13
+    seen = dict(chunks=0, pairs=0, mismatched=0, singles=0, multi_chunk=0, full_slices=0)
+    for size, recs, pinfo in blocks:
+        nchunks = (size + 511) // 512
+        seen["multi_chunk"] += nchunks > 1
+        for c in range(nchunks):
+            n = min(512, size - 512 * c)
+            r = recs[512 * c:512 * c + n]
+            key, arena = (r >> pid_bits) & 255, (r >> 30) & 1
+            pf = int(pinfo[c])
+            n1 = n - 2 * pf
+            assert 0 <= pf and n1 >= 0
+            S = (n + 127) // 128
+            X = max(0, pf + n1 - 64 * S)
+            px, L = pf + X, pf + n1 - X
+            assert L <= 64 * S and L + px == n
+            pos = 0
+            slot_key = {}
+            for d in range(S):
+                ca, cb = L // S + (d < L % S), px // S + (d < px % S)
+                ka, kb = key[pos:pos + ca], key[pos + ca:pos + ca + cb]
+                aa, ab = arena[pos:pos + ca], arena[pos + ca:pos + ca + cb]
+                for ln in range(ca):
+                    slot_key[ln * S + d] = (int(ka[ln]), int(kb[ln]) if ln < cb else None, int(aa[ln]), ln, int(ab[ln]) if ln < cb else None)
+                pos += ca + cb
+                seen["full_slices"] += ca == 64
+            assert pos == n and sorted(slot_key) == list(range(L))
+            pair_keys = [slot_key[p][0] for p in range(pf)]
+            assert all(slot_key[p][0] == slot_key[p][1] for p in range(pf))                       # a pair slot: two records of one key
+            assert pair_keys == sorted(pair_keys)                                                 # key-major order
+            assert all(slot_key[p][2] == slot_key[p][4] == (slot_key[p][3] & 1) for p in range(pf))   # its arena, on both members: the lane parity (the kernel reads A's bit: a mismatched slot's B carries its own key's, unused)
+            assert all(slot_key[p][1] is not None and slot_key[p][0] != slot_key[p][1] for p in range(pf, px))   # a mismatched slot: two singles of different keys
+            assert all(slot_key[p][1] is None for p in range(px, L))                              # a single slot: A only
+            singles = [slot_key[p][0] for p in range(pf, L)] + [slot_key[p][1] for p in range(pf, px)]
+            assert len(singles) == len(set(singles)) == n1                                        # one single per key at most
+            from collections import Counter
+            cnt = Counter(pair_keys)
+            assert all(2 * cnt.get(k, 0) + (k in set(singles)) == int((key == k).sum()) for k in set(key.tolist()))
+            # the arena of a single (and of a mismatched slot, which carries its A's rule): not the one its key's pair slot of the same slice uses
+            by_slice = {}
+            for p in range(pf):
+                by_slice.setdefault((p % S, slot_key[p][0]), []).append(slot_key[p][2])
+            for p in range(pf, L):
+                used = by_slice.get((p % S, slot_key[p][0]), [])
+                if len(used) == 1:
+                    assert slot_key[p][2] != used[0]
+            seen["chunks"] += 1
+            seen["pairs"] += pf
+            seen["mismatched"] += X
+            seen["singles"] += n1
+    print("pair layout seen:", seen)
+    assert seen["chunks"] > 30 and seen["pairs"] > 2000 and seen["singles"] > 100 and seen["mismatched"] > 0 and seen["multi_chunk"] > 0, seen
