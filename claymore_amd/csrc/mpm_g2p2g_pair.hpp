@@ -24,13 +24,16 @@ namespace mpm {
 #endif
 // bit m: material m reads the 27 gather nodes once for both particles when the wave's pairs share their bases (else: one gather per particle)
 #if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_WAVES_FLUID))
-#define MPM_PAIR_WAVES_FLUID 3
+#define MPM_PAIR_WAVES_FLUID 4// (J-fluid: with the late record fetch below the instantiation needs 127 registers: four waves per SIMD, -2 % at rest, -3 % in the flow against three)
 #endif
 #if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_CZ2))
 #define MPM_PAIR_CZ2 0
 #endif
 #if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_DUAL))
 #define MPM_PAIR_DUAL 0// 1: a B that cannot ride with its A claims the other arena and scatters in the same chain (ScatterChainDual) instead of the serial path - measured +6 % in the C3 flow (every iteration with such a lane pays two read-modify-writes per step): off, profiles/r06_ab_pairs_phase2.txt
+#endif
+#if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_LATE_FETCH_FLUID))
+#define MPM_PAIR_LATE_FETCH_FLUID 1// the same switch for the J-fluid instantiation (16-byte records: the shorter prefetch distance costs nothing, the registers buy the fourth wave)
 #endif
 #if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_LATE_FETCH))
 #define MPM_PAIR_LATE_FETCH 0// 0: the next slice's particle records are requested at the top of the iteration; 1: behind the material update; 2: A's at the top, B's behind the material update
@@ -265,6 +268,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 	constexpr int NCH = MatTraits<MAT>::nch;
 	constexpr int REC = MatTraits<MAT>::rec;
 	constexpr bool kSharedGather = ((MPM_PAIR_SHARED_GATHER >> MAT) & 1) != 0;
+	constexpr int kLateFetch	 = MAT == 0 ? MPM_PAIR_LATE_FETCH_FLUID : MPM_PAIR_LATE_FETCH;
 	__shared__ float4 g2p[kG2PNodes];
 	__shared__ float4 p2g[kP2GArena2 + kP2GNodes];
 	__shared__ unsigned char s_owner[2 * 216];
@@ -297,18 +301,17 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 	//      slice or single slice.  The loop reads the descriptor two slices ahead with v_readlane: no scalar cursor to carry (a scalar one took ~100
 	//      scalar instructions per iteration and ~25 live scalar registers, i.e. spills into vector registers).
 	const int nchunks = (size + kListChunk - 1) / kListChunk;
-	int d_pos = 0, d_cnt = 0;// d_cnt = lanes with an A | lanes with a B << 8
+	int d_slice = 0;// position | lanes with an A << 16 | lanes with a B << 24 (one register: the loop is short of them)
 	auto form_slices = [&](int first) {// descriptors of slices first .. first + 63
 		int before = 0;// slices of the chunks before c (wave-uniform)
-		d_pos = 0, d_cnt = 0;
+		d_slice = 0;
 		for(int c = 0; c < nchunks; ++c) {
 			const PairChunk pc = pair_chunk(chunk_records(size, c), __builtin_amdgcn_readlane(pinfo, c));
 			const int t		   = first + lane - before;
 			if(t >= 0 && t < pc.S) {
 				int pos, ca, cb;
 				pair_slice(pc, t, pos, ca, cb);
-				d_pos = c * kListChunk + pos;
-				d_cnt = ca | (cb << 8);
+				d_slice = (c * kListChunk + pos) | (ca << 16) | (cb << 24);
 			}
 			before += pc.S;
 		}
@@ -318,8 +321,8 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 		int pos, cnt, cnt_b;// position of A's first record in the block's list; lanes with an A (0: beyond the end); lanes with a B (the first ones; B's records `cnt` behind A's)
 	};
 	auto read_slice = [&](int t, Slice& sl) {// t wave-uniform, inside the current batch
-		const int p = __builtin_amdgcn_readlane(d_pos, t & 63), c = __builtin_amdgcn_readlane(d_cnt, t & 63);
-		sl			= Slice {p, c & 255, c >> 8};
+		const int d = __builtin_amdgcn_readlane(d_slice, t & 63);
+		sl			= Slice {d & 0xffff, (d >> 16) & 255, d >> 24};
 	};
 	// (idle lanes re-read the last record of their member's run: same inputs, nothing stored; a slice without B's: the lane re-reads A's record;
 	//  beyond the end: the block's first record, never processed)
@@ -420,12 +423,8 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 		if(((t_cur + 2) & 63) == 0) form_slices(t_cur + 2);// (a block with more than 64 slices: the next batch of descriptors)
 		read_slice(t_cur + 2, s_nn);
 		load_recs(s_nn, rec_nn);
-#if MPM_PAIR_LATE_FETCH != 1
-		fetch(rec_next[0], pf[0]);
-#endif
-#if MPM_PAIR_LATE_FETCH == 0
-		fetch(rec_next[1], pf[1]);
-#endif
+		if constexpr(kLateFetch != 1) fetch(rec_next[0], pf[0]);
+		if constexpr(kLateFetch == 0) fetch(rec_next[1], pf[1]);
 		MPM_MARK("P_gather");
 		// ---- stencil bases + weights (:774-797), gather (:801-835)
 		int base[2][3], arena[2][3];
@@ -584,16 +583,12 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 				}
 			}
 		}
-#if MPM_PAIR_LATE_FETCH
-		// The next slice's particle records are requested HERE, behind the material update, not at the top of the iteration: requested at the top, their
+		// (kLateFetch) The next slice's particle records are requested HERE, behind the material update, not at the top of the iteration: requested at the top, their
 		// 22 destination registers (sand) are live through the gather and the material update, the allocator runs out, parks the loads in registers it
 		// needs again and waits for them - s_waitcnt vmcnt(0) in the re-bucketing, i.e. the whole HBM latency exposed in every iteration.  From here the
 		// loads have the scatter chain (27 LDS round trips) and the other two waves of the SIMD to arrive in.
-#if MPM_PAIR_LATE_FETCH == 1
-		fetch(rec_next[0], pf[0]);
-#endif
-		fetch(rec_next[1], pf[1]);
-#endif
+		if constexpr(kLateFetch == 1) fetch(rec_next[0], pf[0]);
+		if constexpr(kLateFetch != 0) fetch(rec_next[1], pf[1]);
 		MPM_MARK("P_scatter");
 		// ---- the pair scatters now (:887-905): payload ((:850) contrib = (A m - stress new_dt) D^-1, times dx: cell units), claim, 27 steps back to back
 		P2GPayload pv[2];
