@@ -23,7 +23,7 @@ Extra objects on the JSON line:
                  this run's kernel time / 8 TB/s (what the memory system really moved, beside the algorithmic figure).
                  NOTE: `value` and `ms_per_step` are ALWAYS the timed K substeps; when `headline_window` is "flow", roofline.frac /
                  kernel_ms describe ANOTHER window of the same run - the pair that belongs to `value` is roofline.rest
-                 (roofline.timed_frac repeats its fraction)
+                 (roofline.timed_frac repeats its fraction); roofline.deep is a third window after --deep-start substeps (default 9000: deep in the collapse)
   cpu_baseline - the CPU oracle ("port" of the reference pipeline) timed on this host on the same input, outside the timed
                  region (rank 0, N = 1 only): OpenMP over G2P2G's particle blocks, the grid update and the rebuild's
                  order-independent loops; `cores` = the threads it ran on
@@ -223,6 +223,8 @@ def main():
     ap.add_argument("--flow-start", type=int, default=3000,
                     help="N = 1, default scene: after the timed window the run goes on to this substep and a second short window is timed "
                          "inside the flow (reported as roofline.flow; 0 = skip)")
+    ap.add_argument("--deep-start", type=int, default=9000,
+                    help="default run (N = 1, C3): a third 20-substep window after this many substeps, deep in the collapse -> roofline.deep (0 = skip; adds ~15 s)")
     ap.add_argument("--sync-interval", type=int, default=0, help="debug: mpm_config.sync_interval (0 = library default)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="debug: rank r uses device r %% (devices present) instead of device LOCAL_RANK - several ranks per GPU.  RCCL refuses "
@@ -373,6 +375,20 @@ def main():
             assert sum(cf.particles[i] for i in range(cf.model_count)) == n_total and df.lost_particles == 0, "flow window lost particles"
             flow = {"start_step": args.flow_start + 5, "steps": 20, "kernel_ms": tmf.g2p2g_ms, "ms_per_step": 1e3 * tf / 20,
                     "blocks": {"particle": cf.particle_blocks, "neighbor": cf.neighbor_blocks, "exterior": cf.exterior_blocks}}
+            if args.deep_start > args.flow_start + 25:
+                # third window, deep in the collapse (the flow window is not the worst of the configured workload): the pile spreads
+                # against the walls, single cells hold hundreds of particles
+                eng.run_fixed(args.deep_start - (args.flow_start + 25), dt)
+                eng.run_fixed(5, dt)
+                torch.cuda.synchronize()
+                td0 = time.perf_counter()
+                eng.run_fixed(20, dt)
+                torch.cuda.synchronize()
+                td = time.perf_counter() - td0
+                tmd, dd, cd = eng.timers(), eng.diagnostics(), eng.counts()
+                assert sum(cd.particles[i] for i in range(cd.model_count)) == n_total and dd.lost_particles == 0, "deep window lost particles"
+                flow["deep"] = {"start_step": args.deep_start + 5, "steps": 20, "kernel_ms": tmd.g2p2g_ms, "ms_per_step": 1e3 * td / 20,
+                                "blocks": {"particle": cd.particle_blocks, "neighbor": cd.neighbor_blocks, "exterior": cd.exterior_blocks}}
         eng.close()
     else:
         from claymore_amd.mgsp import MgspGroupRank
@@ -481,6 +497,12 @@ def main():
             head["valu"] = {"flops_per_particle": fpp, "achieved_tflops": tflf, "peak": FP32_VECTOR_PEAK_TFLOPS, "frac": tflf / FP32_VECTOR_PEAK_TFLOPS,
                             "note": "algorithmic FLOPs of the reference formulation (SURVEY.md 8d), not executed instructions"}
             attach(head, "flow", flow["kernel_ms"])
+            if "deep" in flow:
+                dp = flow["deep"]
+                da = (n_rank * bpp) / (dp["kernel_ms"] * 1e-3) / 1e9
+                head["deep"] = {"bound": "hbm", "achieved": da, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": da / HBM_PEAK_GBS, "kernel_ms": dp["kernel_ms"],
+                                "window": f"deep: substeps {dp['start_step']}-{dp['start_step'] + dp['steps']} of the same run (the pile spreads against the walls)",
+                                "ms_per_step": dp["ms_per_step"], "blocks": dp["blocks"]}
             head["rest"] = rest
             head["timed_frac"] = rest["frac"]      # the fraction that belongs to `value` / ms_per_step (a consumer must not pair `value` with roofline.frac of another window)
             out["roofline"] = head
