@@ -1314,3 +1314,31 @@ def test_the_sort_writes_the_pair_layout_it_promises():
             seen["singles"] += n1
     print("pair layout seen:", seen)
     assert seen["chunks"] > 30 and seen["pairs"] > 2000 and seen["singles"] > 100 and seen["mismatched"] > 0 and seen["multi_chunk"] > 0, seen
+
+
+def test_mid_size_flow_parity_630k():
+    """The flow regime against the ORACLE at a size where every path of G2P2G carries thousands of particles per substep (at scale
+    the claim losers, edge lanes, shell atomics - and since round 6 the split pairs - had been compared with the oracle on <= 10 k-particle scenes only;
+    the 40 M-particle runs are 8 substeps against the oracle or invariants): a 32 x 77 x 32-cell column of Drucker-Prager sand (630 784 particles, 256^3)
+    one block above the floor's wall zone, thrown at it obliquely at (1.5, -4, 0.8) m/s - it hits after ~25 substeps, the lower half yields and spreads,
+    2 % of the particles change block per substep -, 160 substeps on both engines (the oracle on 32 threads), particles matched by nearest neighbour
+    (unambiguous while the deviation is far below the spacing of 0.5 dx): positions, b, log Jp and the block counts."""
+    bits = 8
+    sc = scenes.sand_column(bits, (32, 77, 32), min_corner=(112, 12, 112))
+    sc["models"][0]["v0"] = (1.5, -4.0, 0.8)
+    n = scenes.total_particles(sc)
+    assert n == 630784
+    nsteps, dt = 160, 1e-4
+    hip = run_engine(sc, nsteps, dt)
+    ora = run_engine(sc, nsteps, dt, api=oracle_api_threads(32))
+    res = {"hip": hip, "oracle": ora, "scene": sc}
+    err = match_and_compare(res)
+    print("mid-size flow parity:", err)
+    assert err["pos_rel"] < POS_TOL, err
+    # b and log Jp of a particle that yields in a 4 m/s impact: 3 x the measured 4.0e-4 (relative to max(1, |b|)) / 1.7e-4 - the return mapping
+    # amplifies a 1e-7 difference of the trial strain by the stiffness ratio; the positions above do not feel it
+    assert err["state_rel"] < 1.2e-3 and err["logjp_abs"] < 5e-4, err
+    ch, co = hip["counts"], ora["counts"]
+    assert (ch.particle_blocks, ch.neighbor_blocks, ch.exterior_blocks) == (co.particle_blocks, co.neighbor_blocks, co.exterior_blocks)
+    xo = ora["state"][0][0]
+    assert xo[:, 1].min() < 13.5 / 256 and np.abs(ora["state"][0][2]).max() > 1e-3      # it reached the floor and yielded
