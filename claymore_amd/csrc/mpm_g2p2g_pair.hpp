@@ -412,11 +412,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 			}
 			okey[h] = pf[h].key & 255;
 		}
-#if defined(MPM_EXPERIMENT) && defined(MPM_HACK_LANE_ARENA)// timing experiment only (valid where every slot is a pair slot): the arena from the lane parity, not from the record
-		const int arena_sel = lane & 1;
-#else
 		const int arena_sel = pf[0].key >> 8;// the slot's scatter arena
-#endif
 		// the list records two slices ahead, the particle records one slice ahead
 		Slice s_nn;
 		int rec_nn[2];
@@ -628,59 +624,6 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 		const bool win	   = a_ok && (int) s_owner[key_a] == lane;
 		const bool dual	   = b_own && (int) s_owner[key_b] == (lane | 64);
 		const bool merge_b = win && b_same;
-#if defined(MPM_EXPERIMENT) && defined(MPM_HACK_CHAIN_FIRST)
-		MPM_MARK("P_chain");
-		float4* const node0 = p2g + (win ? code_off(pv_code[0]) + arena_sel * kP2GArena2 : 0);
-		if(__any(dual)) {
-			float4* const node1 = p2g + (dual ? code_off(pv_code[1]) + (arena_sel ^ 1) * kP2GArena2 : 0);
-			ScatterChainDual chain(node0, node1, pv[0], pv[1], mass, win, merge_b, dual);
-			chain.run();
-		} else {
-			ScatterChain2<1> chain(node0, pv[0], pv[1], mass, win, merge_b);
-			chain.template at<0>();
-		}
-		MPM_MARK("P_serial");
-		// ---- what the chain will not take - A without a claim or on the cube's edge, B neither riding with its A nor holding a claim of its own - goes first:
-		//      the payloads are dead once the chain is set up (both add into the arenas with plain read-modify-writes; a single wave's LDS operations execute
-		//      in program order)
-		{
-			const bool left_a = pv_in[0] && !win;
-#if defined(MPM_EXPERIMENT) && defined(MPM_HACK_NOSPLIT)// timing experiment only: a B that does not ride with its A is dropped (wrong physics)
-			const bool left_b = false;
-#else
-			const bool left_b = pv_in[1] && !merge_b && !dual;
-#endif
-#ifdef MPM_G2P2G_STATS
-			st_iter += 1;
-			st_losers += __popcll(__ballot(left_a && !code_edge(pv_code[0]))) + __popcll(__ballot(left_b && !code_edge(pv_code[1])));
-			st_edge += __popcll(__ballot(pv_in[0] && code_edge(pv_code[0]))) + __popcll(__ballot(pv_in[1] && code_edge(pv_code[1])));
-			st_split += __popcll(__ballot(dual));
-			st_retry_iters += __any(left_a || left_b) ? 1 : 0;
-#endif
-#if defined(MPM_EXPERIMENT) && defined(MPM_HACK_NOSERIAL)// timing experiment only: what the chain does not take is dropped (wrong physics)
-			if(false)
-#else
-			if(__any(left_a))
-#endif
-			{
-				if constexpr(kQueue)
-					serial_push(p2g, s_queue, qn, left_a, pv_code[0], pv[0], mass, lane, info, next_grid);
-				else
-					p2g_serial(p2g, left_a, pv_code[0], pv[0], mass, lane, info, next_grid);
-			}
-#if defined(MPM_EXPERIMENT) && defined(MPM_HACK_NOSERIAL)
-			if(false)
-#else
-			if(__any(left_b))
-#endif
-			{
-				if constexpr(kQueue)
-					serial_push(p2g, s_queue, qn, left_b, pv_code[1], pv[1], mass, lane, info, next_grid);
-				else
-					p2g_serial(p2g, left_b, pv_code[1], pv[1], mass, lane, info, next_grid);
-			}
-		}
-#else
 		MPM_MARK("P_serial");
 		// ---- what the chain will not take - A without a claim or on the cube's edge, B neither riding with its A nor holding a claim of its own - goes first:
 		//      the payloads are dead once the chain is set up (both add into the arenas with plain read-modify-writes; a single wave's LDS operations execute
@@ -732,7 +675,6 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 			ScatterChain2<1> chain(node0, pv[0], pv[1], mass, win, merge_b);
 			chain.template at<0>();
 		}
-#endif
 		if(s_next.cnt == 0) break;
 		s_cur  = s_next;
 		s_next = s_nn;

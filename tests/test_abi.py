@@ -91,7 +91,7 @@ def test_experiment_switch_without_the_guard_does_not_compile():
     src = os.path.join(ROOT, "claymore_amd", "csrc", "mpm_device_math.hpp")
     base = [ge.HIPCC, "--offload-arch=gfx950", "-std=c++17", "--cuda-device-only", "-x", "hip", "-E", "-o", os.devnull, src]
     assert subprocess.run(base, capture_output=True).returncode == 0
-    for sw in ("MPM_HACK_NOSERIAL", "MPM_HACK_NOSHELL", "MPM_HACK_NOWB", "MPM_HACK_UNDEF", "MPM_G2P2G_WAVES=2"):
+    for sw in ("MPM_HACK_NOSERIAL", "MPM_HACK_NOSHELL", "MPM_HACK_NOWB", "MPM_HACK_UNDEF", "MPM_G2P2G_WAVES=2", "MPM_HACK_NOSPLIT", "MPM_PAIR_WAVES=2", "MPM_PAIR_DUAL=1"):
         r = subprocess.run(base + ["-D" + sw], capture_output=True, text=True)
         assert r.returncode != 0 and "MPM_EXPERIMENT" in r.stderr, (sw, r.stderr[-300:])
         assert subprocess.run(base + ["-D" + sw, "-DMPM_EXPERIMENT"], capture_output=True).returncode == 0
