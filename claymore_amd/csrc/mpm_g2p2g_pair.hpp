@@ -26,9 +26,6 @@ namespace mpm {
 #if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_WAVES_FLUID))
 #define MPM_PAIR_WAVES_FLUID 4// (J-fluid: with the late record fetch below the instantiation needs 127 registers: four waves per SIMD, -2 % at rest, -3 % in the flow against three)
 #endif
-#if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_CZ2))
-#define MPM_PAIR_CZ2 0
-#endif
 #if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_DUAL))
 #define MPM_PAIR_DUAL 0// 1: a B that cannot ride with its A claims the other arena and scatters in the same chain (ScatterChainDual) instead of the serial path - measured +6 % in the C3 flow (every iteration with such a lane pays two read-modify-writes per step): off, profiles/r06_ab_pairs_phase2.txt
 #endif
@@ -162,13 +159,8 @@ struct ChainHalf {
 		}
 		const float W  = wij * pw[2][k];
 		// (k = 2: fma with the constant 2 - the doubled z row of ScatterChain would cost three registers per particle)
-#if MPM_PAIR_CZ2
-		const v2f_ m0  = {mass, k == 0 ? pen0 : (k == 1 ? pen0 + cz0 : pen0 + (cz0 + cz0))};
-		const v2f_ t12 = k == 0 ? pen12 : (k == 1 ? pen12 + cz12 : pen12 + (cz12 + cz12));
-#else
 		const v2f_ m0  = {mass, k == 0 ? pen0 : (k == 1 ? pen0 + cz0 : fmaf(2.f, cz0, pen0))};
 		const v2f_ t12 = k == 0 ? pen12 : (k == 1 ? pen12 + cz12 : cz12 * 2.f + pen12);
-#endif
 		a01			   = m0 * W + a01;
 		a23			   = t12 * W + a23;
 	}
