@@ -46,9 +46,9 @@ BYTES_PER_PARTICLE = {0: 72, 1: 136, 2: 144, 3: 144}  # BASELINE.md section 4 / 
 # ~0.1 k, SVD ~0.8 k, stress 0.1-0.2 k); this engine executes fewer (tensor-product gather, eigen-decomposition)
 FLOPS_PER_PARTICLE = {0: 1800, 1: 2700, 2: 2700, 3: 2700}
 def _pair_kernel(material):
-    """Which G2P2G instantiation the library launches for a material (claymore_hip.hip: MPM_PAIR_DEFAULT 0x7 - two particles per lane for the
-    J-fluid, fixed-corotated and sand -, overridden by the environment's MPM_G2P2G_PAIRS)."""
-    return bool((int(os.environ.get("MPM_G2P2G_PAIRS", "0x7"), 0) >> int(material)) & 1)
+    """Which G2P2G instantiation the library launches for a material (claymore_hip.hip: MPM_PAIR_DEFAULT 0xF - two particles per lane for all
+    four materials -, overridden by the environment's MPM_G2P2G_PAIRS)."""
+    return bool((int(os.environ.get("MPM_G2P2G_PAIRS", "0xF"), 0) >> int(material)) & 1)
 
 
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8 TB/s spec
@@ -183,7 +183,7 @@ def attach_counters(dst, pmc, pmc_name, window, lib_sha, kernel_ms, n_rank, bpp)
                                  "counters of another build are not attached (re-take the PMC passes: tools/gpu_profile_r05.sh)")
         return
     dst["traffic"] = w["traffic_bytes"]
-    dst["traffic_source"] = f"{pmc_name}[{window}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of g2p2g_kernel<2>, corrected as MI355X_MICROARCH.md prescribes; {pmc.get('stamp', 'unstamped')}: the library this run loaded)"
+    dst["traffic_source"] = f"{pmc_name}[{window}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of {pmc.get('kernel', 'the G2P2G kernel')}, corrected as MI355X_MICROARCH.md prescribes; {pmc.get('stamp', 'unstamped')}: the library this run loaded)"
     if kernel_ms > 0:
         # what the memory system moved per launch (counters of the profiled launch) over THIS run's kernel time: the physical HBM rate
         dst["physical_frac"] = w["traffic_bytes"] / (kernel_ms * 1e-3) / (HBM_PEAK_GBS * 1e9)

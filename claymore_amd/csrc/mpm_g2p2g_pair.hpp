@@ -32,6 +32,9 @@ namespace mpm {
 #if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_LATE_FETCH_FLUID))
 #define MPM_PAIR_LATE_FETCH_FLUID 1// the same switch for the J-fluid instantiation (16-byte records: the shorter prefetch distance costs nothing, the registers buy the fourth wave)
 #endif
+#if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_LATE_FETCH_NACC))
+#define MPM_PAIR_LATE_FETCH_NACC 1// NACC: with the early fetch the instantiation reloads a dozen spilled constants per iteration; with the late one it needs 165 registers and none
+#endif
 #if !(defined(MPM_EXPERIMENT) && defined(MPM_PAIR_LATE_FETCH))
 #define MPM_PAIR_LATE_FETCH 0// 0: the next slice's particle records are requested at the top of the iteration; 1: behind the material update; 2: A's at the top, B's behind the material update
 #endif
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 	constexpr int NCH = MatTraits<MAT>::nch;
 	constexpr int REC = MatTraits<MAT>::rec;
 	constexpr bool kSharedGather = ((MPM_PAIR_SHARED_GATHER >> MAT) & 1) != 0;
-	constexpr int kLateFetch	 = MAT == 0 ? MPM_PAIR_LATE_FETCH_FLUID : MPM_PAIR_LATE_FETCH;
+	constexpr int kLateFetch	 = MAT == 0 ? MPM_PAIR_LATE_FETCH_FLUID : (MAT == 3 ? MPM_PAIR_LATE_FETCH_NACC : MPM_PAIR_LATE_FETCH);
 	__shared__ float4 g2p[kG2PNodes];
 	__shared__ float4 p2g[kP2GArena2 + kP2GNodes];
 	__shared__ unsigned char s_owner[2 * 216];

@@ -1346,10 +1346,9 @@ def test_mid_size_flow_parity_630k():
 
 @pytest.mark.parametrize("mask", ["0", "0xF"])
 def test_both_g2p2g_kernels_pass_the_material_parity_tests(mask):
-    """The library ships two G2P2G kernels - one particle per lane (mpm_g2p2g.hpp) and two (mpm_g2p2g_pair.hpp; the default for the J-fluid,
-    fixed-corotated and sand) - selected per material by a mask the library reads once per process (MPM_G2P2G_PAIRS).  The suite runs with the
-    default; this test runs the material parity tests against the oracle in a subprocess with the mask forced to NO pairs and to ALL FOUR materials
-    (NACC's pair instantiation is compiled in but not the default), so that neither kernel nor layout rots: both pass the same bounds."""
+    """The library ships two G2P2G kernels - one particle per lane (mpm_g2p2g.hpp) and two (mpm_g2p2g_pair.hpp; the default) - selected per material by a mask the library reads once per process (MPM_G2P2G_PAIRS).  The suite runs with the
+    default (all four materials on pairs); this test runs the material parity tests against the oracle in a subprocess with the mask forced to NO pairs
+    and to ALL FOUR materials, so that neither kernel nor layout rots: both pass the same bounds."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))

@@ -107,6 +107,17 @@ def main():
                 g, p, w = window(eng, 10, 40, sc4["dt"])
                 row.append(f"| C4 one sphere: g2p2g {g:.4f} step {w:.4f}")
                 eng.close()
+            if "c2nacc" in want:   # C2's sphere as NACC (no BASELINE config uses NACC: a scene for its kernel instantiation alone)
+                from claymore_amd import _ffi as _f
+                scn = scenes.sphere_drop(material=_f.NACC)
+                scn["models"][0]["params"] = {}
+                eng = build_engine(scn, api=api)
+                eng.initial_setup()
+                g, p, w = window(eng, 10, 50, scn["dt"])
+                row.append(f"| C2 as NACC at rest: g2p2g {g:.4f} step {w:.4f}")
+                g, p, w = window(eng, 400, 50, scn["dt"])     # (in free fall; the default NACC parameters do not survive the impact at step ~2500 in either kernel)
+                row.append(f"after 500: g2p2g {g:.4f} step {w:.4f}")
+                eng.close()
             if "c5flow" in want:   # the dam break under way
                 sc5f = scenes.fluid_dam(10, (32, 192, 256))
                 eng = build_engine(sc5f, api=api)

@@ -36,7 +36,7 @@ def main(src, dst):
     n = 40108032
     first = open(f"{src}/c3_default_pmc.txt").readline()
     stamp = first[first.rfind("(") + 1:first.rfind(")")] if "(" in first else "unstamped"
-    out = {"_comment": "g2p2g_kernel<2> per launch on C3 (40 108 032 sand particles, 512^3), MI355X; rocprofv3 --pmc passes of tools/gpu_profile_rNN.sh "
+    out = {"_comment": "the sand G2P2G kernel (see `kernel`) per launch on C3 (40 108 032 sand particles, 512^3), MI355X; rocprofv3 --pmc passes of tools/gpu_profile_rNN.sh "
                        "(profiles/rNN_c3_default_pmc.txt, rNN_c3_moving_pmc.txt of the same round as this file); FETCH_SIZE calibrated on carry_grid_kernel of the same pass (a streaming kernel: the counter tallies a "
                        "128-B request as 64 B), WRITE_SIZE as reported.  The calibration holds for the rest window, whose record reads are streams; the flow window reads scattered 32-B records and row entries "
                        "(64-B requests are tallied in full), so its true read volume lies between read_bytes_uncalibrated and read_bytes: traffic_bytes is an UPPER bound there, traffic_bytes_low the lower one",
