@@ -68,6 +68,11 @@ struct mpm_ctx {
 	hipEvent_t ev_tag0 = nullptr, ev_tag1 = nullptr;// group loop: key list exported (compute -> comm) / tagging complete (comm -> compute); created on first use
 	// MGSP windowed loop: the status read-back of substep t is waited for AFTER the halo-first G2P2G of substep t + 1 has been enqueued,
 	// so the timing events exist twice (index = parity of the substep)
+	// lean_events (the windowed group loop in its deferred order): a substep records three events on the compute stream instead of seven - an event between two
+	// kernels is a barrier packet of its own, 5-6 us each (profiles/r06_rank_alone_seq.txt) -: no start event (a substep's time is end-to-end of the previous one's),
+	// the end event doubles as the read-back's, the halo event is recorded once.  ev_pending: the event the outstanding read-back completes with.
+	bool lean_events = false;
+	hipEvent_t ev_pending = nullptr;
 	hipEvent_t ev_status = nullptr, ev2_a[2] = {nullptr, nullptr}, ev2_b[2] = {nullptr, nullptr}, ev2_g0[2] = {nullptr, nullptr}, ev2_g1[2] = {nullptr, nullptr};
 	// grid[0] already holds the velocities of the coming substep (the rebuild's carry-over applied the grid update for this dt):
 	// only inside mpm_run_fixed, never when a call returns
@@ -77,7 +82,7 @@ struct mpm_ctx {
 	// Between two host synchronisations of mpm_run_fixed the block counts below are ESTIMATES (the values of the last
 	// synchronisation): launches are sized by them with a margin, every kernel reads the true counts from the status block.
 	bool rebuild_cleared = false;// the rebuild's part of substep_clear_kernel has been issued together with the P2G part
-	std::vector<hipEvent_t> ev_ring;// 4 events per substep of a window (substep start, G2P2G start / end, substep end)
+	std::vector<hipEvent_t> ev_ring;// 3 events per substep of a window (substep start, G2P2G start / end; its end is the next one's start) + the window's closing event
 	Partition part[2];
 	float* grid[2] = {nullptr, nullptr};
 	int rollid	   = 0;
@@ -996,7 +1001,7 @@ int mpm_run_fixed(mpm_ctx* ctx, int nsteps, float dt) {
 	hipStream_t s = ctx->s_compute;
 	const int K = ctx->cfg.sync_interval > 0 ? std::min(ctx->cfg.sync_interval, 64) : 8;// (clamped to 64: claymore_amd.h)
 	FlagGuard guard {ctx};
-	while((int) ctx->ev_ring.size() < 4 * K) {
+	while((int) ctx->ev_ring.size() < 3 * K + 1) {
 		hipEvent_t e = nullptr;
 		HIP_TRY(hipEventCreate(&e));
 		ctx->ev_ring.push_back(e);
@@ -1008,8 +1013,10 @@ int mpm_run_fixed(mpm_ctx* ctx, int nsteps, float dt) {
 	double acc_grid = 0, acc_g2p2g = 0, acc_part = 0, acc_total = 0;
 	int in_window = 0;
 	for(int it = 0; it < nsteps; ++it) {
-		hipEvent_t* ev = &ctx->ev_ring[4 * in_window];
-		HIP_TRY(hipEventRecord(ev[0], s));
+		// three events per substep - start, G2P2G start, G2P2G end -; its end is the next substep's start (or the window's closing event): an event between two
+		// kernels is a barrier packet of its own, 5-6 us on the stream (profiles/r06_rank_alone_seq.txt), a tenth of a 0.2 ms substep when there were four
+		hipEvent_t* ev = &ctx->ev_ring[3 * in_window];
+		if(in_window == 0) HIP_TRY(hipEventRecord(ev[0], s));
 		int rc = launch_grid_update(ctx, dt);
 		if(rc) return rc;
 		const bool fuse_next = it + 1 < nsteps;// the last substep leaves the canonical state behind
@@ -1031,7 +1038,7 @@ int mpm_run_fixed(mpm_ctx* ctx, int nsteps, float dt) {
 			if(rc) return rc;
 			if(std::isinf(host_maxvel(ctx))) return fail(ctx, MPM_ERR_NONFINITE, "Maximum velocity is infinity");
 			for(int w = 0; w < in_window; ++w) {
-				hipEvent_t* e = &ctx->ev_ring[4 * w];
+				hipEvent_t* e = &ctx->ev_ring[3 * w];
 				float t_grid = 0, t_g = 0, t_part = 0, t_tot = 0;
 				HIP_TRY(hipEventElapsedTime(&t_grid, e[0], e[1]));
 				HIP_TRY(hipEventElapsedTime(&t_g, e[1], e[2]));
