@@ -17,7 +17,7 @@
 #if defined(MPM_NO_FASTSTAY) || defined(MPM_HACK_STALE_INTERIOR) || defined(MPM_HACK_EDGEWIN) || defined(MPM_HACK_NOSHELL) || defined(MPM_HACK_NOSERIAL) || defined(MPM_HACK_NOWB) || defined(MPM_HACK_UNDEF) || defined(MPM_SCALAR_GS) || defined(MPM_GATHER_B96) || \
 	defined(MPM_NT_LOADS) || defined(MPM_LDS_PAD) || defined(MPM_G2P2G_NOLOOP) || defined(MPM_G2P2G_STATS) || defined(MPM_PRE_SITES) || defined(MPM_SERIAL_QUEUE) ||        \
 	defined(MPM_G2P2G_WAVES) || defined(MPM_G2P2G_WAVES_FLUID) || defined(MPM_QUEUE_ENTRIES) || defined(MPM_HACK_NOSPLIT) || defined(MPM_PAIR_WAVES) || defined(MPM_PAIR_WAVES_FLUID) ||                   \
-	defined(MPM_PAIR_SHARED_GATHER) || defined(MPM_PAIR_LATE_FETCH) || defined(MPM_PAIR_LATE_FETCH_FLUID) || defined(MPM_PAIR_LATE_FETCH_NACC) || defined(MPM_PAIR_DUAL)
+	defined(MPM_PAIR_SHARED_GATHER) || defined(MPM_PAIR_LATE_FETCH) || defined(MPM_PAIR_LATE_FETCH_FLUID) || defined(MPM_PAIR_LATE_FETCH_NACC) || defined(MPM_PAIR_DUAL) || defined(MPM_GATHER_ASM) || defined(MPM_CHAIN_ASM)
 #error "experiment switch without -DMPM_EXPERIMENT: a product library is built with none of them"
 #endif
 #endif

@@ -112,6 +112,24 @@ struct P2GPayload {
 // x / y components and the (w, w (x_i - x_p)) weight pairs go through packed fp32.  A node is {vx, vy, vz, vz}: the
 // duplicate makes the load a full ds_read_b128 (4.0 cycles per wave against 7.1 for ds_read_b96) and gives the z
 // accumulators a natural register pair.
+#if !defined(MPM_EXPERIMENT) || !defined(MPM_GATHER_ASM)
+#define MPM_GATHER_ASM 1
+#endif
+typedef float v4f_ __attribute__((ext_vector_type(4)));
+// One z-pencil of the gather arena (three nodes, 16 B each) with all three reads IN FLIGHT and a wait in front of each use.  Written out because the
+// compiler, short of registers in this kernel, loads the three nodes into ONE register quad, one after the other, each behind s_waitcnt lgkmcnt(0): 54 exposed
+// LDS round trips per pair of particles.  The waits are safe whatever else the compiler has outstanding: LDS operations complete in order, lgkmcnt(N) says "all but
+// the newest N are done", and operations the compiler does not know about only make its own waits longer.  (No scalar loads inside the particle loop: tools/kstat.sh.)
+template<int OFF>
+MPM_DEV v4f_ lds_issue_b128(unsigned addr) {
+	v4f_ v;
+	__asm__ volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(v) : "v"(addr), "n"(OFF) : "memory");
+	return v;
+}
+template<int N>
+MPM_DEV void lds_arrived(v4f_& v) {// v was requested when N younger LDS reads were issued after it
+	__asm__ volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
+}
 MPM_DEV void gather_apic(const float4* __restrict__ gbase, const float (&w)[3][3], const float (&fd)[3], float (&vel)[3], float (&A)[9]) {
 	v2f_ wz[3], wy[3], wx[3];// {w, w * (node - particle)} per axis and stencil offset
 #pragma unroll
@@ -123,6 +141,60 @@ MPM_DEV void gather_apic(const float4* __restrict__ gbase, const float (&w)[3][3
 	v2f_ vel_xy = {0.f, 0.f}, A0_xy = {0.f, 0.f}, A3_xy = {0.f, 0.f}, A6_xy = {0.f, 0.f};
 	v2f_ velz_A2 = {0.f, 0.f};
 	float A5 = 0.f, A8 = 0.f;
+#if MPM_GATHER_ASM
+	// (Also measured: a rolling window - node q + 3 requested into the registers node q leaves behind - needs two registers more, which the sand and J-fluid
+	//  instantiations pay with a reload inside the particle loop: +3 % / +1.5 %, profiles/r06_ab_pairs_phase2.txt.)
+	const unsigned lds0 = (unsigned) (size_t) gbase;// (the low half of a generic pointer into LDS is the LDS address)
+	v2f_ u0_xy, uy_xy, uz_xy, u0z_uyz;
+	float uzz;
+	auto pencil = [&](auto ic, auto jc) {
+		constexpr int I = decltype(ic)::value, J = decltype(jc)::value;
+		constexpr int off = (I * kG2PStrideX + J * kG2PStrideY) * 16;
+		v4f_ n0 = lds_issue_b128<off>(lds0), n1 = lds_issue_b128<off + kG2PStrideZ * 16>(lds0), n2 = lds_issue_b128<off + 2 * kG2PStrideZ * 16>(lds0);
+		v2f_ t0_xy, t1_xy, t0z_t1z;
+		lds_arrived<2>(n0);
+		{
+			const v2f_ vxy = {n0.x, n0.y}, vzz = {n0.z, n0.w};
+			t0_xy = vxy * wz[0].x, t1_xy = vxy * wz[0].y, t0z_t1z = wz[0] * vzz;
+		}
+		lds_arrived<1>(n1);
+		{
+			const v2f_ vxy = {n1.x, n1.y}, vzz = {n1.z, n1.w};
+			t0_xy = vxy * wz[1].x + t0_xy, t1_xy = vxy * wz[1].y + t1_xy, t0z_t1z = wz[1] * vzz + t0z_t1z;
+		}
+		lds_arrived<0>(n2);
+		{
+			const v2f_ vxy = {n2.x, n2.y}, vzz = {n2.z, n2.w};
+			t0_xy = vxy * wz[2].x + t0_xy, t1_xy = vxy * wz[2].y + t1_xy, t0z_t1z = wz[2] * vzz + t0z_t1z;
+		}
+		__builtin_amdgcn_sched_barrier(0);// one pencil at a time: registers are the scarce resource
+		if constexpr(J == 0) {
+			u0_xy = t0_xy * wy[0].x, uy_xy = t0_xy * wy[0].y, uz_xy = t1_xy * wy[0].x, u0z_uyz = wy[0] * t0z_t1z.x, uzz = wy[0].x * t0z_t1z.y;
+		} else {
+			u0_xy	= t0_xy * wy[J].x + u0_xy;
+			uy_xy	= t0_xy * wy[J].y + uy_xy;
+			uz_xy	= t1_xy * wy[J].x + uz_xy;
+			u0z_uyz = wy[J] * t0z_t1z.x + u0z_uyz;
+			uzz += wy[J].x * t0z_t1z.y;
+		}
+	};
+	auto slab = [&](auto ic) {
+		constexpr int I = decltype(ic)::value;
+		pencil(ic, std::integral_constant<int, 0> {});
+		pencil(ic, std::integral_constant<int, 1> {});
+		pencil(ic, std::integral_constant<int, 2> {});
+		vel_xy	= u0_xy * wx[I].x + vel_xy;
+		A0_xy	= u0_xy * wx[I].y + A0_xy;
+		A3_xy	= uy_xy * wx[I].x + A3_xy;
+		A6_xy	= uz_xy * wx[I].x + A6_xy;
+		velz_A2 = wx[I] * u0z_uyz.x + velz_A2;
+		A5 += wx[I].x * u0z_uyz.y;
+		A8 += wx[I].x * uzz;
+	};
+	slab(std::integral_constant<int, 0> {});
+	slab(std::integral_constant<int, 1> {});
+	slab(std::integral_constant<int, 2> {});
+#else
 #pragma unroll
 	for(int i = 0; i < 3; ++i) {
 		v2f_ u0_xy = {0.f, 0.f}, uy_xy = {0.f, 0.f}, uz_xy = {0.f, 0.f}, u0z_uyz = {0.f, 0.f};
@@ -153,6 +225,7 @@ MPM_DEV void gather_apic(const float4* __restrict__ gbase, const float (&w)[3][3
 		A5 += wx[i].x * u0z_uyz.y;
 		A8 += wx[i].x * uzz;
 	}
+#endif
 	vel[0] = vel_xy.x;
 	vel[1] = vel_xy.y;
 	vel[2] = velz_A2.x;

@@ -144,7 +144,8 @@ struct ChainHalf {
 		slab0  = p.mv[0] - cx0 * p.fd[0] - cy0 * p.fd[1] - cz0 * p.fd[2];
 		slab12 = (v2f_) {p.mv[1], p.mv[2]} - cx12 * p.fd[0] - cy12 * p.fd[1] - cz12 * p.fd[2];
 	}
-	MPM_DEV void add(int o, float mass, v2f_& a01, v2f_& a23) {// o: compile-time after unrolling
+	// the part of a step that does not need the node's accumulator: weight and the two channel pairs {mass, x}, {y, z} of this particle at stencil offset o
+	MPM_DEV void prep(int o, float mass, float& W, v2f_& m0, v2f_& t12) {// o: compile-time after unrolling
 		const int i = o / 9, j = (o / 3) % 3, k = o % 3;
 		if(k == 0) {
 			if(j == 0) {
@@ -160,12 +161,17 @@ struct ChainHalf {
 			}
 			wij = pw[0][i] * pw[1][j];
 		}
-		const float W  = wij * pw[2][k];
+		W = wij * pw[2][k];
 		// (k = 2: fma with the constant 2 - the doubled z row of ScatterChain would cost three registers per particle)
-		const v2f_ m0  = {mass, k == 0 ? pen0 : (k == 1 ? pen0 + cz0 : fmaf(2.f, cz0, pen0))};
-		const v2f_ t12 = k == 0 ? pen12 : (k == 1 ? pen12 + cz12 : cz12 * 2.f + pen12);
-		a01			   = m0 * W + a01;
-		a23			   = t12 * W + a23;
+		m0	= (v2f_) {mass, k == 0 ? pen0 : (k == 1 ? pen0 + cz0 : fmaf(2.f, cz0, pen0))};
+		t12 = k == 0 ? pen12 : (k == 1 ? pen12 + cz12 : cz12 * 2.f + pen12);
+	}
+	MPM_DEV void add(int o, float mass, v2f_& a01, v2f_& a23) {
+		float W;
+		v2f_ m0, t12;
+		prep(o, mass, W, m0, t12);
+		a01 = m0 * W + a01;
+		a23 = t12 * W + a23;
 	}
 };
 
@@ -220,12 +226,65 @@ struct ScatterChainDual {
 };
 
 // The scatter chain for a PAIR: per node the two contributions are summed in registers, one read-modify-write (cf. ScatterChain).
+#if !defined(MPM_EXPERIMENT) || !defined(MPM_CHAIN_ASM)
+#define MPM_CHAIN_ASM 1
+#endif
 template<int NSITES>
 struct ScatterChain2 {
 	float4* node0;
 	float mass;
 	int win;
 	ChainHalf h[2];
+#if MPM_CHAIN_ASM
+	// A step is an LDS round trip: the read of node o can only be issued behind the write of node o - 1 (another lane may have written that very node), and what
+	// the wave can do meanwhile is the part of step o that does not need the accumulator - both particles' weights and channel values (prep).  The compiler put only
+	// A's half in front of its wait (B's went behind A's multiply-adds); the read is issued and awaited by hand here (lds_issue_b128 / s_waitcnt with the prepared
+	// values as inputs, so that they are formed first), as in gather_apic.
+	unsigned lds0;
+	v4f_ acc;
+	MPM_DEV ScatterChain2(float4* n0, const P2GPayload& pa, const P2GPayload& pb, float m, bool w, bool with_b)
+		: node0(n0)
+		, mass(m)
+		, win(w)
+		, lds0((unsigned) (size_t) n0) {
+		h[0].init(pa, true);
+		h[1].init(pb, with_b);
+		if(win) acc = lds_issue_b128<0>(lds0);
+	}
+	template<int O>
+	MPM_DEV void step() {
+		float wa, wb;
+		v2f_ m0a, t12a, m0b, t12b;
+		h[0].prep(O, mass, wa, m0a, t12a);
+		h[1].prep(O, mass, wb, m0b, t12b);
+		__asm__ volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc) : "v"(wa), "v"(m0a), "v"(t12a), "v"(wb), "v"(m0b), "v"(t12b));
+		v2f_ a01 = {acc.x, acc.y};
+		v2f_ a23 = {acc.z, acc.w};
+		a01 = m0a * wa + a01;
+		a23 = t12a * wa + a23;
+		a01 = m0b * wb + a01;
+		a23 = t12b * wb + a23;
+		constexpr int i = O / 9, j = (O / 3) % 3, k = O % 3;
+		node0[i * kP2GStrideX + j * kP2GStrideY + k] = make_float4(a01.x, a01.y, a23.x, a23.y);
+		__asm__ volatile("" ::: "memory");
+		if constexpr(O + 1 < 27) {
+			constexpr int i1 = (O + 1) / 9, j1 = ((O + 1) / 3) % 3, k1 = (O + 1) % 3;
+			acc = lds_issue_b128<(i1 * kP2GStrideX + j1 * kP2GStrideY + k1) * 16>(lds0);
+		}
+	}
+	template<int O, int END>
+	MPM_DEV void steps() {
+		if constexpr(O < END) {
+			step<O>();
+			steps<O + 1, END>();
+		}
+	}
+	template<int SITE>
+	MPM_DEV void at() {
+		static_assert(SITE >= 0 && SITE < NSITES, "site out of range");
+		if(win) steps<SITE * 27 / NSITES, (SITE + 1) * 27 / NSITES>();
+	}
+#else
 	float4 acc;
 	MPM_DEV ScatterChain2(float4* n0, const P2GPayload& pa, const P2GPayload& pb, float m, bool w, bool with_b)
 		: node0(n0)
@@ -256,6 +315,7 @@ struct ScatterChain2 {
 			for(int o = SITE * 27 / NSITES; o < (SITE + 1) * 27 / NSITES; ++o) step(o);
 		}
 	}
+#endif
 };
 
 template<int MAT>
@@ -350,10 +410,10 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 		float row[ROW ? ROW : 1];
 		int key;
 	};
-	auto fetch = [&](int rec, Prefetch& f) {
-		const int tag	  = (rec >> tag_shift) & 31;
+	// the source bin of a record: the bin offset of its source block sits in lane `tag` of the block's info row (one ds_bpermute, an LDS round trip)
+	auto source_bin = [&](int rec) { return __shfl(info, (rec >> tag_shift) & 31) + ((rec & (cfg.ppb - 1)) >> 6); };
+	auto fetch_from = [&](int rec, int sbin, Prefetch& f) {
 		const int sp	  = rec & (cfg.ppb - 1);
-		const int sbin	  = __shfl(info, tag) + (sp >> 6);
 		const float* bin  = mv.bins_src + (size_t) sbin * (kBin * NCH);
 		const float4* src = reinterpret_cast<const float4*>(bin + (sp & 63) * REC);
 		f.key			  = ((rec >> key_shift) & 255) | ((rec >> kArenaBit) & 1) << 8;// sort key | the slot's scatter arena (pair layout, mpm_kernels.hpp)
@@ -366,9 +426,20 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 			f.row[1]	   = t.y;
 		}
 	};
+	auto fetch = [&](int rec, Prefetch& f) { fetch_from(rec, source_bin(rec), f); };
+	// both members of a slot: the two look-ups are in flight together (issued one after the other they were two exposed round trips at the top of every iteration)
+	auto fetch2 = [&](const int (&rec)[2], Prefetch (&f)[2]) {
+		int sb[2] = {source_bin(rec[0]), source_bin(rec[1])};
+		__asm__ volatile("" : "+v"(sb[0]), "+v"(sb[1]));
+		fetch_from(rec[0], sb[0], f[0]);
+		fetch_from(rec[1], sb[1], f[1]);
+	};
 	Prefetch pf[2];
-	fetch(rec_cur[0], pf[0]);
-	fetch(rec_cur[1], pf[1]);
+	fetch2(rec_cur, pf);
+	// (kLateFetch == 0) the source bins of the NEXT slice's records are looked up one phase ahead - in front of the scatter chain, whose 27 round trips cover this one -
+	// and carried into the next iteration, whose record loads then start at once
+	int sb_next[2] = {0, 0};
+	if constexpr(kLateFetch == 0) sb_next[0] = source_bin(rec_next[0]), sb_next[1] = source_bin(rec_next[1]);
 #pragma unroll
 	for(int lb = 0; lb < 8; ++lb) {
 		const int cx = lane >> 4, cy = (lane >> 2) & 3, cz = lane & 3;
@@ -414,8 +485,11 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 		if(((t_cur + 2) & 63) == 0) form_slices(t_cur + 2);// (a block with more than 64 slices: the next batch of descriptors)
 		read_slice(t_cur + 2, s_nn);
 		load_recs(s_nn, rec_nn);
-		if constexpr(kLateFetch != 1) fetch(rec_next[0], pf[0]);
-		if constexpr(kLateFetch == 0) fetch(rec_next[1], pf[1]);
+		if constexpr(kLateFetch == 0) {
+			fetch_from(rec_next[0], sb_next[0], pf[0]);
+			fetch_from(rec_next[1], sb_next[1], pf[1]);
+		}
+		if constexpr(kLateFetch == 2) fetch(rec_next[0], pf[0]);
 		MPM_MARK("P_gather");
 		// ---- stencil bases + weights (:774-797), gather (:801-835)
 		int base[2][3], arena[2][3];
@@ -578,8 +652,8 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 		// 22 destination registers (sand) are live through the gather and the material update, the allocator runs out, parks the loads in registers it
 		// needs again and waits for them - s_waitcnt vmcnt(0) in the re-bucketing, i.e. the whole HBM latency exposed in every iteration.  From here the
 		// loads have the scatter chain (27 LDS round trips) and the other two waves of the SIMD to arrive in.
-		if constexpr(kLateFetch == 1) fetch(rec_next[0], pf[0]);
-		if constexpr(kLateFetch != 0) fetch(rec_next[1], pf[1]);
+		if constexpr(kLateFetch == 1) fetch2(rec_next, pf);
+		if constexpr(kLateFetch == 2) fetch(rec_next[1], pf[1]);
 		MPM_MARK("P_scatter");
 		// ---- the pair scatters now (:887-905): payload ((:850) contrib = (A m - stress new_dt) D^-1, times dx: cell units), claim, 27 steps back to back
 		P2GPayload pv[2];
@@ -600,7 +674,9 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 				pv_in[h]   = pv_code[h] >= 0;
 			}
 		}
-		// ---- claims: A for the slot's arena; a B with another base than its A (or without a chain-able A) for the OTHER arena, on its own
+		// ---- claims: A for the slot's arena; a B with another base than its A (or without a chain-able A) for the OTHER arena, on its own.
+		//      (Also measured: claims written and read back in FRONT of the material update, which would cover the round trip: +0.5-1 % for sand, +2.5 % for the J-fluid -
+		//       one more register across the update; profiles/r06_ab_pairs_phase2.txt.)
 		const bool a_ok	   = pv_in[0] && !code_edge(pv_code[0]);
 		const bool b_same  = pv_in[1] && pv_in[0] && pv_code[1] == pv_code[0];
 #if MPM_PAIR_DUAL
@@ -661,6 +737,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 			}
 		}
 		MPM_MARK("P_chain");
+		if constexpr(kLateFetch == 0) sb_next[0] = source_bin(rec_nn[0]), sb_next[1] = source_bin(rec_nn[1]);// (rec_nn was requested at the top of this iteration)
 		float4* const node0 = p2g + (win ? code_off(pv_code[0]) + arena_sel * kP2GArena2 : 0);
 		if(__any(dual)) {
 			float4* const node1 = p2g + (dual ? code_off(pv_code[1]) + (arena_sel ^ 1) * kP2GArena2 : 0);
