@@ -104,18 +104,26 @@ __device__ __forceinline__ int wave_append(int* counter, bool pred) {
 }
 
 
+// Inclusive prefix sum over the 64 lanes of a wave on the DPP cross-lane paths - four shifts inside the rows of 16 lanes, then lane 15 of rows 0 / 2 into rows
+// 1 / 3 and lane 31 into the upper half (row_bcast15 / row_bcast31: gfx9 only) - six vector instructions; the shuffle version is six ds_bpermute, i.e. six
+// dependent LDS round trips (in prepare_blocks_kernel's counting sort: a third of a chunk's exposed latency).  Every lane of the wave must be active.
+__device__ __forceinline__ int wave_scan_incl(int v) {
+	v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);// row_shr:1
+	v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);// row_shr:2
+	v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);// row_shr:4
+	v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);// row_shr:8
+	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);// row_bcast15 into rows 1 and 3
+	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);// row_bcast31 into rows 2 and 3
+	return v;
+}
+
 // The same for a whole workgroup (every thread must call it; blockDim.x a multiple of 64, at most 1024): `amount` items per
 // thread, ONE global atomic per workgroup.  Returns the thread's first slot (meaningless for amount == 0).
 __device__ __forceinline__ int block_append(int* counter, int amount) {
 	__shared__ int s_wave[16];
 	__shared__ int s_base;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
-	int incl = amount;// inclusive scan over the wave
-#pragma unroll
-	for(int off = 1; off < 64; off <<= 1) {
-		const int v = __shfl_up(incl, off);
-		if(lane >= off) incl += v;
-	}
+	const int incl = wave_scan_incl(amount);// inclusive scan over the wave
 	__syncthreads();// (s_wave / s_base may still be read by a previous call)
 	if(lane == 63) s_wave[wave] = incl;
 	__syncthreads();
@@ -456,12 +464,7 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 			__syncthreads();
 			{// exclusive prefix sum of the counts over the keys: lane owns keys 4 lane .. 4 lane + 3
 				const int c0 = s_cnt[4 * lane], c1 = s_cnt[4 * lane + 1], c2 = s_cnt[4 * lane + 2], c3 = s_cnt[4 * lane + 3];
-				int incl = c0 + c1 + c2 + c3;
-#pragma unroll
-				for(int off = 1; off < 64; off <<= 1) {
-					const int v = __shfl_up(incl, off);
-					if(lane >= off) incl += v;
-				}
+				const int incl = wave_scan_incl(c0 + c1 + c2 + c3);
 				const int excl = incl - (c0 + c1 + c2 + c3);
 				__syncthreads();
 				s_cnt[4 * lane]		= excl;
@@ -472,19 +475,27 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 			__syncthreads();
 			// wrap-around rule: the p-th record in key-major order goes to slice p mod S, position p / S
 			const int S = (nrec + 63) >> 6;
+			int first[NIT];// (all look-ups in flight together: read one by one at their use they were NIT exposed LDS round trips; the same for the write-back below)
+#pragma unroll
+			for(int it = 0; it < NIT; ++it) first[it] = s_cnt[(recs[it] >> key_shift) & 255];
+			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 			for(int it = 0; it < NIT; ++it) {
 				if(it * 64 + lane < nrec) {
 					const unsigned rec = recs[it] & rec_mask;
-					const int p		   = s_cnt[(rec >> key_shift) & 255] + rank[it];
+					const int p		   = first[it] + rank[it];
 					const int pos	   = div_small(p, S);
 					s_sorted[(p - pos * S) * 64 + pos] = (int) rec;
 				}
 			}
 			__syncthreads();
+			int out[NIT];
+#pragma unroll
+			for(int it = 0; it < NIT; ++it) out[it] = s_sorted[it * 64 + lane];
+			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 			for(int it = 0; it < NIT; ++it)
-				if(it < S && lane < slice_records(nrec, it)) list[chunk0 + it * 64 + lane] = s_sorted[it * 64 + lane];
+				if(it < S && lane < slice_records(nrec, it)) list[chunk0 + it * 64 + lane] = out[it];
 			__syncthreads();
 		};
 		// The pair layout (top of this file): records of one key are dealt out two by two, the odd one of a key goes to the single slices.
@@ -507,13 +518,8 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 					c[i] = s_cnt[4 * lane + i];
 					v[i] = (c[i] >> 1) | ((c[i] & 1) << 16);
 				}
-				int incl = v[0] + v[1] + v[2] + v[3];
-#pragma unroll
-				for(int off = 1; off < 64; off <<= 1) {
-					const int u = __shfl_up(incl, off);
-					if(lane >= off) incl += u;
-				}
-				const int tot = __shfl(incl, 63);
+				const int incl = wave_scan_incl(v[0] + v[1] + v[2] + v[3]);
+				const int tot  = __builtin_amdgcn_readlane(incl, 63);
 				pf			  = tot & 0xffff;
 				int excl	  = incl - (v[0] + v[1] + v[2] + v[3]);
 #pragma unroll
@@ -525,11 +531,15 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 			__syncthreads();
 			const PairChunk pc = pair_chunk(nrec, pf);
 			const int n1s	   = pc.L - pc.px;// singles with a slot of their own (the last n1 - n1s singles share the mismatched slots two by two)
+			int ent[NIT];// (all look-ups in flight together: read one by one at their use they were NIT exposed LDS round trips; the same for the write-back below)
+#pragma unroll
+			for(int it = 0; it < NIT; ++it) ent[it] = s_cnt[(recs[it] >> key_shift) & 255];
+			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 			for(int it = 0; it < NIT; ++it) {
 				if(it * 64 + lane < nrec) {
 					unsigned rec = recs[it] & rec_mask;
-					const int e	 = s_cnt[(rec >> key_shift) & 255];
+					const int e	 = ent[it];
 					const int nk = e >> 18, pp = e & 0x3ff;// records of the key, full pairs before it
 					const int r	 = rank[it];
 					int p, member;
@@ -562,9 +572,13 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 				}
 			}
 			__syncthreads();
+			int out[NIT];
+#pragma unroll
+			for(int it = 0; it < NIT; ++it) out[it] = s_sorted[it * 64 + lane];
+			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 			for(int it = 0; it < NIT; ++it)
-				if(it * 64 + lane < nrec) list[chunk0 + it * 64 + lane] = s_sorted[it * 64 + lane];
+				if(it * 64 + lane < nrec) list[chunk0 + it * 64 + lane] = out[it];
 			if(lane == 0) pairinfo[chunk0 / kPrepChunk] = pf;
 			__syncthreads();
 		};
