@@ -411,6 +411,17 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 	const int pbc = min(*pbc_ptr, cfg.cap);
 	for(int b = blockIdx.x; b < pbc; b += gridDim.x) {
 	const int kx = cur_keys[3 * b], ky = cur_keys[3 * b + 1], kz = cur_keys[3 * b + 2];
+	// (a settled block's work is two chains of dependent loads - key -> table -> bin offset, and size / row -> keep -> handed-on pair counts -; the first model's
+	//  second chain is started HERE, beside the first one, instead of behind it: the kernel is latency-bound at rest)
+	int size0 = 0, row0 = 0, keep0 = -2, hand0 = 0;
+	if constexpr(SORT) {
+		if(pm.n > 0) {
+			size0 = pm.size[0][b];
+			row0  = pm.row_of[0][b];
+			if(pm.keep[0]) keep0 = pm.keep[0][row0];
+			if(pm.pairinfo[0]) hand0 = pm.pairhand[0][(size_t) row0 * kPairChunks + (lane & (kPairChunks - 1))];
+		}
+	}
 	// ---- look-ups (model independent except for the bin offsets)
 	int srcno = -1, other = -1;
 	if(lane < 27) {
@@ -431,8 +442,8 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 	for(int m = 0; m < pm.n; ++m) {
 		int info = other;
 		if constexpr(SORT) {
-		const int size = pm.size[m][b];
-		const int row  = pm.row_of[m][b];
+		const int size = m == 0 ? size0 : pm.size[m][b];
+		const int row  = m == 0 ? row0 : pm.row_of[m][b];
 		int* list	   = pm.list[m] + (size_t) row * cfg.ppb;
 		// The sort is the identity - and is skipped: 8 B of list traffic per particle and the LDS work - when G2P2G has found that every
 		// particle of the block stayed with an unchanged sort key (keep[row] = their number), nobody arrived (the block's new size is that
@@ -440,7 +451,8 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 		// chunk of full slices or of a single one.  A column at rest is all such blocks but its surface.
 		const int tail	= size & (kPrepChunk - 1);
 		int* pairinfo	= pm.pairinfo[m] ? pm.pairinfo[m] + (size_t) b * kPairChunks : nullptr;// (pair layout: settled blocks keep their order whatever their shape)
-		const bool same = pm.keep[m] && size > 0 && pm.keep[m][row] == size && (pairinfo || tail <= 64 || (tail & 63) == 0);
+		const int kept	= m == 0 ? keep0 : (pm.keep[m] ? pm.keep[m][row] : -2);
+		const bool same = pm.keep[m] && size > 0 && kept == size && (pairinfo || tail <= 64 || (tail & 63) == 0);
 		constexpr int NIT = kPrepChunk / 64;
 		unsigned recs[NIT];
 		auto load_chunk = [&](int chunk0, int nrec) {// unconditional, clamped: all loads of a chunk are in flight together
@@ -582,7 +594,7 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 			if(lane == 0) pairinfo[chunk0 / kPrepChunk] = pf;
 			__syncthreads();
 		};
-		if(pairinfo && same && lane < kPairChunks) pairinfo[lane] = pm.pairhand[m][(size_t) row * kPairChunks + lane];
+		if(pairinfo && same && lane < kPairChunks) pairinfo[lane] = m == 0 ? hand0 : pm.pairhand[m][(size_t) row * kPairChunks + lane];
 		for(int chunk0 = 0; chunk0 < size && !same; chunk0 += kPrepChunk) {
 			if(chunk0) load_chunk(chunk0, min(kPrepChunk, size - chunk0));
 			if(pairinfo)
