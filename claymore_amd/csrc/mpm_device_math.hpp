@@ -458,7 +458,11 @@ MPM_DEV void stress_nacc(const MaterialConst& mc, const StressScale& ss, float (
 			Bn[2]				  = sh2 * B_s_coeff + trB3;
 			rebuild				  = true;
 			if(mc.hardening_on && p0 > 1e-4f && p_trial < p0 - 1e-4f && p_trial > 1e-4f + p_min) {
-				const float p_center = (1.0f - mc.beta) * p0 * 0.5f;
+				// (1 - beta is formed HERE, in the branch: hoisted out of G2P2G's particle loop as a loop invariant it holds a vector register across the loop - gfx950 has no
+				//  scalar float ALU - which the pair kernel's NACC instantiation does not have: it was spilled and reloaded inside the loop)
+				float beta_here = mc.beta;
+				__asm__ volatile("" : "+s"(beta_here));
+				const float p_center = (1.0f - beta_here) * p0 * 0.5f;
 				const float q_trial	 = __builtin_amdgcn_sqrtf(1.5f * s_sqrnorm);
 				float d0 = p_center - p_trial, d1 = -q_trial;
 				const float dn = rsqrt_approx(d0 * d0 + d1 * d1);

@@ -350,18 +350,27 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 	const int key_shift = cfg.pid_bits;
 	const int tag_shift = cfg.pid_bits + kKeyBits;
 	const int info		= mv.blockinfo[(size_t) b * kInfoRow + lane];
-	const int pinfo		= mv.pairinfo_in[(size_t) b * kPairChunks + (lane & (kPairChunks - 1))];// full pairs of chunk (lane & 15); by block number: the same round trip as the scalars above
+	int chunk_nrec;// records of chunk (lane & 15) of the block; 0 beyond its last chunk (the last chunk absorbs a short tail: pair_chunks, mpm_kernels.hpp)
+	{
+		const int nch = pair_chunks(size), cl = lane & (kPairChunks - 1);
+		chunk_nrec	  = cl < nch ? (cl + 1 < nch ? 512 : size - 512 * cl) : 0;
+	}
+	// full pairs of chunk (lane & 15) | its records << 16 (by block number: the same round trip as the scalars above; the records are formed per lane here, once per
+	// block: formed from `size` where they are used they cost scalar registers across the particle loop - spills into vector lanes, +113 v_readlane inside it)
+	const int pinfo		= (mv.pairinfo_in[(size_t) b * kPairChunks + (lane & (kPairChunks - 1))] & 0xffff) | (chunk_nrec << 16);// (the entries beyond the last chunk were never written)
 	// ---- the slices of the block in the pair layout (mpm_kernels.hpp).  Lane t forms the descriptor of slice t (of slice 64 k + t in the k-th batch of
 	//      a block with more than 64 slices) once per block: position of A's first record in the block's list, lanes in use (0: beyond the end), pair
 	//      slice or single slice.  The loop reads the descriptor two slices ahead with v_readlane: no scalar cursor to carry (a scalar one took ~100
 	//      scalar instructions per iteration and ~25 live scalar registers, i.e. spills into vector registers).
-	const int nchunks = (size + kListChunk - 1) / kListChunk;
 	int d_slice = 0;// position | lanes with an A << 16 | lanes with a B << 24 (one register: the loop is short of them)
 	auto form_slices = [&](int first) {// descriptors of slices first .. first + 63
 		int before = 0;// slices of the chunks before c (wave-uniform)
 		d_slice = 0;
-		for(int c = 0; c < nchunks; ++c) {
-			const PairChunk pc = pair_chunk(chunk_records(size, c), __builtin_amdgcn_readlane(pinfo, c));
+#pragma unroll 1
+		for(int c = 0; c < kPairChunks; ++c) {
+			const int pe = __builtin_amdgcn_readlane(pinfo, c);
+			if((pe >> 16) == 0) break;// (beyond the block's last chunk)
+			const PairChunk pc = pair_chunk(pe >> 16, pe & 0xffff);
 			const int t		   = first + lane - before;
 			if(t >= 0 && t < pc.S) {
 				int pos, ca, cb;
@@ -768,7 +777,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 	}
 	if(lane == 0) mv.keep[b] = settled ? size : -1;
 	// if nobody leaves or arrives, row b of list_out holds the records in THIS layout: hand the pair counts on under the block's number
-	if(lane < kPairChunks) mv.pairinfo_out[(size_t) b * kPairChunks + lane] = pinfo;
+	if(lane < kPairChunks) mv.pairinfo_out[(size_t) b * kPairChunks + lane] = pinfo & 0xffff;
 	__syncthreads();
 	// ---- arena -> next grid (:907-936), as in g2p2g_kernel
 	int lane_wb = lane;

@@ -164,12 +164,27 @@ constexpr int kListChunk = 512;
 // slice sit in neighbouring lanes), and for a single the arena its key's pair slot of the same slice does NOT use - a key's single never competes
 // with its own pairs.  The one number a reader needs beside the block's size is Pf per chunk: pairinfo[block][chunk], kPairChunks ints per block,
 // indexed by the block's number like the look-up row (G2P2G fetches both in its first round trip).
+// Chunks of the pair layout: records [512 c, 512 c + 512) like the sliced layout's - but the LAST chunk of a block absorbs a tail of up to kPairTailMerge records
+// (a block of 513 .. 768 particles is ONE chunk of 5 or 6 slices).  Mismatched slots arise in FULL chunks only (512 records are 256 slots: every single displaces
+// another one), and a column that stood at 512 particles per block is compressed by a few per cent when it flows: 68 % of the blocks of the C3 flow hold more than 512
+// particles, most of them 513 - 640, and the few records of their second chunk sat in a slice of their own while the first chunk sent 3.1 % of all particles down the
+// serial path as second members of mismatched slots.  With the tail in the same chunk its slice takes the singles: 0.4 % (tools/flow_mismatch.py), the same number of slices.
+constexpr int kPairTailMerge = 256;
+constexpr int kPairChunkMax	 = 512 + kPairTailMerge;// records of the largest chunk: 6 slices
+constexpr int kPairLayoutId	 = 2;					  // (checkpoints: 1 was the layout with plain 512-record chunks)
+__host__ __device__ __forceinline__ int pair_chunks(int size) {// chunks of a block with `size` records
+	const int nfull = size >> 9, tail = size & 511;
+	return nfull + ((tail > 0 && !(nfull >= 1 && tail <= kPairTailMerge)) ? 1 : 0);
+}
+__host__ __device__ __forceinline__ int pair_chunk_records(int size, int c) {// records of chunk c (which starts at record 512 c)
+	return c + 1 < pair_chunks(size) ? 512 : size - 512 * c;
+}
 constexpr int kPairChunks = 16;// chunks per list row the pair layout supports (ppb <= 8192 = the reference's 128 particles per cell)
 constexpr int kArenaBit	  = 30;// (records are {tag 5, key 8, slot <= 13} = 26 bits)
 struct PairChunk {// the slices of one chunk in the pair layout (all wave-uniform)
 	int n, pf, S, px, L, qb, rb, qa, ra;// px = slots with a B (Pf + X), L = slots; q / r: quotient and remainder of px and L by S
 };
-__device__ __forceinline__ int div_small(int n, int d) {// n / d for 0 <= n <= 512, 1 <= d <= 8 (exact, checked exhaustively)
+__device__ __forceinline__ int div_small(int n, int d) {// n / d for 0 <= n <= 1024, 1 <= d <= 8 (exact, checked exhaustively: tests/test_pair_layout_model.py)
 	// ceil(65536 / d) for d = 2..8 as 16-bit fields of two constants: a division by a run-time d, even a wave-uniform one, is ~40 scalar
 	// instructions of reciprocal refinement, and G2P2G forms a slice length in every iteration
 	const unsigned long long lo = 0x3334400055568000ull, hi = 0x200024932aabull;
@@ -398,8 +413,9 @@ template<bool SORT>
 __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, PrepareModels pm, const int* __restrict__ pbc_ptr, const int* __restrict__ cur_table, const int* __restrict__ cur_keys, const int* __restrict__ prev_table, int* __restrict__ publish, int* __restrict__ part_count) {
 	// records are sorted in chunks of 512 (8 per lane): every 64-slot slice of a chunk is one G2P2G iteration
 	constexpr int kPrepChunk = kListChunk;
-	__shared__ int s_sorted[kPrepChunk];
+	__shared__ int s_sorted[kPairChunkMax];// (the pair layout's last chunk of a block may hold kPairChunkMax records)
 	__shared__ int s_cnt[256];// per key (216 used): count, then first position of the key in key-major order
+	__shared__ int s_cur[256];// (pair layout, merged last chunk: the running rank of a key's records in the second pass)
 	const int lane = threadIdx.x;
 	// (MPM_GROUP_OVERLAP_TAG=1 runs the tagging kernels - halo_mark_all / halo_split_dev - on the comm stream BESIDE this kernel: they read
 	//  ST_NBC / ST_PBC only and must never read what is published here, ST_EBC and *part_count)
@@ -442,8 +458,9 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 	for(int m = 0; m < pm.n; ++m) {
 		int info = other;
 		if constexpr(SORT) {
-		const int size = m == 0 ? size0 : pm.size[m][b];
-		const int row  = m == 0 ? row0 : pm.row_of[m][b];
+		// (wave-uniform, and said so: the list's address is then a scalar base plus a 32-bit lane offset - one register per load in flight instead of two)
+		const int size = __builtin_amdgcn_readfirstlane(m == 0 ? size0 : pm.size[m][b]);
+		const int row  = __builtin_amdgcn_readfirstlane(m == 0 ? row0 : pm.row_of[m][b]);
 		int* list	   = pm.list[m] + (size_t) row * cfg.ppb;
 		// The sort is the identity - and is skipped: 8 B of list traffic per particle and the LDS work - when G2P2G has found that every
 		// particle of the block stayed with an unchanged sort key (keep[row] = their number), nobody arrived (the block's new size is that
@@ -453,13 +470,13 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 		int* pairinfo	= pm.pairinfo[m] ? pm.pairinfo[m] + (size_t) b * kPairChunks : nullptr;// (pair layout: settled blocks keep their order whatever their shape)
 		const int kept	= m == 0 ? keep0 : (pm.keep[m] ? pm.keep[m][row] : -2);
 		const bool same = pm.keep[m] && size > 0 && kept == size && (pairinfo || tail <= 64 || (tail & 63) == 0);
-		constexpr int NIT = kPrepChunk / 64;
+		constexpr int NIT = kPrepChunk / 64;// (records per lane of a 512-record group; a merged last chunk of the pair layout is worked off in two groups)
 		unsigned recs[NIT];
 		auto load_chunk = [&](int chunk0, int nrec) {// unconditional, clamped: all loads of a chunk are in flight together
 #pragma unroll
 			for(int it = 0; it < NIT; ++it) recs[it] = (unsigned) list[chunk0 + min(it * 64 + lane, nrec - 1)];
 		};
-		if(size > 0 && !same) load_chunk(0, min(kPrepChunk, size));
+		if(size > 0 && !same) load_chunk(0, min(kPrepChunk, size));// (the first 512 records of the first chunk)
 		// the bin offsets of the 27 source blocks: the look-up issued at the top has arrived by now, this dependent load
 		// overlaps the LDS-only sort below
 		if(lane < 27) info = srcno >= 0 ? pm.binoff_src[m][srcno] : -1;
@@ -511,15 +528,27 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 			__syncthreads();
 		};
 		// The pair layout (top of this file): records of one key are dealt out two by two, the odd one of a key goes to the single slices.
+		// The pair layout (top of this file): records of one key are dealt out two by two, the odd one of a key goes to the single slices.  nrec <= 512: one group of
+		// records, held in registers from the counting pass to the placement.  A merged last chunk (512 < nrec <= kPairChunkMax) is worked off in two groups with the
+		// register budget of one: the counting pass only counts, the placement pass reads a group again and draws its ranks from a second set of cursors (s_cur).
 		auto sort_chunk_pairs = [&](int chunk0, int nrec) {
+			const bool big = nrec > kPrepChunk;// (wave-uniform)
+			const int n0 = min(nrec, kPrepChunk), n1g = nrec - n0;// records of group 0 (in recs[]) and of group 1
 #pragma unroll
-			for(int q = 0; q < 4; ++q) s_cnt[lane + 64 * q] = 0;
+			for(int q = 0; q < 4; ++q) s_cnt[lane + 64 * q] = 0, s_cur[lane + 64 * q] = 0;
 			__syncthreads();
 			int rank[NIT];
 #pragma unroll
 			for(int it = 0; it < NIT; ++it) {
 				rank[it] = 0;
-				if(it * 64 + lane < nrec) rank[it] = atomicAdd(&s_cnt[(recs[it] >> key_shift) & 255], 1);
+				if(it * 64 + lane < n0) rank[it] = atomicAdd(&s_cnt[(recs[it] >> key_shift) & 255], 1);
+			}
+			if(big) {// group 1 (at most kPairTailMerge records) is counted too; its records replace the first ones of group 0 in the registers
+#pragma unroll
+				for(int it = 0; it < kPairTailMerge / 64; ++it) recs[it] = (unsigned) list[chunk0 + kPrepChunk + min(it * 64 + lane, n1g - 1)];// (only the tail's records: a full load_chunk here costs 14 registers)
+#pragma unroll
+				for(int it = 0; it < kPairTailMerge / 64; ++it)
+					if(it * 64 + lane < n1g) atomicAdd(&s_cnt[(recs[it] >> key_shift) & 255], 1);
 			}
 			__syncthreads();
 			int pf;
@@ -536,71 +565,96 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 				int excl	  = incl - (v[0] + v[1] + v[2] + v[3]);
 #pragma unroll
 				for(int i = 0; i < 4; ++i) {
-					s_cnt[4 * lane + i] = (excl & 0x3ff) | ((excl >> 16) << 10) | (c[i] << 18);// full pairs before the key (<= 256) | singles before it (<= 216) | records of the key (<= 512)
+					s_cnt[4 * lane + i] = (excl & 0x3ff) | ((excl >> 16) << 10) | (c[i] << 18);// full pairs before the key (<= 384) | singles before it (<= 216) | records of the key (<= 768)
 					excl += v[i];
 				}
 			}
 			__syncthreads();
 			const PairChunk pc = pair_chunk(nrec, pf);
 			const int n1s	   = pc.L - pc.px;// singles with a slot of their own (the last n1 - n1s singles share the mismatched slots two by two)
-			int ent[NIT];// (all look-ups in flight together: read one by one at their use they were NIT exposed LDS round trips; the same for the write-back below)
-#pragma unroll
-			for(int it = 0; it < NIT; ++it) ent[it] = s_cnt[(recs[it] >> key_shift) & 255];
-			__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-			for(int it = 0; it < NIT; ++it) {
-				if(it * 64 + lane < nrec) {
-					unsigned rec = recs[it] & rec_mask;
-					const int e	 = ent[it];
-					const int nk = e >> 18, pp = e & 0x3ff;// records of the key, full pairs before it
-					const int r	 = rank[it];
-					int p, member;
-					const bool paired = r < (nk & ~1);
-					if(paired) {
-						p	   = pp + (r >> 1);
-						member = r & 1;
+			auto place = [&](unsigned rec_raw, int r, int e) {
+				unsigned rec = rec_raw & rec_mask;
+				const int nk = e >> 18, pp = e & 0x3ff;// records of the key, full pairs before it
+				int p, member;
+				const bool paired = r < (nk & ~1);
+				if(paired) {
+					p	   = pp + (r >> 1);
+					member = r & 1;
+				} else {
+					const int j = (e >> 10) & 0xff;// singles before this one
+					if(j < n1s) {
+						p	   = pc.px + j;
+						member = 0;
 					} else {
-						const int j = (e >> 10) & 0xff;// singles before this one
-						if(j < n1s) {
-							p	   = pc.px + j;
-							member = 0;
-						} else {
-							p	   = pc.pf + ((j - n1s) >> 1);
-							member = (j - n1s) & 1;
+						p	   = pc.pf + ((j - n1s) >> 1);
+						member = (j - n1s) & 1;
+					}
+				}
+				const int ln = div_small(p, pc.S), d = p - ln * pc.S;
+				int pos, ca, cb;
+				pair_slice(pc, d, pos, ca, cb);
+				// the slot's scatter arena: lane parity - but a single takes the arena its key's pair slot of this slice does not use
+				int arena = ln & 1;
+				if(!paired) {
+					int i0 = d - (pp - div_small(pp, pc.S) * pc.S);// the key's i0-th pair slot is the first one in slice d
+					i0 += i0 < 0 ? pc.S : 0;
+					if(i0 < (nk >> 1)) arena = 1 ^ (div_small(pp + i0, pc.S) & 1);
+				}
+				rec |= (unsigned) arena << kArenaBit;
+				s_sorted[pos + (member ? ca : 0) + ln] = (int) rec;
+			};
+			int ent[NIT];// (all look-ups in flight together: read one by one at their use they were NIT exposed LDS round trips; the same for the write-back below)
+			if(!big) {
+#pragma unroll
+				for(int it = 0; it < NIT; ++it) ent[it] = s_cnt[(recs[it] >> key_shift) & 255];
+				__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+				for(int it = 0; it < NIT; ++it)
+					if(it * 64 + lane < n0) place(recs[it], rank[it], ent[it]);
+			} else {
+				auto place_group = [&](int ng) {// the ng records in recs[]: ranks from the second set of cursors
+#pragma unroll
+					for(int it = 0; it < NIT; ++it) {
+						if(it * 64 + lane < ng) {
+							const int key = (recs[it] >> key_shift) & 255;
+							const int r	  = atomicAdd(&s_cur[key], 1);
+							place(recs[it], r, s_cnt[key]);
 						}
 					}
-					const int ln = div_small(p, pc.S), d = p - ln * pc.S;
-					int pos, ca, cb;
-					pair_slice(pc, d, pos, ca, cb);
-					// the slot's scatter arena: lane parity - but a single takes the arena its key's pair slot of this slice does not use
-					int arena = ln & 1;
-					if(!paired) {
-						int i0 = d - (pp - div_small(pp, pc.S) * pc.S);// the key's i0-th pair slot is the first one in slice d
-						i0 += i0 < 0 ? pc.S : 0;
-						if(i0 < (nk >> 1)) arena = 1 ^ (div_small(pp + i0, pc.S) & 1);
-					}
-					rec |= (unsigned) arena << kArenaBit;
-					s_sorted[pos + (member ? ca : 0) + ln] = (int) rec;
-				}
+				};
+				place_group(n1g);// (group 1's records are in the registers)
+				load_chunk(chunk0, n0);
+				place_group(n0);
 			}
 			__syncthreads();
-			int out[NIT];
+			{
+				int out[NIT];
 #pragma unroll
-			for(int it = 0; it < NIT; ++it) out[it] = s_sorted[it * 64 + lane];
-			__builtin_amdgcn_sched_barrier(0);
+				for(int it = 0; it < NIT; ++it) out[it] = s_sorted[it * 64 + lane];
+				__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-			for(int it = 0; it < NIT; ++it)
-				if(it * 64 + lane < nrec) list[chunk0 + it * 64 + lane] = out[it];
+				for(int it = 0; it < NIT; ++it)
+					if(it * 64 + lane < n0) list[chunk0 + it * 64 + lane] = out[it];
+			}
+			if(big) {// (the merged tail)
+#pragma unroll
+				for(int it = 0; it < kPairTailMerge / 64; ++it)
+					if(it * 64 + lane < n1g) list[chunk0 + kPrepChunk + it * 64 + lane] = s_sorted[kPrepChunk + it * 64 + lane];
+			}
 			if(lane == 0) pairinfo[chunk0 / kPrepChunk] = pf;
 			__syncthreads();
 		};
 		if(pairinfo && same && lane < kPairChunks) pairinfo[lane] = m == 0 ? hand0 : pm.pairhand[m][(size_t) row * kPairChunks + lane];
 		for(int chunk0 = 0; chunk0 < size && !same; chunk0 += kPrepChunk) {
-			if(chunk0) load_chunk(chunk0, min(kPrepChunk, size - chunk0));
+			const int left = size - chunk0;
+			// (pair layout: what is left fits the last chunk - 512 records and a tail of up to kPairTailMerge: pair_chunks)
+			const int nrec = (pairinfo && left > kPrepChunk && left <= kPairChunkMax) ? left : min(kPrepChunk, left);
+			if(chunk0) load_chunk(chunk0, min(kPrepChunk, nrec));
 			if(pairinfo)
-				sort_chunk_pairs(chunk0, min(kPrepChunk, size - chunk0));
+				sort_chunk_pairs(chunk0, nrec);
 			else
-				sort_chunk(chunk0, min(kPrepChunk, size - chunk0));
+				sort_chunk(chunk0, nrec);
+			if(nrec > kPrepChunk) break;
 		}
 		}
 		if constexpr(!SORT) {

@@ -8,8 +8,29 @@ import itertools
 import numpy as np
 
 
+KPAIR_TAIL_MERGE = 256      # mpm_kernels.hpp: the last chunk of a block absorbs a tail of up to this many records
+CHUNK_MAX = 512 + KPAIR_TAIL_MERGE
+
+
+def pair_chunks(size):
+    """The chunks of a block's list in the pair layout: (first record, records) - 512 each, the last one up to CHUNK_MAX (mpm_kernels.hpp: pair_chunks / pair_chunk_records)."""
+    nfull, tail = size >> 9, size & 511
+    n = nfull + (1 if (tail > 0 and not (nfull >= 1 and tail <= KPAIR_TAIL_MERGE)) else 0)
+    return [(512 * c, 512 if c + 1 < n else size - 512 * c) for c in range(n)]
+
+
+def test_chunks_tile_every_block_size():
+    for size in range(0, 8193):
+        ch = pair_chunks(size)
+        assert sum(n for _, n in ch) == size and all(0 < n <= CHUNK_MAX for _, n in ch) and all(n == 512 for _, n in ch[:-1])
+        assert [a for a, _ in ch] == [512 * c for c in range(len(ch))] and len(ch) <= 16
+        assert sum(-(-n // 128) for _, n in ch) == -(-size // 128)                 # merging the tail never costs a slice
+        if size > 512 and 0 < size % 512 <= KPAIR_TAIL_MERGE:
+            assert ch[-1][1] == 512 + size % 512
+
+
 def div_small(n, d):
-    """n // d for 0 <= n <= 512, 1 <= d <= 8 by a 16-bit reciprocal (the kernel's table: ceil(65536 / d) for d = 2..8)."""
+    """n // d for 0 <= n <= 1024, 1 <= d <= 8 by a 16-bit reciprocal (the kernel's table: ceil(65536 / d) for d = 2..8)."""
     inv = 65536 if d == 1 else -(-65536 // d)
     return (n * inv) >> 16
 
@@ -32,14 +53,14 @@ def pair_slice(c, t):
 
 def test_div_small_is_exact_on_its_domain():
     for d in range(1, 9):
-        for n in range(0, 513):
+        for n in range(0, 1025):
             assert div_small(n, d) == n // d, (n, d)
 
 
 def test_slices_tile_the_chunk_for_every_size_and_pair_count():
-    """For every chunk size n <= 512 and every feasible number of full pairs: the S = ceil(n / 128) slices are dense and in order, never wider than
+    """For every chunk size n <= CHUNK_MAX and every feasible number of full pairs: the S = ceil(n / 128) slices are dense and in order, never wider than
     64 lanes, their B lanes a prefix of their A lanes, and together they hold exactly n records; the mismatched slots are X = max(0, Pf + n1 - 64 S)."""
-    for n in range(1, 513):
+    for n in range(1, CHUNK_MAX + 1):
         for pf in range(0, n // 2 + 1):
             c = pair_chunk(n, pf)
             at = 0
@@ -68,9 +89,10 @@ def test_the_placement_rule_is_a_bijection_and_keeps_a_keys_pairs_apart():
     rng = np.random.default_rng(20)
     for trial in range(400):
         nkeys = int(rng.integers(1, 80))
-        counts = rng.poisson(rng.uniform(0.5, 12.0), nkeys) + (rng.random(nkeys) < 0.3)
+        counts = rng.poisson(rng.uniform(0.5, 12.0 if trial % 3 else 18.0), nkeys) + (rng.random(nkeys) < 0.3)
         counts = counts[counts > 0].astype(int)
-        while counts.sum() > 512:
+        limit = 512 if trial % 3 else CHUNK_MAX                      # (every third trial: a merged last chunk)
+        while counts.sum() > limit:
             counts[np.argmax(counts)] -= 1
         counts = counts[counts > 0]
         n = int(counts.sum())

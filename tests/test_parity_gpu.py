@@ -1224,7 +1224,7 @@ def _ckpt_lists(eng, ppb):
     nch = int(np.frombuffer(buf[64 + 4:64 + 8].tobytes(), np.int32)[0])
     bincount_src, bucketed, layout = int(m0[4]), int(m0[5]), int(np.frombuffer(buf[64 + 12:64 + 16].tobytes(), np.int32)[0])
     nmodels = int(hdr[4])
-    assert nmodels == 1 and layout == 1, "the model is not in the pair layout"
+    assert nmodels == 1 and layout == 2, "the model is not in the pair layout"
     o = [448]
 
     def take(nbytes, dtype):
@@ -1263,13 +1263,15 @@ def test_the_sort_writes_the_pair_layout_it_promises():
     blocks = _ckpt_lists(eng, ppb)
     eng.close()
     pid_bits = 13
-    seen = dict(chunks=0, pairs=0, mismatched=0, singles=0, multi_chunk=0, full_slices=0)
+    from test_pair_layout_model import pair_chunks
+    seen = dict(chunks=0, pairs=0, mismatched=0, singles=0, multi_chunk=0, full_slices=0, merged=0)
     for size, recs, pinfo in blocks:
-        nchunks = (size + 511) // 512
-        seen["multi_chunk"] += nchunks > 1
-        for c in range(nchunks):
-            n = min(512, size - 512 * c)
-            r = recs[512 * c:512 * c + n]
+        chunks = pair_chunks(size)                                   # 512-record chunks, the last one with a tail of up to 256 records more
+        seen["multi_chunk"] += len(chunks) > 1
+        seen["merged"] += bool(chunks) and chunks[-1][1] > 512
+        for c, (first, n) in enumerate(chunks):
+            assert first == 512 * c
+            r = recs[first:first + n]
             key, arena = (r >> pid_bits) & 255, (r >> 30) & 1
             pf = int(pinfo[c])
             n1 = n - 2 * pf
@@ -1313,7 +1315,7 @@ def test_the_sort_writes_the_pair_layout_it_promises():
             seen["mismatched"] += X
             seen["singles"] += n1
     print("pair layout seen:", seen)
-    assert seen["chunks"] > 30 and seen["pairs"] > 2000 and seen["singles"] > 100 and seen["mismatched"] > 0 and seen["multi_chunk"] > 0, seen
+    assert seen["chunks"] > 30 and seen["pairs"] > 2000 and seen["singles"] > 100 and seen["mismatched"] > 0 and seen["multi_chunk"] > 0 and seen["merged"] > 0, seen
 
 
 def test_mid_size_flow_parity_630k():
