@@ -767,7 +767,7 @@ __global__ __launch_bounds__(kG2P2GThreads, MAT == 0 ? MPM_PAIR_WAVES_FLUID : MP
 		atomicAdd(&status[24], st_iter);
 		atomicAdd(&status[25], st_losers);
 		atomicAdd(&status[26], st_edge);
-		atomicAdd(&status[27], st_split);// (the pair kernel reports its split pairs where the one-particle kernel reports its iterations with a retry)
+		atomicAdd(&status[27], MPM_PAIR_DUAL ? st_split : st_retry_iters);// iterations with a serial entry, as the one-particle kernel reports them (with MPM_PAIR_DUAL: the lanes whose B scattered from the other arena)
 		atomicAdd(&status[28], st_partial);
 		atomicAdd(&status[41], st_retry_iters);
 	}

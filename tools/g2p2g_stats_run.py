@@ -20,4 +20,4 @@ for upto in (10, 1000, 3000, 3100):
     d2 = eng.diagnostics(); c2 = np.array([d2.reserved[i] for i in range(4)] + [0], dtype=np.float64)
     one = (c2 - cur) % 2**32; prev = c2
     c = eng.counts(); t = eng.timers()
-    print(f"step {done}: blocks {c.particle_blocks} g2p2g {t.g2p2g_ms:.3f} ms | per substep: iterations {one[0]:.0f}, loser lanes {one[1]:.0f} ({100*one[1]/40108032:.2f} % of particles), edge lanes {one[2]:.0f} ({100*one[2]/40108032:.2f} %), iterations with retry {one[3]:.0f} ({100*one[3]/one[0]:.1f} %), idle lanes {one[4]:.0f}")
+    print(f"step {done}: blocks {c.particle_blocks} g2p2g {t.g2p2g_ms:.3f} ms | per substep: iterations {one[0]:.0f}, loser lanes {one[1]:.0f} ({100*one[1]/40108032:.2f} % of particles), edge lanes {one[2]:.0f} ({100*one[2]/40108032:.2f} %), iterations with a serial entry {one[3]:.0f} ({100*one[3]/one[0]:.1f} %)")
