@@ -527,7 +527,6 @@ __global__ __launch_bounds__(64) void prepare_blocks_kernel(GridCfg cfg, Prepare
 				if(it < S && lane < slice_records(nrec, it)) list[chunk0 + it * 64 + lane] = out[it];
 			__syncthreads();
 		};
-		// The pair layout (top of this file): records of one key are dealt out two by two, the odd one of a key goes to the single slices.
 		// The pair layout (top of this file): records of one key are dealt out two by two, the odd one of a key goes to the single slices.  nrec <= 512: one group of
 		// records, held in registers from the counting pass to the placement.  A merged last chunk (512 < nrec <= kPairChunkMax) is worked off in two groups with the
 		// register budget of one: the counting pass only counts, the placement pass reads a group again and draws its ranks from a second set of cursors (s_cur).

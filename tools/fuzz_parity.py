@@ -35,7 +35,7 @@ for case in range(cases):
         same = (ch.particle_blocks, ch.neighbor_blocks, ch.exterior_blocks) == (co.particle_blocks, co.neighbor_blocks, co.exterior_blocks)
         ok = w["pos_rel"] < 1e-5 and same
         worst = max(worst, w["pos_rel"])
-        msg = f"pos_rel {w['pos_rel']:.2e} F_rel {w['F_rel']:.2e} blocks {'equal' if same else 'DIFFER'}"
+        msg = f"pos_rel {w['pos_rel']:.2e} state_rel {w['state_rel']:.2e} blocks {'equal' if same else 'DIFFER'}"
     except Exception as e:  # noqa: BLE001
         ok, msg = False, repr(e)[:200]
     bad += not ok
