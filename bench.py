@@ -220,6 +220,10 @@ def main():
     ap.add_argument("--partition", default="longest-axis", choices=["longest-axis", "y", "x", "z", "octants", "xz-columns", "y-x"],
                     help="--gpus N > 1, strong scaling: the shape of the static particle partition (claymore_amd.scenes.PARTITION_SHAPES; "
                          "profiles/r06_mgsp_partition.txt: slabs along the longest axis are the best cut while the column stands, x slabs once it has collapsed)")
+    ap.add_argument("--equal-count", action="store_true",
+                    help="--gpus N > 1, strong scaling: cut the column into exactly equal particle counts instead of moving the cut planes to the nearest "
+                         "particle-block faces (default: block-aligned pieces within 10 %% of the equal share - no block is shared by two ranks at the start: "
+                         "C3 cut 8 ways along y is 10 890 instead of 11 979 particle blocks on the largest rank)")
     ap.add_argument("--flow-start", type=int, default=3000,
                     help="N = 1, default scene: after the timed window the run goes on to this substep and a second short window is timed "
                          "inside the flow (reported as roofline.flow; 0 = skip)")
@@ -399,9 +403,10 @@ def main():
             return objs[0]
 
         stage["at"] = "ncclCommInitRank"
+        from claymore_amd import mgsp as _mgsp
         if args.partition != "longest-axis":
-            from claymore_amd import mgsp as _mgsp
             _mgsp.PARTITION_SHAPE = args.partition
+        _mgsp.ALIGN_TO_BLOCKS = not args.equal_count   # (strong scaling: the cut planes are particle-block faces; weak scaling is prepartitioned)
         sim = MgspGroupRank(sc, rank, world, device=local_rank, bootstrap=bootstrap, prepartitioned=weak)
         if rank == 0:
             sys.stderr.write(f"bench.py: RCCL communicator up, world {world} (this rank {rank})\n")
@@ -446,7 +451,7 @@ def main():
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "particles": n_total, "dt": dt,
                        "parallelism": "single GPU" if not use_mgsp else
-                       f"mgsp static particle partition x{world} ({'one column per rank' if weak else 'equal-count pieces of the one column, shape ' + (args.partition if args.partition != 'longest-axis' else 'slabs along the longest axis (y)')}), C++ driver on RCCL",
+                       f"mgsp static particle partition x{world} ({'one column per rank' if weak else ('equal-count' if args.equal_count else 'block-aligned') + ' pieces of the one column, shape ' + (args.partition if args.partition != 'longest-axis' else 'slabs along the longest axis (y)')}), C++ driver on RCCL",
                        "blocks": blocks, "phases_ms": phases, **({"oversubscribed": "ranks share GPUs (debug launch, not a measurement)"} if args.oversubscribe else {})},
             "headline_window": "timed",   # which window roofline.frac / kernel_ms describe: "flow" once the flow window has run (below); `value` / ms_per_step are ALWAYS the timed K substeps (= roofline.rest then)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -35,26 +35,33 @@ ROW = 3 + 256  # one halo record: key (3 x int32) + grid block (4 x 64 x f32)
 PARTITION_SHAPE = None  # None: slabs along every model's longest axis; or a key of scenes.PARTITION_SHAPES ("y", "x", "z", "octants", ...): set by bench.py / the tools
 
 
-def partition_scene(scene, rank, world, axis=None, shape=None):
+ALIGN_TO_BLOCKS = False  # True (bench.py's strong scaling, the tools): the slabs' cut planes are moved to the nearest particle-block faces (scenes.split_slabs)
+
+
+def partition_scene(scene, rank, world, axis=None, shape=None, align=None):
     """Static particle partition: every model is cut into `world` equal-count pieces of the initial lattice.  Default: slabs along the
     model's LONGEST axis (axis=None): slabs as thick as possible keep the interfaces - the halo blocks that have to be computed first, sent
     and reduced every substep - small against the interior that hides the exchange (the C3 column of 128 x 306 x 128 cells cut 8 ways along
     x would be 4 blocks thick, i.e. almost all halo; along y it is 9.5 blocks thick).  `shape` (or the module's PARTITION_SHAPE) names another
-    cut of scenes.PARTITION_SHAPES - x / z slabs, octants, ... - compared in tools/mgsp_strong_local.py (profiles/r06_mgsp_partition.txt)."""
+    cut of scenes.PARTITION_SHAPES - x / z slabs, octants, ... - compared in tools/mgsp_strong_local.py (profiles/r06_mgsp_partition.txt).
+    `align` (default: the module's ALIGN_TO_BLOCKS): slabs whose cut planes are particle-block faces (scenes.split_slabs: pieces within 10 % of the
+    equal share, no block shared by two ranks at the start)."""
     shape = shape if shape is not None else PARTITION_SHAPE
+    align = ALIGN_TO_BLOCKS if align is None else align
+    block = scenes.block_faces(scene["bits"]) if align and "bits" in scene else None
     sc = dict(scene)
     sc["models"] = []
     for m in scene["models"]:
         if shape is not None:
             mm = dict(m)
-            mm["xyz"] = scenes.split_boxes(m["xyz"], scenes.PARTITION_SHAPES[shape](world))[rank]
+            mm["xyz"] = scenes.split_boxes(m["xyz"], scenes.PARTITION_SHAPES[shape](world), block=block)[rank]
             sc["models"].append(mm)
             continue
         ax = axis
         if ax is None:
             xyz = m["xyz"]
             ax = int(np.argmax(xyz.max(axis=0) - xyz.min(axis=0))) if xyz.shape[0] else 0
-        part = scenes.split_slabs(m["xyz"], world, ax)[rank]
+        part = scenes.split_slabs(m["xyz"], world, ax, block=block)[rank]
         mm = dict(m)
         mm["xyz"] = part
         sc["models"].append(mm)

@@ -133,23 +133,51 @@ def fluid_dam(bits=10, size_cells=(256, 192, 256), min_corner=(12, 12, 12)):
             "models": [{"material": J_FLUID, "xyz": lattice_box(bits, lo, hi), "v0": (0, 0, 0), "params": {}}]}
 
 
-def split_slabs(xyz, parts, axis=0):
-    """Static particle partition of MGSP: equal-count slabs of the initial lattice along `axis`."""
+def split_slabs(xyz, parts, axis=0, block=None, tolerance=0.10):
+    """Static particle partition of MGSP: equal-count slabs of the initial lattice along `axis`.
+
+    block = (origin, width): the particle blocks' faces along the axis lie at origin + k * width (block_faces()).  The equal-count cuts are then
+    moved to the nearest face, so that no particle block is shared by two ranks at the start: a slab whose two cut planes pass through blocks
+    owns two layers of half-filled blocks, and G2P2G's cost is per iteration of a block, not per particle (C3 cut 8 ways along y: 77 block layers,
+    9.6 per rank - an equal-count slab touches 11 layers, an aligned one holds 9 or 10).  Kept only if no piece grows beyond (1 + tolerance) of
+    the equal share (and none is empty); otherwise the equal-count cut stands."""
     col = xyz[:, axis]
-    if col.size < 2 or bool(np.all(col[1:] >= col[:-1])):  # the lattice samplers emit particles sorted along x
-        bounds = np.linspace(0, xyz.shape[0], parts + 1).astype(np.int64)
+    n = xyz.shape[0]
+    sorted_already = col.size < 2 or bool(np.all(col[1:] >= col[:-1]))  # the lattice samplers emit particles sorted along x
+    bounds = np.linspace(0, n, parts + 1).astype(np.int64)
+    if block is not None and parts > 1 and n >= parts:
+        order = None if sorted_already else np.argsort(col, kind="stable")
+        cs = col if sorted_already else col[order]
+        origin, width = block
+        cuts = 0.5 * (cs[bounds[1:-1] - 1].astype(np.float64) + cs[bounds[1:-1]].astype(np.float64))  # between the two particles an equal-count cut separates
+        faces = origin + np.round((cuts - origin) / width) * width
+        snapped = np.concatenate([[0], np.searchsorted(cs, faces.astype(cs.dtype), side="left"), [n]]).astype(np.int64)
+        sizes = np.diff(snapped)
+        if sizes.min() > 0 and sizes.max() <= (1.0 + tolerance) * n / parts:
+            bounds = snapped
+        if order is not None:
+            return [np.ascontiguousarray(xyz[order[bounds[i]:bounds[i + 1]]]) for i in range(parts)]
+        return [np.ascontiguousarray(xyz[bounds[i]:bounds[i + 1]]) for i in range(parts)]
+    if sorted_already:
         return [np.ascontiguousarray(xyz[bounds[i]:bounds[i + 1]]) for i in range(parts)]
     order = np.argsort(col, kind="stable")
     return [np.ascontiguousarray(xyz[idx]) for idx in np.array_split(order, parts)]
 
 
-def split_boxes(xyz, shape):
+def block_faces(bits):
+    """(origin, width) of the particle blocks' faces along any axis, in world units: a particle at x belongs to block (lround(x / dx) - 2) / 4
+    (particle_block_key, mpm_kernels.hpp; reference: Projects/GMPM/mgmpm_kernels.cuh:21-36), i.e. block k holds x / dx in [4 k + 1.5, 4 k + 5.5)."""
+    dx = 1.0 / (1 << bits)
+    return 1.5 * dx, 4.0 * dx
+
+
+def split_boxes(xyz, shape, block=None):
     """Static particle partition into shape = (nx, ny, nz) equal-count boxes of the initial lattice: nx slabs along x, each cut into ny along
-    y, each of those into nz along z (the reference's scenarios put their per-GPU bodies side by side in x and z, Projects/MGSP/mgsp.cu:52-57,
+    y, each of those into nz along z; block: cut planes moved to particle-block faces (split_slabs) (the reference's scenarios put their per-GPU bodies side by side in x and z, Projects/MGSP/mgsp.cu:52-57,
     :67-72; SURVEY 8(e): "slabs / octants").  Returns the nx * ny * nz particle arrays, x-major."""
     parts = [xyz]
     for axis, n in enumerate(shape):
-        parts = [q for p in parts for q in split_slabs(p, n, axis)] if n > 1 else parts
+        parts = [q for p in parts for q in split_slabs(p, n, axis, block=block)] if n > 1 else parts
     return parts
 
 

@@ -47,3 +47,34 @@ def test_weak_scaling_columns_layout():
         assert False
     except ValueError:
         pass
+
+
+def test_block_aligned_slabs_share_no_particle_block():
+    """scenes.split_slabs(block=...): the cut planes of bench.py's strong-scaling partition are particle-block faces - no block of the initial
+    lattice is shared by two ranks, the pieces stay within 10 % of the equal share, and a cut that cannot keep that bound stays equal-count."""
+    bits = 8
+    dx = 1.0 / (1 << bits)
+    xyz = scenes.lattice_box(bits, (13, 5, 19), (13 + 6, 5 + 154, 19 + 5))   # 154 cells = 38.5 block layers along y (C3: 77 layers, 8 ranks)
+    block = scenes.block_faces(bits)
+
+    def layers(p, axis):
+        return set(((np.rint(p[:, axis] / np.float32(dx)).astype(np.int64) - 2) // 4).tolist())
+
+    for world in (2, 4, 8):
+        parts = scenes.split_slabs(xyz, world, 1, block=block)
+        assert sum(p.shape[0] for p in parts) == xyz.shape[0]
+        assert max(p.shape[0] for p in parts) <= 1.10 * xyz.shape[0] / world
+        ls = [layers(p, 1) for p in parts]
+        for a in range(world):
+            for b in range(a + 1, world):
+                assert not (ls[a] & ls[b]), (world, a, b)
+        eq = scenes.split_slabs(xyz, world, 1)
+        assert sum(len(layers(p, 1)) for p in eq) >= sum(len(s) for s in ls)
+    # a body two blocks thick cannot be cut 8 ways on block faces: the equal-count cut stands
+    thin = scenes.lattice_box(bits, (12, 12, 12), (20, 20, 20))
+    parts = scenes.split_slabs(thin, 8, 1, block=block)
+    assert max(p.shape[0] for p in parts) - min(p.shape[0] for p in parts) <= 1
+    # the partition is a partition: same multiset of particles
+    parts = scenes.split_slabs(xyz, 4, 1, block=block)
+    allp = np.concatenate(parts)
+    assert np.array_equal(np.sort(allp.view([("x", "f4"), ("y", "f4"), ("z", "f4")]), axis=0), np.sort(np.ascontiguousarray(xyz).view([("x", "f4"), ("y", "f4"), ("z", "f4")]), axis=0))

@@ -8,7 +8,7 @@ mkdir -p $O
 export TMPDIR=/tmp
 f() { grep -v "amdgpu.ids\|^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path"; }
 bash tools/gpu_final_r06.sh "" 2>&1 | tail -6
-{ cat build_stamp.txt; timeout 900 python tools/mgsp_strong_local.py 20 1,2,4,8 y,x,octants,xz-columns 0 2>&1 | f; timeout 1500 python tools/mgsp_strong_local.py 20 1,2,4,8 y,x,octants,xz-columns 3000 2>&1 | f; } > $O/mgsp_partition.txt
+{ cat build_stamp.txt; timeout 900 python tools/mgsp_strong_local.py 20 1,2,4,8 y,y+aligned,x,octants,xz-columns 0 2>&1 | f; timeout 1500 python tools/mgsp_strong_local.py 20 1,2,4,8 y,y+aligned,x,octants,xz-columns 3000 2>&1 | f; } > $O/mgsp_partition.txt
 { cat build_stamp.txt; timeout 600 python tools/mgsp_rank_alone.py 40 2,4,8 2>&1 | f; } > $O/mgsp_rank_alone.txt
 bash tools/gpu_rank_alone_prof.sh > /dev/null 2>&1
 { echo "# $(cat build_stamp.txt): tools/gpu_rank_alone_prof.sh (1/8 slab of C3 on the group driver, world 1 on RCCL, 40 substeps)"; cat gpurun_out/rank_alone_trace.txt; } > $O/rank_alone_kernel_trace.txt

@@ -46,10 +46,11 @@ w1, tm1, pb1 = plain(sc)
 print(f"# C3 whole column: plain engine {w1:.3f} ms per substep (device {tm1.total_ms:.3f}, g2p2g {tm1.g2p2g_ms:.3f}); {pb1} particle blocks; warm-up 5 + {steps} timed substeps")
 gw, gg = group(sc)
 print(f"  world 1 group driver (RCCL, one rank) on the whole column: {gw:.3f} ms per substep (g2p2g {gg:.3f})")
-for world in worlds:
-    local = partition_scene(sc, world // 2, world)
+for world, align in [(w, al) for w in worlds for al in (False, True)]:
+    # equal-count slabs: a middle slab; block-aligned slabs (scenes.split_slabs, bench.py's default): the piece with the most particles
+    local = partition_scene(sc, world // 2, world, align=False) if not align else max((partition_scene(sc, r, world, align=True) for r in range(world)), key=scenes.total_particles)
     n = scenes.total_particles(local)
     a, tma, pba = plain(local)
     b, bg = group(local)
-    print(f"1/{world} slab ({n} particles, {pba} particle blocks) alone: plain engine {a:.3f} ms per substep (device {tma.total_ms:.3f}, g2p2g {tma.g2p2g_ms:.3f}, partition {tma.partition_ms:.3f}) | "
+    print(f"1/{world} slab{', block-aligned (the largest piece)' if align else ''} ({n} particles, {pba} particle blocks) alone: plain engine {a:.3f} ms per substep (device {tma.total_ms:.3f}, g2p2g {tma.g2p2g_ms:.3f}, partition {tma.partition_ms:.3f}) | "
           f"group driver {b:.3f} (g2p2g {bg:.3f}) | T1 / plain = {w1 / a:.2f}, T1 / group = {w1 / b:.2f} of {world}")

@@ -32,6 +32,8 @@ dt = sc["dt"]
 t1 = None
 print(f"# C3: {n_total} sand particles, 512^3; {'at rest' if not flow else f'in the flow ({flow} substeps first)'}; warm-up 5 + {steps} timed substeps; every rank a context on one GPU")
 for shape, world in [(None, 1)] * (1 in worlds) + [(sh, w) for sh in shapes for w in worlds if w > 1]:
+    mgsp_mod.ALIGN_TO_BLOCKS = bool(shape) and shape.endswith("+aligned")   # "y+aligned": the cut planes moved to particle-block faces (scenes.split_slabs)
+    shape = shape[:-len("+aligned")] if mgsp_mod.ALIGN_TO_BLOCKS else shape
     mgsp_mod.PARTITION_SHAPE = shape
     if world == 1:
         eng = build_engine(sc)
@@ -81,7 +83,7 @@ for shape, world in [(None, 1)] * (1 in worlds) + [(sh, w) for sh in shapes for 
     tot = sum(o["particles"] for o in out)
     assert tot == n_total and sum(o["lost"] for o in out) == 0 and sum(o["disc"] for o in out) == 0, out
     pb = sum(o["pb"] for o in out)
-    print(f"shape {shape} {scenes.PARTITION_SHAPES[shape](world)} world {world}: wall {wall:.3f} ms per substep for ALL ranks on one GPU -> {wall / world:.3f} per rank (lower bound of the {world}-GPU substep); "
+    print(f"shape {shape}{' block-aligned' if mgsp_mod.ALIGN_TO_BLOCKS else ''} {scenes.PARTITION_SHAPES[shape](world)} world {world}: wall {wall:.3f} ms per substep for ALL ranks on one GPU -> {wall / world:.3f} per rank (lower bound of the {world}-GPU substep); "
           f"work vs 1 rank x{wall / t1:.3f}; speed-up bound {world * t1 / wall:.2f} of {world}" if t1 else f"world {world}: wall {wall:.3f}")
     print(f"         particle blocks {pb} over all ranks; per rank: particles {min(o['n'] for o in out)}-{max(o['n'] for o in out)}, particle blocks {min(o['pb'] for o in out)}-{max(o['pb'] for o in out)}, "
           f"halo particle blocks {min(o['halo_pb'] for o in out)}-{max(o['halo_pb'] for o in out)} ({100.0 * sum(o['halo_pb'] for o in out) / pb:.0f} % of all), "
